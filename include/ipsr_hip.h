@@ -1,0 +1,118 @@
+/*
+ * ipsr_hip.h — C-ABI of libipsr_hip.so, the MI355X (gfx950) implementation of the
+ * IPSR / CSA patch-attention hot path of Image-Processing-Systems-Laboratory/DeepInPainting.
+ *
+ * The reference has NO native/FFI interface (it is pure Python on torch); its "plugin API" for this
+ * path is the Python surface IPSRFunction.apply / IPSR_model / InnerCos / util.* .  Each entry point
+ * below therefore cites the reference Python code it replaces (file:line under /root/reference).
+ * The Python host side (deepinpainting_amd/models, deepinpainting_amd/util) binds these through
+ * ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless marked [host].
+ *   - all tensors are dense, row-major, NCHW:  x[b][c][y][x]  ->  ((b*C + c)*h + y)*w + x.
+ *     N = number of patches = nH*nW with nH = (h-patch)/stride+1 (reference util/util.py:95-98).
+ *     Only patch == 1, stride == 1 is implemented in this round (the reference itself raises for
+ *     shift_sz != 1, models/IPSRFunction.py:134); other values return IPSR_ERR_UNSUPPORTED.
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.  No entry point
+ *     allocates, frees or synchronises: the caller owns every buffer incl. the workspace whose size
+ *     the matching *_workspace_bytes() query returns.  All entry points are re-entrant per stream.
+ *   - return value: 0 = ok, <0 = error (codes below); ipsr_last_error() returns a thread-local
+ *     message for the last failing call on this thread.
+ *   - arithmetic is fp32 throughout with a FIXED summation order (documented in DESIGN.md §4 and
+ *     restated in oracle/ipsr_oracle.c), so results are bit-reproducible run to run.
+ */
+#ifndef IPSR_HIP_H
+#define IPSR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPSR_OK                 0
+#define IPSR_ERR_INVALID       -1   /* bad argument (null pointer, non-positive size ...)          */
+#define IPSR_ERR_UNSUPPORTED   -2   /* patch/stride/size outside what this build implements       */
+#define IPSR_ERR_WORKSPACE     -3   /* workspace too small                                        */
+#define IPSR_ERR_LAUNCH        -4   /* hipLaunchKernel / hipMemsetAsync reported an error         */
+
+/* ABI version: bumped whenever a signature changes. */
+int ipsr_abi_version(void);
+/* Thread-local message of the last failing call ("" if none). */
+const char* ipsr_last_error(void);
+
+/* ---- K1  feature-mask pyramid --------------------------------------------------------------
+ * replaces util.cal_feat_mask (util/util.py:68-84): `layers` x Conv2d(1,1,4,2,1,weight=1/16) on the
+ * 0/1 mask, then (> threshold) after the LAST conv only, returned as bytes.
+ * mask  [H,W] u8 (0/1)  ->  feat [h,w] u8, h = H after `layers` halvings ((H-2)/2+1 each). */
+size_t ipsr_feat_mask_workspace_bytes(int H, int W, int layers);
+int ipsr_feat_mask(const uint8_t* mask, int H, int W, int layers, float threshold,
+                   uint8_t* feat, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K2  index prep -------------------------------------------------------------------------
+ * replaces util.cal_mask_given_mask_thred (util/util.py:88-161): raster scan of the feature mask;
+ * flag[i] = (sum of mask over patch i >= mask_thred); mask_point_idx = raster-ordered list of the
+ * flagged patches (first *count entries valid; the rest is filled with -1).
+ * (nonmask_point_idx == arange(N) and the dead flatten_offsets are produced by the Python host.) */
+int ipsr_index_prep(const uint8_t* feat, int h, int w, int patch, int stride, int mask_thred,
+                    int32_t* flag /*[N]*/, int32_t* mask_point_idx /*[N]*/, int32_t* count /*[1]*/,
+                    void* stream);
+
+/* ---- K3  patch unfold + L2 normalisation ----------------------------------------------------
+ * replaces NonparametricShift._extract_patches/_build (util/NonparametricShift.py:36-73):
+ * inv[b][k] = 1/(||x[b,:,k]||_2 + 1e-8);  xn[b][c][k] = x[b][c][k] * inv[b][k]   (patch == 1). */
+int ipsr_patch_normalize(const float* x, int B, int C, int N, float* xn, float* inv, void* stream);
+
+/* ---- K4+K5  cross-correlation + arg-max ------------------------------------------------------
+ * replaces conv_enc(ref) + MaxCoord.update_output (models/IPSRFunction.py:59-65,
+ * util/MaxCoord.py:16-28):  S[k][q] = <xn[:,k], ref[:,q]>;  ind[q] = argmax_k S[k][q] (lowest k on
+ * ties), vmax[q] = max_k S[k][q].  S is never written unless S_out != NULL (tests only). */
+size_t ipsr_corr_argmax_workspace_bytes(int B, int C, int N);
+int ipsr_corr_argmax(const float* xn, const float* ref, int B, int C, int N,
+                     int32_t* ind /*[B,N]*/, float* vmax /*[B,N]*/, float* S_out /*[B,N,N] or NULL*/,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---- whole layer forward (K3..K7) -------------------------------------------------------------
+ * replaces IPSRFunction.forward (models/IPSRFunction.py:13-140).
+ *   x, ref            [B,C,h,w] fp32           (ref = ref.relu4_3)
+ *   mask_point_idx    [M] i32  raster-ordered masked patch positions, shared by the whole batch
+ *                     (reference semantics: one mask per batch, models/IPSR.py:36)
+ *   out               [B,C,h,w] fp32
+ *   ind, vmax         [B,N]     arg-max / max of the correlation (kept for inspection + backward)
+ *   attn_rows         [B,M,N]   the reference's `in_attention` rows (IPSRFunction.py:76,123-125)
+ *   bwd_index         [B, ipsr_bwd_index_ints(N,M)] i32: what ipsr_backward needs of
+ *                     trunc(kbar) (IPSRFunction.py:36,134) in sparse form. */
+size_t ipsr_bwd_index_ints(int N, int M);
+size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride);
+int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
+                 int B, int C, int h, int w, int patch, int stride,
+                 float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K8  backward -----------------------------------------------------------------------------
+ * replaces IPSRFunction.backward (models/IPSRFunction.py:144-178):
+ * grad_in[b,:,k] = g[b,:,k] + triple_w * sum_q trunc(A[b])[q][k] * g[b,:,q]. */
+int ipsr_backward(const float* grad_out, const int32_t* mask_point_idx, int M,
+                  const float* attn_rows, const int32_t* bwd_index, float triple_w,
+                  int B, int C, int h, int w, float* grad_in, void* stream);
+
+/* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
+ * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
+ * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.
+ * x has Cx >= Cuse channels per sample (InnerCos2 reads the first 512 of 1024, InnerCos2.py:38);
+ * target is [B,Cuse,N].  loss is one fp32 on the device.  The backward entry point returns
+ * d loss / d x (only for the first Cuse channels; the rest is zero-filled). */
+size_t innercos_workspace_bytes(int B, int Cuse, int N);
+int innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask /*[N] fp32*/,
+                  const float* target, float strength, float* loss /*[1]*/,
+                  void* ws, size_t ws_bytes, void* stream);
+int innercos_loss_backward(const float* x, int B, int Cx, int Cuse, int N, const float* mask,
+                           const float* target, float strength, const float* grad_loss /*[1]*/,
+                           float* grad_x /*[B,Cx,N]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPSR_HIP_H */

@@ -1,0 +1,349 @@
+/*
+ * ipsr_oracle.c — CPU restatement (ORACLE) of the IPSR patch-attention hot path of
+ * Image-Processing-Systems-Laboratory/DeepInPainting.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library, and only as the checker / the reported CPU baseline — never as a product
+ * path.  The product (deepinpainting_amd) fails loudly when libipsr_hip.so is missing.
+ *
+ * Parity pinning: the reference holds no tests or golden vectors.  This restatement
+ * is pinned against outputs of the reference ITSELF, run in the build container by
+ * oracle/gen_golden.py (which imports /root/reference read-only) and committed as fixtures under
+ * tests/golden/; tests/test_oracle_golden.py checks every function below against them.
+ *
+ * Entry points mirror include/ipsr_hip.h one-to-one with a `_cpu` suffix and HOST pointers, so the
+ * same ctypes harness drives both.  Each function cites the reference code it restates
+ * (file:line under /root/reference).
+ *
+ * Canonical arithmetic.  The reference leaves fp32 summation order to its BLAS/conv backend; the
+ * restatement fixes one order per reduction (identical to what the HIP kernels do) so
+ * that HIP-vs-oracle parity can be asserted bit-for-bit, incl. the arg-max indices:
+ *   - correlation / reconstruction dot products: one fmaf chain in ascending reduction index
+ *     (what v_mfma_f32_32x32x2_f32 computes when K is walked in order);
+ *   - patch norm: 8 contiguous channel segments, fmaf chain inside each, partials added in order;
+ *   - recurrence dot <u, o>: 64 "lanes", lane j owns the 8-channel chunks ch with ch % 64 == j
+ *     (fmaf chain, ascending), then an xor-butterfly over the 64 partials;
+ *   - everything else is element-wise with every product and sum rounded separately (no FMA
+ *     contraction: build with -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define IPSR_OK 0
+#define IPSR_ERR_INVALID -1
+#define IPSR_ERR_UNSUPPORTED -2
+
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(IPSR_ORACLE_NO_CLONES)
+#define HOT __attribute__((target_clones("default", "avx2,fma")))
+#else
+#define HOT
+#endif
+
+int ipsr_oracle_abi_version(void) { return 1; }
+
+/* ---- K1: util.cal_feat_mask (util/util.py:68-84) -------------------------------------------
+ * The reference convolves the 0/1 mask with all-1/16 4x4 kernels (stride 2, zero padding 1) `layers`
+ * times in fp32 and thresholds once at the end.  Every intermediate is count/16^level with
+ * count <= 16^level, exactly representable in fp32 for layers <= 5, so integer counting is exact. */
+static int out_dim(int n) { return (n + 2 - 4) / 2 + 1; }
+
+int ipsr_feat_mask_cpu(const uint8_t* mask, int H, int W, int layers, float threshold, uint8_t* feat)
+{
+    if (!mask || !feat || H < 2 || W < 2 || layers < 1 || layers > 5) return IPSR_ERR_INVALID;
+    int h = H, w = W;
+    uint32_t* cur = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)H * W);
+    uint32_t* nxt = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)H * W);
+    if (!cur || !nxt) { free(cur); free(nxt); return IPSR_ERR_INVALID; }
+    for (size_t i = 0; i < (size_t)H * W; ++i) cur[i] = mask[i] ? 1u : 0u;
+    for (int l = 0; l < layers; ++l) {
+        int oh = out_dim(h), ow = out_dim(w);
+        if (oh < 1 || ow < 1) { free(cur); free(nxt); return IPSR_ERR_INVALID; }
+        for (int y = 0; y < oh; ++y)
+            for (int x = 0; x < ow; ++x) {
+                uint32_t s = 0;
+                for (int dy = 0; dy < 4; ++dy) {
+                    int yy = 2 * y - 1 + dy;
+                    if (yy < 0 || yy >= h) continue;
+                    for (int dx = 0; dx < 4; ++dx) {
+                        int xx = 2 * x - 1 + dx;
+                        if (xx < 0 || xx >= w) continue;
+                        s += cur[(size_t)yy * w + xx];
+                    }
+                }
+                nxt[(size_t)y * ow + x] = s;
+            }
+        uint32_t* t = cur; cur = nxt; nxt = t;
+        h = oh; w = ow;
+    }
+    float scale = 1.0f;
+    for (int l = 0; l < layers; ++l) scale *= (1.0f / 16.0f);
+    for (size_t i = 0; i < (size_t)h * w; ++i) feat[i] = ((float)cur[i] * scale > threshold) ? 1 : 0;
+    free(cur); free(nxt);
+    return IPSR_OK;
+}
+
+/* ---- K2: util.cal_mask_given_mask_thred (util/util.py:88-161) ------------------------------ */
+int ipsr_index_prep_cpu(const uint8_t* feat, int h, int w, int patch, int stride, int mask_thred,
+                        int32_t* flag, int32_t* mask_point_idx, int32_t* count)
+{
+    if (!feat || !flag || !mask_point_idx || !count || patch < 1 || stride < 1 || h < patch || w < patch)
+        return IPSR_ERR_INVALID;
+    int nH = (h - patch) / stride + 1, nW = (w - patch) / stride + 1;  /* util.py:95-96 */
+    int N = nH * nW, m = 0;
+    for (int i = 0; i < N; ++i) {
+        int py = i / nW, px = i % nW, s = 0;                            /* util.py:114-118 */
+        for (int dy = 0; dy < patch; ++dy)
+            for (int dx = 0; dx < patch; ++dx) s += feat[(size_t)(py * stride + dy) * w + px * stride + dx];
+        flag[i] = (s >= mask_thred) ? 1 : 0;                            /* util.py:132-135 */
+        if (flag[i]) mask_point_idx[m++] = i;
+    }
+    for (int i = m; i < N; ++i) mask_point_idx[i] = -1;
+    *count = m;
+    return IPSR_OK;
+}
+
+/* ---- K3: NonparametricShift._extract_patches/_build (util/NonparametricShift.py:36-73) ----- */
+HOT int ipsr_patch_normalize_cpu(const float* x, int B, int C, int N, float* xn, float* inv)
+{
+    if (!x || !xn || !inv || B < 1 || C < 1 || N < 1) return IPSR_ERR_INVALID;
+    const int L = (C + 7) / 8;
+    for (int b = 0; b < B; ++b) {
+        const float* xb = x + (size_t)b * C * N;
+        float* xnb = xn + (size_t)b * C * N;
+        for (int k = 0; k < N; ++k) {
+            float tot = 0.0f;
+            for (int s = 0; s < 8; ++s) {
+                float part = 0.0f;
+                int c1 = (s + 1) * L < C ? (s + 1) * L : C;
+                for (int c = s * L; c < c1; ++c) part = fmaf(xb[(size_t)c * N + k], xb[(size_t)c * N + k], part);
+                tot = (s == 0) ? part : tot + part;
+            }
+            /* enc_patches[i]*(1/(enc_patches[i].norm(2)+1e-8))   NonparametricShift.py:40 */
+            float iv = 1.0f / (sqrtf(tot) + 1e-8f);
+            inv[(size_t)b * N + k] = iv;
+        }
+        for (int c = 0; c < C; ++c)
+            for (int k = 0; k < N; ++k) xnb[(size_t)c * N + k] = xb[(size_t)c * N + k] * inv[(size_t)b * N + k];
+    }
+    return IPSR_OK;
+}
+
+/* ---- K4+K5: conv_enc(ref) + MaxCoord (IPSRFunction.py:59-65, MaxCoord.py:16-28) ------------ */
+HOT int ipsr_corr_argmax_cpu(const float* xn, const float* ref, int B, int C, int N,
+                             int32_t* ind, float* vmax, float* S_out)
+{
+    if (!xn || !ref || !ind || !vmax || B < 1 || C < 1 || N < 1) return IPSR_ERR_INVALID;
+    /* every (b, q-block) is independent, so threading changes nothing in the results */
+    enum { QB = 256 };
+    const int nqb = (N + QB - 1) / QB;
+#pragma omp parallel for schedule(static)
+    for (int job = 0; job < B * nqb; ++job) {
+        const int b = job / nqb, q0 = (job % nqb) * QB;
+        const int nq = N - q0 < QB ? N - q0 : QB;
+        const float* A = xn + (size_t)b * C * N;
+        const float* R = ref + (size_t)b * C * N + q0;
+        float acc[QB];
+        float* best = vmax + (size_t)b * N + q0;
+        int32_t* bi = ind + (size_t)b * N + q0;
+        for (int k = 0; k < N; ++k) {
+            for (int q = 0; q < nq; ++q) acc[q] = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float a = A[(size_t)c * N + k];
+                const float* r = R + (size_t)c * N;
+                for (int q = 0; q < nq; ++q) acc[q] = fmaf(a, r[q], acc[q]);
+            }
+            if (S_out) memcpy(S_out + ((size_t)b * N + k) * N + q0, acc, sizeof(float) * nq);
+            if (k == 0) for (int q = 0; q < nq; ++q) { best[q] = acc[q]; bi[q] = 0; }
+            else for (int q = 0; q < nq; ++q) if (acc[q] > best[q]) { best[q] = acc[q]; bi[q] = k; }  /* first max wins */
+        }
+    }
+    return IPSR_OK;
+}
+
+/* 64-lane dot used by the coherent-attention recurrence (IPSRFunction.py:109-118). */
+HOT static float lane_dot(const float* u, const float* o, int C)
+{
+    float p[64];
+    for (int j = 0; j < 64; ++j) p[j] = 0.0f;
+    const int nch = (C + 7) / 8;
+    for (int ch = 0; ch < nch; ++ch) {
+        int j = ch & 63;
+        int c1 = ch * 8 + 8 < C ? ch * 8 + 8 : C;
+        float a = p[j];
+        for (int c = ch * 8; c < c1; ++c) a = fmaf(u[c], o[c], a);
+        p[j] = a;
+    }
+    for (int s = 1; s < 64; s <<= 1) {
+        float t[64];
+        for (int j = 0; j < 64; ++j) t[j] = p[j] + p[j ^ s];
+        memcpy(p, t, sizeof(p));
+    }
+    return p[0];
+}
+
+size_t ipsr_bwd_index_ints_cpu(int N, int M) { return (size_t)2 * N + 2 + (size_t)M; }
+
+/* ---- whole layer forward: IPSRFunction.forward (models/IPSRFunction.py:13-140) -------------- */
+HOT int ipsr_forward_cpu(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
+                         int B, int C, int h, int w, int patch, int stride,
+                         float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index)
+{
+    if (!x || !ref || !out || !ind || !vmax || B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return IPSR_ERR_INVALID;
+    if (patch != 1 || stride != 1) return IPSR_ERR_UNSUPPORTED;   /* reference raises too: IPSRFunction.py:134 */
+    if (M > 0 && (!mask_point_idx || !attn_rows)) return IPSR_ERR_INVALID;
+    const int N = h * w;
+    float* xn = (float*)malloc(sizeof(float) * (size_t)B * C * N);
+    float* inv = (float*)malloc(sizeof(float) * (size_t)B * N);
+    int rc = ipsr_patch_normalize_cpu(x, B, C, N, xn, inv);
+    if (rc == IPSR_OK) rc = ipsr_corr_argmax_cpu(xn, ref, B, C, N, ind, vmax, NULL);
+    if (rc != IPSR_OK) { free(xn); free(inv); return rc; }
+
+    int8_t* is_mask = (int8_t*)calloc(N, 1);
+    for (int l = 0; l < M; ++l) is_mask[mask_point_idx[l]] = 1;
+    float* o = (float*)malloc(sizeof(float) * C);
+    float* u = (float*)malloc(sizeof(float) * C);
+    float* kk = (float*)malloc(sizeof(float) * C);
+
+    for (int b = 0; b < B; ++b) {
+        const float* xb = x + (size_t)b * C * N;
+        const float* xnb = xn + (size_t)b * C * N;
+        const int32_t* indb = ind + (size_t)b * N;
+        const float* vb = vmax + (size_t)b * N;
+        float* outb = out + (size_t)b * C * N;
+        float* attn = attn_rows ? attn_rows + (size_t)b * M * N : NULL;
+
+        /* coherent-attention recurrence over the masked positions in raster order (:82-129) */
+        for (int l = 0; l < M; ++l) {
+            const int q = mask_point_idx[l];
+            const int kq = indb[q];
+            for (int c = 0; c < C; ++c) kk[c] = xb[(size_t)c * N + kq];          /* known_region  :94 */
+            float* a = attn + (size_t)l * N;
+            if (l == 0) {                                                         /* :98-101 */
+                memcpy(o, kk, sizeof(float) * C);
+                for (int k = 0; k < N; ++k) a[k] = 0.0f;
+                a[kq] = 1.0f;
+            } else {
+                for (int c = 0; c < C; ++c) u[c] = xnb[(size_t)c * N + q];        /* value_2 :109 */
+                const float at = lane_dot(u, o, C);                               /* :116 */
+                const float v = vb[q];                                            /* vamx_mask :70 */
+                const float s = at + v;
+                const float wn = at / s, wo = v / s;                              /* :120-121 */
+                for (int c = 0; c < C; ++c) { float t0 = wn * o[c], t1 = wo * kk[c]; o[c] = t0 + t1; }   /* :122 */
+                const float* ap = attn + (size_t)(l - 1) * N;
+                for (int k = 0; k < N; ++k) a[k] = ap[k] * wn;                    /* :123 */
+                a[kq] = a[kq] + wo;                                               /* :124 */
+            }
+        }
+        /* reconstruction: conv_transpose2d(kbar, raw patches) (:130-133) */
+        for (int q = 0; q < N; ++q)
+            if (!is_mask[q]) { const int kq = indb[q]; for (int c = 0; c < C; ++c) outb[(size_t)c * N + q] = xb[(size_t)c * N + kq]; }
+        for (int l = 0; l < M; ++l) {
+            const int q = mask_point_idx[l];
+            const float* a = attn + (size_t)l * N;
+            for (int c = 0; c < C; ++c) {
+                const float* xr = xb + (size_t)c * N;
+                float acc = 0.0f;
+                for (int k = 0; k < N; ++k) acc = fmaf(a[k], xr[k], acc);
+                outb[(size_t)c * N + q] = acc;
+            }
+        }
+        /* sparse form of trunc(kbar) for the backward (:36,134 — kbar is stored in a LongTensor) */
+        if (bwd_index) {
+            int32_t* col_off = bwd_index + (size_t)b * ipsr_bwd_index_ints_cpu(N, M);
+            int32_t* col_q = col_off + N + 1;
+            int32_t* nz_count = col_q + N;
+            int32_t* nz_rows = nz_count + 1;
+            for (int k = 0; k <= N; ++k) col_off[k] = 0;
+            for (int q = 0; q < N; ++q) if (!is_mask[q]) col_off[indb[q] + 1]++;
+            for (int k = 0; k < N; ++k) col_off[k + 1] += col_off[k];
+            int32_t* fill = (int32_t*)calloc(N, sizeof(int32_t));
+            for (int q = 0; q < N; ++q) col_q[q] = -1;
+            for (int q = 0; q < N; ++q) if (!is_mask[q]) { int k = indb[q]; col_q[col_off[k] + fill[k]++] = q; }
+            free(fill);
+            int nz = 0;
+            for (int l = 0; l < M; ++l) {
+                const float* a = attn + (size_t)l * N;
+                int any = 0;
+                for (int k = 0; k < N; ++k) if (truncf(a[k]) != 0.0f) { any = 1; break; }
+                if (any) nz_rows[nz++] = l;
+            }
+            for (int l = nz; l < M; ++l) nz_rows[l] = -1;
+            *nz_count = nz;
+        }
+    }
+    free(is_mask); free(o); free(u); free(kk); free(xn); free(inv);
+    return IPSR_OK;
+}
+
+/* ---- K8: IPSRFunction.backward (models/IPSRFunction.py:144-178) ------------------------------ */
+int ipsr_backward_cpu(const float* g, const int32_t* mask_point_idx, int M, const float* attn_rows,
+                      const int32_t* bwd_index, float triple_w, int B, int C, int h, int w, float* gin)
+{
+    if (!g || !gin || !bwd_index || B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return IPSR_ERR_INVALID;
+    const int N = h * w;
+    for (int b = 0; b < B; ++b) {
+        const int32_t* col_off = bwd_index + (size_t)b * ipsr_bwd_index_ints_cpu(N, M);
+        const int32_t* col_q = col_off + N + 1;
+        const int32_t nz = col_q[N];
+        const int32_t* nz_rows = col_q + N + 1;
+        const float* attn = attn_rows ? attn_rows + (size_t)b * M * N : NULL;
+        for (int c = 0; c < C; ++c) {
+            const float* gr = g + ((size_t)b * C + c) * N;
+            float* go = gin + ((size_t)b * C + c) * N;
+            for (int k = 0; k < N; ++k) {
+                float acc = 0.0f;
+                for (int e = col_off[k]; e < col_off[k + 1]; ++e) acc = acc + gr[col_q[e]];     /* one-hot rows :129 */
+                for (int i = 0; i < nz; ++i) {                                                  /* masked rows, truncated */
+                    const int l = nz_rows[i];
+                    acc = fmaf(truncf(attn[(size_t)l * N + k]), gr[mask_point_idx[l]], acc);
+                }
+                const float t = acc * triple_w;                                                 /* :173 */
+                go[k] = gr[k] + t;
+            }
+        }
+    }
+    return IPSR_OK;
+}
+
+/* ---- K9: InnerCos.forward / InnerCos2.forward (models/InnerCos.py:30-41, InnerCos2.py:34-46) - */
+int innercos_loss_cpu(const float* x, int B, int Cx, int Cuse, int N, const float* mask,
+                      const float* target, float strength, float* loss)
+{
+    if (!x || !mask || !target || !loss || B < 1 || Cuse < 1 || Cx < Cuse || N < 1) return IPSR_ERR_INVALID;
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < Cuse; ++c) {
+            const float* xr = x + ((size_t)b * Cx + c) * N;
+            const float* tr = target + ((size_t)b * Cuse + c) * N;
+            for (int n = 0; n < N; ++n) {
+                float m = xr[n] * mask[n];           /* InnerCos.py:34 */
+                float d = m * strength - tr[n];      /* :36 */
+                acc += (double)(d * d);
+            }
+        }
+    *loss = (float)(acc / ((double)B * Cuse * N));
+    return IPSR_OK;
+}
+
+int innercos_loss_backward_cpu(const float* x, int B, int Cx, int Cuse, int N, const float* mask,
+                               const float* target, float strength, const float* grad_loss, float* grad_x)
+{
+    if (!x || !mask || !target || !grad_loss || !grad_x || B < 1 || Cuse < 1 || Cx < Cuse || N < 1) return IPSR_ERR_INVALID;
+    const float scale = (*grad_loss) * (2.0f / (float)((double)B * Cuse * N));
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < Cx; ++c) {
+            float* gr = grad_x + ((size_t)b * Cx + c) * N;
+            if (c >= Cuse) { for (int n = 0; n < N; ++n) gr[n] = 0.0f; continue; }
+            const float* xr = x + ((size_t)b * Cx + c) * N;
+            const float* tr = target + ((size_t)b * Cuse + c) * N;
+            for (int n = 0; n < N; ++n) {
+                float m = xr[n] * mask[n];
+                float d = m * strength - tr[n];
+                float ms = mask[n] * strength;
+                gr[n] = (d * scale) * ms;
+            }
+        }
+    return IPSR_OK;
+}
