@@ -1,0 +1,10 @@
+"""deepinpainting_amd — MI355X (gfx950) implementation of the IPSR patch-attention training hot path of
+Image-Processing-Systems-Laboratory/DeepInPainting behind the reference's own Python surface.
+
+    from deepinpainting_amd.models.models import create_model      # reference: models/models.py:2-12
+    from deepinpainting_amd.models.IPSRFunction import IPSRFunction # reference: models/IPSRFunction.py
+
+The compute path is libipsr_hip.so (hand-written HIP, C-ABI in include/ipsr_hip.h).  There is no CPU or
+eager-PyTorch fallback for the layer: if the library is missing the ops raise.
+"""
+__version__ = "0.1.0"

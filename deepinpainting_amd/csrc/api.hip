@@ -1,0 +1,189 @@
+// api.hip — the C-ABI of libipsr_hip.so (declared in include/ipsr_hip.h): argument checks, workspace
+// carving and the launch sequence of the layer.  No allocation, no synchronisation, no global state
+// besides the thread-local error string.
+#include <cstdarg>
+#include <cstdio>
+
+#include "ipsr_common.h"
+
+namespace ipsr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(IPSR_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return IPSR_OK;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct FwdPlan {
+    int N, Cp;
+    size_t xn, xT, inv, corr, wn, wo, flags, total;   // byte sizes of the workspace slices
+};
+
+static FwdPlan plan_forward(int B, int C, int h, int w, int M)
+{
+    FwdPlan p;
+    p.N = h * w;
+    p.Cp = (C + 7) & ~7;
+    const size_t Mx = M > 0 ? M : 1;
+    p.xn = align_up((size_t)B * C * p.N * 4, 256);
+    p.xT = align_up((size_t)B * p.N * p.Cp * 4, 256);
+    p.inv = align_up((size_t)B * p.N * 4, 256);
+    p.corr = align_up(corr_argmax_ws_bytes(B, C, p.N), 256);
+    p.wn = align_up((size_t)B * Mx * 4, 256);
+    p.wo = p.wn;
+    p.flags = align_up((size_t)2 * B * Mx * 4, 256);   // rowflag [B,M] followed by kq [B,M]
+    p.total = p.xn + p.xT + p.inv + p.corr + p.wn + p.wo + p.flags + 256;
+    return p;
+}
+
+}  // namespace ipsr
+
+using namespace ipsr;
+
+extern "C" {
+
+int ipsr_abi_version(void) { return 1; }
+
+const char* ipsr_last_error(void) { return g_err; }
+
+size_t ipsr_feat_mask_workspace_bytes(int H, int W, int layers)
+{
+    (void)layers;
+    if (H < 2 || W < 2) return 0;
+    const size_t h1 = (size_t)((H - 2) / 2 + 1), w1 = (size_t)((W - 2) / 2 + 1);
+    return 2 * align_up(h1 * w1 * sizeof(uint32_t), 256);
+}
+
+int ipsr_feat_mask(const uint8_t* mask, int H, int W, int layers, float threshold, uint8_t* feat,
+                   void* ws, size_t ws_bytes, void* stream)
+{
+    if (!mask || !feat) return fail(IPSR_ERR_INVALID, "ipsr_feat_mask: null pointer");
+    if (H < 2 || W < 2 || layers < 1 || layers > 5) return fail(IPSR_ERR_INVALID, "ipsr_feat_mask: bad size H=%d W=%d layers=%d", H, W, layers);
+    if (layers > 1 && !ws) return fail(IPSR_ERR_WORKSPACE, "ipsr_feat_mask: workspace required");
+    return launch_feat_mask(mask, H, W, layers, threshold, feat, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int ipsr_index_prep(const uint8_t* feat, int h, int w, int patch, int stride, int mask_thred,
+                    int32_t* flag, int32_t* mask_point_idx, int32_t* count, void* stream)
+{
+    if (!feat || !flag || !mask_point_idx || !count) return fail(IPSR_ERR_INVALID, "ipsr_index_prep: null pointer");
+    if (patch < 1 || stride < 1 || h < patch || w < patch) return fail(IPSR_ERR_INVALID, "ipsr_index_prep: bad geometry h=%d w=%d patch=%d stride=%d", h, w, patch, stride);
+    return launch_index_prep(feat, h, w, patch, stride, mask_thred, flag, mask_point_idx, count, static_cast<hipStream_t>(stream));
+}
+
+int ipsr_patch_normalize(const float* x, int B, int C, int N, float* xn, float* inv, void* stream)
+{
+    if (!x || !xn || !inv) return fail(IPSR_ERR_INVALID, "ipsr_patch_normalize: null pointer");
+    if (B < 1 || C < 1 || N < 1) return fail(IPSR_ERR_INVALID, "ipsr_patch_normalize: bad size B=%d C=%d N=%d", B, C, N);
+    return launch_patch_normalize(x, B, C, N, xn, nullptr, (C + 7) & ~7, inv, static_cast<hipStream_t>(stream));
+}
+
+size_t ipsr_corr_argmax_workspace_bytes(int B, int C, int N)
+{
+    if (B < 1 || C < 1 || N < 1) return 0;
+    return corr_argmax_ws_bytes(B, C, N);
+}
+
+int ipsr_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
+                     float* S_out, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!xn || !ref || !ind || !vmax || !ws) return fail(IPSR_ERR_INVALID, "ipsr_corr_argmax: null pointer");
+    if (B < 1 || C < 1 || N < 1) return fail(IPSR_ERR_INVALID, "ipsr_corr_argmax: bad size B=%d C=%d N=%d", B, C, N);
+    if (!aligned16(xn) || !aligned16(ref)) return fail(IPSR_ERR_INVALID, "ipsr_corr_argmax: xn/ref must be 16-byte aligned");
+    return launch_corr_argmax(xn, ref, B, C, N, ind, vmax, S_out, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t ipsr_bwd_index_ints(int N, int M) { return (size_t)2 * N + 2 + (size_t)(M > 0 ? M : 0); }
+
+size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride)
+{
+    if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0 || patch != 1 || stride != 1) return 0;
+    return plan_forward(B, C, h, w, M).total;
+}
+
+int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
+                 int B, int C, int h, int w, int patch, int stride,
+                 float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
+                 void* ws, size_t ws_bytes, void* stream)
+{
+    if (!x || !ref || !out || !ind || !vmax || !ws) return fail(IPSR_ERR_INVALID, "ipsr_forward: null pointer");
+    if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0 || M > h * w) return fail(IPSR_ERR_INVALID, "ipsr_forward: bad size B=%d C=%d h=%d w=%d M=%d", B, C, h, w, M);
+    if (patch != 1 || stride != 1)
+        return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: only shift_sz=1, stride=1 is implemented (got %d, %d); the reference raises for these too (models/IPSRFunction.py:134)", patch, stride);
+    if (M > 0 && (!mask_point_idx || !attn_rows)) return fail(IPSR_ERR_INVALID, "ipsr_forward: M > 0 needs mask_point_idx and attn_rows");
+    if (!aligned16(x) || !aligned16(ref) || !aligned16(out) || !aligned16(ws) || (attn_rows && !aligned16(attn_rows)))
+        return fail(IPSR_ERR_INVALID, "ipsr_forward: x/ref/out/attn_rows/ws must be 16-byte aligned");
+    const FwdPlan p = plan_forward(B, C, h, w, M);
+    if (ws_bytes < p.total) return fail(IPSR_ERR_WORKSPACE, "ipsr_forward: workspace %zu < %zu", ws_bytes, p.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    char* base = static_cast<char*>(ws);
+    float* xn = reinterpret_cast<float*>(base); base += p.xn;
+    float* xT = reinterpret_cast<float*>(base); base += p.xT;
+    float* inv = reinterpret_cast<float*>(base); base += p.inv;
+    void* corr_ws = base; base += p.corr;
+    float* wn = reinterpret_cast<float*>(base); base += p.wn;
+    float* wo = reinterpret_cast<float*>(base); base += p.wo;
+    int32_t* flags = reinterpret_cast<int32_t*>(base);
+
+    if (int rc = launch_patch_normalize(x, B, C, p.N, xn, xT, p.Cp, inv, st)) return rc;
+    if (int rc = launch_corr_argmax(xn, ref, B, C, p.N, ind, vmax, nullptr, corr_ws, p.corr, st)) return rc;
+
+    AttnArgs a;
+    a.x = x; a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
+    a.B = B; a.C = C; a.Cp = p.Cp; a.N = p.N; a.M = M;
+    a.wn = wn; a.wo = wo; a.rowflag = flags; a.attn = attn_rows; a.out = out; a.bwd_index = bwd_index;
+    return launch_attention(a, st);
+}
+
+int ipsr_backward(const float* grad_out, const int32_t* mask_point_idx, int M, const float* attn_rows,
+                  const int32_t* bwd_index, float triple_w, int B, int C, int h, int w, float* grad_in, void* stream)
+{
+    if (!grad_out || !grad_in || !bwd_index) return fail(IPSR_ERR_INVALID, "ipsr_backward: null pointer");
+    if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return fail(IPSR_ERR_INVALID, "ipsr_backward: bad size");
+    if (M > 0 && (!mask_point_idx || !attn_rows)) return fail(IPSR_ERR_INVALID, "ipsr_backward: M > 0 needs mask_point_idx and attn_rows");
+    return launch_backward(grad_out, mask_point_idx, M, attn_rows, bwd_index, triple_w, B, C, h * w, grad_in, static_cast<hipStream_t>(stream));
+}
+
+size_t innercos_workspace_bytes(int B, int Cuse, int N) { return innercos_ws_bytes(B, Cuse, N); }
+
+int innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,
+                  float strength, float* loss, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!x || !mask || !target || !loss || !ws) return fail(IPSR_ERR_INVALID, "innercos_loss: null pointer");
+    if (B < 1 || Cuse < 1 || Cx < Cuse || N < 1) return fail(IPSR_ERR_INVALID, "innercos_loss: bad size B=%d Cx=%d Cuse=%d N=%d", B, Cx, Cuse, N);
+    if (!aligned16(x) || !aligned16(target) || !aligned16(mask)) return fail(IPSR_ERR_INVALID, "innercos_loss: x/target/mask must be 16-byte aligned");
+    return launch_innercos_loss(x, B, Cx, Cuse, N, mask, target, strength, loss, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int innercos_loss_backward(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,
+                           float strength, const float* grad_loss, float* grad_x, void* stream)
+{
+    if (!x || !mask || !target || !grad_loss || !grad_x) return fail(IPSR_ERR_INVALID, "innercos_loss_backward: null pointer");
+    if (B < 1 || Cuse < 1 || Cx < Cuse || N < 1) return fail(IPSR_ERR_INVALID, "innercos_loss_backward: bad size");
+    return launch_innercos_backward(x, B, Cx, Cuse, N, mask, target, strength, grad_loss, grad_x, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

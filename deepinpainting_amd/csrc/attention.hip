@@ -1,0 +1,403 @@
+// attention.hip — K6 coherent-attention recurrence, K7 shift-fold reconstruction and the sparse form of
+// trunc(kbar) that the backward needs.
+//
+// Reference: models/IPSRFunction.py:70-134.  For every sample the reference walks all N positions in
+// raster order in Python; masked position l (q = mask_point_idx[l], kq = ind[q]) does
+//      at = <P[q]/(||P[q]||+1e-8), o_{l-1}>;  s = at + vmax[q];  wn = at/s;  wo = vmax[q]/s
+//      o_l = wn*o_{l-1} + wo*P[kq];          a_l = wn*a_{l-1};  a_l[kq] += wo           (:105-125)
+// (o_0 = P[kq], a_0 = onehot(kq)), fills the dense N x N matrix kbar column by column and finally
+// multiplies it with the raw patches (conv_transpose2d, :130-133).  Here:
+//   * recurrence_kernel  — the only truly serial part: one 64-lane wave per sample keeps o_l in
+//     registers (8 channels per lane per 512), reads patch rows from the patch-major copy xT through a
+//     4-deep register prefetch ring, reduces the dot with DPP + readlane (no LDS, no barrier) and emits
+//     only the scalars (wn_l, wo_l).  Latency-bound by construction: M dependent steps.
+//   * attn_rows_kernel   — a_l[k] is a scalar recurrence per k, independent across k: one thread per k
+//     replays (wn_l, wo_l) and writes the reference's `in_attention` rows [M,N], coalesced.
+//   * recon_gather_kernel — non-masked q: kbar column is one-hot, so out[:,q] = P[ind[q]] is a row
+//     gather (LDS-transposed so that both the read of xT rows and the write of out rows are coalesced).
+//   * recon_masked_kernel — masked q: out[:,q_l] = sum_k a_l[k] * P[k,:], the dense part of the
+//     reference's second GEMM, on fp32 MFMA with k walked in ascending order (one fmaf chain per
+//     output, same bits as the oracle).
+//   * bwd_index_kernel   — kbar is kept by the reference in a LongTensor (:36,134), i.e. truncated:
+//     non-masked columns are exact one-hots -> a CSR "who points at k" index in ascending q;
+//     masked rows survive truncation only where |a_l[k]| >= 1 -> list of such rows.
+#include "ipsr_common.h"
+
+namespace ipsr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+// wave-wide sum with the canonical tree: xor-butterfly 1,2,4,8 inside each row of 16 lanes (DPP), then
+// (r0 + r1) + (r2 + r3) over the four row sums.  Every lane returns the same bits.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_canonical(float p)
+{
+    p = p + dpp_mov<0xB1>(p);    // quad_perm [1,0,3,2]  : lane ^ 1
+    p = p + dpp_mov<0x4E>(p);    // quad_perm [2,3,0,1]  : lane ^ 2
+    p = p + dpp_mov<0x141>(p);   // row_half_mirror      : the other quad of the 8-group (all its lanes hold the same sum)
+    p = p + dpp_mov<0x140>(p);   // row_mirror           : the other 8-group of the row
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K6 serial part.  NCH = ceil(Cp / 512): lane j owns the 8-channel chunks j, j+64, ...
+constexpr int RING = 4;
+
+template <int NCH>
+__global__ void __launch_bounds__(64) recurrence_kernel(const float* __restrict__ xT, const float* __restrict__ inv,
+                                                        const int32_t* __restrict__ ind, const float* __restrict__ vmax,
+                                                        const int32_t* __restrict__ mpi, int Cp, int N, int M,
+                                                        float* __restrict__ wn_out, float* __restrict__ wo_out,
+                                                        int32_t* __restrict__ kq_out, int32_t* __restrict__ rowflag)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+    int* q_s = lds_raw;                 // [M]
+    int* kq_s = q_s + M;                // [M]
+    float* iv_s = reinterpret_cast<float*>(kq_s + M);   // [M]
+    float* vm_s = iv_s + M;             // [M]
+
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* xTb = xT + (size_t)b * N * Cp;
+    const int32_t* indb = ind + (size_t)b * N;
+
+    // resolve the index chain mpi -> ind -> (inv, vmax) for all steps up front, 64 steps at a time
+    for (int l = lane; l < M; l += 64) {
+        const int q = mpi[l];
+        const int kq = indb[q];
+        q_s[l] = q;
+        kq_s[l] = kq;
+        iv_s[l] = inv[(size_t)b * N + q];
+        vm_s[l] = vmax[(size_t)b * N + q];
+        kq_out[(size_t)b * M + l] = kq;
+        rowflag[(size_t)b * M + l] = 0;
+    }
+    __syncthreads();
+
+    float o[NCH][8];
+    float pu[RING][NCH][8], pk[RING][NCH][8];
+
+    auto load_row = [&](float (&dst)[NCH][8], int row) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int base = (lane + 64 * i) * 8;
+            if (base < Cp) {
+                const float4 v0 = *reinterpret_cast<const float4*>(xTb + (size_t)row * Cp + base);
+                const float4 v1 = *reinterpret_cast<const float4*>(xTb + (size_t)row * Cp + base + 4);
+                dst[i][0] = v0.x; dst[i][1] = v0.y; dst[i][2] = v0.z; dst[i][3] = v0.w;
+                dst[i][4] = v1.x; dst[i][5] = v1.y; dst[i][6] = v1.z; dst[i][7] = v1.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[i][e] = 0.0f;
+            }
+        }
+    };
+
+    // step 0: o_0 = P[kq_0]   (IPSRFunction.py:98-101)
+    load_row(o, kq_s[0]);
+    if (lane == 0) { wn_out[(size_t)b * M] = 0.0f; wo_out[(size_t)b * M] = 1.0f; }
+
+    // prime the ring with steps 1..RING
+#pragma unroll
+    for (int d = 0; d < RING; ++d) {
+        const int l = 1 + d;
+        if (l < M) { load_row(pu[d], q_s[l]); load_row(pk[d], kq_s[l]); }
+    }
+
+    for (int l0 = 1; l0 < M; l0 += RING) {
+#pragma unroll
+        for (int d = 0; d < RING; ++d) {
+            const int l = l0 + d;
+            if (l < M) {
+                const float iq = iv_s[l], v = vm_s[l];
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(pu[d][i][e] * iq, o[i][e], acc);   // u = P[q]*inv  (:109)
+                const float at = wave_sum_canonical(acc);                                                // (:116)
+                const float s = at + v;
+                const float wn = at / s, wo = v / s;                                                     // (:120-121)
+#pragma unroll
+                for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t0 = wn * o[i][e];
+                        const float t1 = wo * pk[d][i][e];
+                        o[i][e] = t0 + t1;                                                               // (:122)
+                    }
+                if (lane == 0) { wn_out[(size_t)b * M + l] = wn; wo_out[(size_t)b * M + l] = wo; }
+                const int ln = l + RING;
+                if (ln < M) { load_row(pu[d], q_s[ln]); load_row(pk[d], kq_s[ln]); }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a_l[k] for all l: one thread per k (IPSRFunction.py:100,123-125).  Also flags rows whose truncation
+// toward zero is not all-zero (what survives `ind_lst[idx] = kbar.squeeze()` into a LongTensor, :134).
+__global__ void __launch_bounds__(256) attn_rows_kernel(const float* __restrict__ wn, const float* __restrict__ wo,
+                                                        const int32_t* __restrict__ kq, int N, int M,
+                                                        float* __restrict__ attn, int32_t* __restrict__ rowflag)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const float* wnb = wn + (size_t)b * M;
+    const float* wob = wo + (size_t)b * M;
+    const int32_t* kqb = kq + (size_t)b * M;
+    float* ab = attn + (size_t)b * M * N;
+    float a = 0.0f;
+    for (int l = 0; l < M; ++l) {
+        a = a * wnb[l];
+        if (kqb[l] == k) a = a + wob[l];
+        ab[(size_t)l * N + k] = a;
+        if (truncf(a) != 0.0f) atomicOr(&rowflag[(size_t)b * M + l], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// non-masked columns: out[c][q] = P[ind[q]][c]  (one-hot kbar column, IPSRFunction.py:129-133).
+// (masked columns are written too and overwritten by recon_masked_kernel afterwards.)
+__global__ void __launch_bounds__(256) recon_gather_kernel(const float* __restrict__ xT, const int32_t* __restrict__ ind,
+                                                           int C, int Cp, int N, float* __restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int q0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+    const float* xTb = xT + (size_t)b * N * Cp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ql = ty + 8 * i, q = q0 + ql;
+        float v = 0.0f;
+        if (q < N && c0 + tx < Cp) v = xTb[(size_t)ind[(size_t)b * N + q] * Cp + c0 + tx];
+        tile[ql][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cl = ty + 8 * i, c = c0 + cl;
+        if (c < C && q0 + tx < N) out[((size_t)b * C + c) * N + q0 + tx] = tile[tx][cl];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// masked columns on the matrix cores:  D[c][l] = sum_k xT[k][c] * attn[l][k],  out[c][mpi[l]] = D[c][l].
+// A[i=c][kk=k] = xT[k][c] is patch-major = MFMA operand order (plain LDS copy); B[kk=k][j=l] = attn[l][k]
+// is k-contiguous, so its LDS image is [l][k] with a padded row (33) for conflict-free column reads.
+constexpr int RM_BC = 64, RM_BL = 64, RM_BK = 32;
+
+__global__ void __launch_bounds__(256) recon_masked_kernel(const float* __restrict__ xT, const float* __restrict__ attn,
+                                                           const int32_t* __restrict__ mpi, int C, int Cp, int N, int M,
+                                                           float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][RM_BK][RM_BC];
+    __shared__ float Bs[2][RM_BL][RM_BK + 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int l0 = blockIdx.x * RM_BL, c0 = blockIdx.y * RM_BC, b = blockIdx.z;
+    const float* xTb = xT + (size_t)b * N * Cp;
+    const float* ab = attn + (size_t)b * M * N;
+    const bool vec_ok = (N % 4 == 0);
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+
+    float4 ra[2], rb[2];
+    auto gload = [&](int s) {
+        const int k0 = s * RM_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            {   // A: 32 rows (k) x 16 float4 (c)
+                const int kk = idx >> 4, c4 = (idx & 15) * 4;
+                const int k = k0 + kk, c = c0 + c4;
+                if (k < N && c + 4 <= Cp) ra[i] = *reinterpret_cast<const float4*>(xTb + (size_t)k * Cp + c);
+                else ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            {   // B: 64 rows (l) x 8 float4 (k)
+                const int j = idx >> 3, k4 = (idx & 7) * 4;
+                const int l = l0 + j, k = k0 + k4;
+                if (l < M && vec_ok && k + 4 <= N) rb[i] = *reinterpret_cast<const float4*>(ab + (size_t)l * N + k);
+                else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (l < M && k + e < N) ? ab[(size_t)l * N + k + e] : 0.0f;
+                    rb[i] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<float4*>(&As[buf][idx >> 4][(idx & 15) * 4]) = ra[i];
+            const int j = idx >> 3, k4 = (idx & 7) * 4;
+            Bs[buf][j][k4 + 0] = rb[i].x; Bs[buf][j][k4 + 1] = rb[i].y;
+            Bs[buf][j][k4 + 2] = rb[i].z; Bs[buf][j][k4 + 3] = rb[i].w;
+        }
+    };
+
+    const int nstage = (N + RM_BK - 1) / RM_BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nstage) gload(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < RM_BK / 2; ++kk) {
+            const float a = As[cur][kk * 2 + h][wm * 32 + r];
+            const float bb = Bs[cur][wn * 32 + r][kk * 2 + h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+        }
+        if (s + 1 < nstage) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    const int l = l0 + wn * 32 + r;
+    if (l < M) {
+        const int q = mpi[l];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = c0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (c < C) out[((size_t)b * C + c) * N + q] = acc[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sparse form of trunc(kbar) per sample:
+//   col_off[N+1], col_q[N] : CSR over k of the NON-masked q with ind[q] == k, q ascending (unused tail = -1)
+//   nz_count, nz_rows[M]   : masked rows l (ascending) whose truncated attention row is not all zero
+__global__ void __launch_bounds__(1024) bwd_index_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
+                                                         const int32_t* __restrict__ rowflag, int N, int M,
+                                                         int32_t* __restrict__ bwd_index, size_t ints_per_sample)
+{
+    extern __shared__ __attribute__((aligned(16))) int key[];   // [Npad] ind[q], or -1 for masked q / padding
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x;
+    const int Npad = (N + 3) & ~3;
+    int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
+    int32_t* col_q = col_off + N + 1;
+    int32_t* nz_count = col_q + N;
+    int32_t* nz_rows = nz_count + 1;
+
+    for (int q = tid; q < Npad; q += 1024) key[q] = q < N ? ind[(size_t)b * N + q] : -1;
+    __syncthreads();
+    for (int l = tid; l < M; l += 1024) key[mpi[l]] = -1;
+    __syncthreads();
+
+    // contiguous ownership: thread t owns k in [t*KPT, (t+1)*KPT)
+    const int KPT = (N + 1023) / 1024;
+    const int k_lo = tid * KPT, k_hi = min(N, k_lo + KPT);
+    int total = 0;
+    for (int k = k_lo; k < k_hi; ++k) {
+        int cnt = 0;
+        for (int q = 0; q < Npad; q += 4) {
+            const int4 v = *reinterpret_cast<const int4*>(&key[q]);
+            cnt += (v.x == k) + (v.y == k) + (v.z == k) + (v.w == k);
+        }
+        total += cnt;
+    }
+    // exclusive scan of `total` over the 1024 threads
+    int incl = total;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int t = __shfl_up(incl, s);
+        if (lane >= s) incl += t;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int j = 0; j < wv; ++j) base += wave_tot[j];
+    int off = base + incl - total;
+
+    for (int k = k_lo; k < k_hi; ++k) {
+        col_off[k] = off;
+        for (int q = 0; q < Npad; q += 4) {
+            const int4 v = *reinterpret_cast<const int4*>(&key[q]);
+            if (v.x == k) col_q[off++] = q;
+            if (v.y == k) col_q[off++] = q + 1;
+            if (v.z == k) col_q[off++] = q + 2;
+            if (v.w == k) col_q[off++] = q + 3;
+        }
+    }
+    if (tid == 1023) col_off[N] = off;     // the last thread's running offset is the grand total (N - M)
+    for (int i = N - M + tid; i < N; i += 1024) col_q[i] = -1;
+
+    // ordered compaction of the flagged masked rows (wave 0)
+    if (wv == 0) {
+        int nbase = 0;
+        for (int l0 = 0; l0 < M; l0 += 64) {
+            const int l = l0 + lane;
+            const int f = (l < M) ? (rowflag[(size_t)b * M + l] != 0) : 0;
+            const unsigned long long bal = __ballot(f);
+            if (f) nz_rows[nbase + __popcll(bal & ((1ull << lane) - 1ull))] = l;
+            nbase += __popcll(bal);
+        }
+        for (int i = nbase + lane; i < M; i += 64) nz_rows[i] = -1;
+        if (lane == 0) *nz_count = nbase;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+int launch_attention(const AttnArgs& a, hipStream_t st)
+{
+    const int B = a.B, C = a.C, Cp = a.Cp, N = a.N, M = a.M;
+    const size_t ints = (size_t)2 * N + 2 + M;
+    int32_t* kq = a.rowflag + (size_t)B * (M > 0 ? M : 1);   // [B,M] right behind rowflag (see ipsr_forward carve)
+    if (M > 0) {
+        const int nch = cdiv(Cp, 512);
+        const size_t lds = (size_t)4 * M * sizeof(int);
+        if (lds > 160 * 1024 - 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: M=%d too large for the recurrence's LDS index cache", M);
+#define LAUNCH_REC(NCH)                                                                                              \
+    do {                                                                                                             \
+        if (lds > 48 * 1024)                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&recurrence_kernel<NCH>),                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+        recurrence_kernel<NCH><<<B, 64, lds, st>>>(a.xT, a.inv, a.ind, a.vmax, a.mpi, Cp, N, M, a.wn, a.wo, kq, a.rowflag); \
+    } while (0)
+        switch (nch) {
+            case 1: LAUNCH_REC(1); break;
+            case 2: LAUNCH_REC(2); break;
+            case 3: LAUNCH_REC(3); break;
+            case 4: LAUNCH_REC(4); break;
+            default: return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: C=%d > 2048 channels not supported", C);
+        }
+#undef LAUNCH_REC
+        if (int rc = check_launch("recurrence_kernel")) return rc;
+        attn_rows_kernel<<<dim3(cdiv(N, 256), B), 256, 0, st>>>(a.wn, a.wo, kq, N, M, a.attn, a.rowflag);
+        if (int rc = check_launch("attn_rows_kernel")) return rc;
+    }
+    recon_gather_kernel<<<dim3(cdiv(N, 32), cdiv(C, 32), B), 256, 0, st>>>(a.xT, a.ind, C, Cp, N, a.out);
+    if (int rc = check_launch("recon_gather_kernel")) return rc;
+    if (M > 0) {
+        recon_masked_kernel<<<dim3(cdiv(M, RM_BL), cdiv(C, RM_BC), B), 256, 0, st>>>(a.xT, a.attn, a.mpi, C, Cp, N, M, a.out);
+        if (int rc = check_launch("recon_masked_kernel")) return rc;
+    }
+    if (a.bwd_index) {
+        const size_t lds = (size_t)((N + 3) & ~3) * sizeof(int);
+        if (lds > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: N=%d too large for bwd_index_kernel", N);
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        bwd_index_kernel<<<B, 1024, lds, st>>>(a.ind, a.mpi, a.rowflag, N, M, a.bwd_index, ints);
+        if (int rc = check_launch("bwd_index_kernel")) return rc;
+    }
+    return IPSR_OK;
+}
+
+}  // namespace ipsr

@@ -1,0 +1,251 @@
+// corr_argmax.hip — K4 + K5: patch x reference cross-correlation fused with the arg-max over patches.
+//
+// Reference: tmp1 = conv_enc(ref.relu4_3) (models/IPSRFunction.py:59) followed by MaxCoord.update_output
+// (util/MaxCoord.py:16-28):
+//      S[k][q] = sum_c xn[c][k] * ref[c][q]        (N x N, reduction over C)
+//      ind[q]  = argmax_k S[k][q]  (lowest k on ties),   vmax[q] = max_k S[k][q]
+// The reference materialises S (N*N fp32 per sample) and re-reads it for the max; here S lives only in
+// MFMA accumulators and the running (max, argmax) is folded in the epilogue of every 128-row k-tile.
+//
+// This is the one genuine dense contraction of the layer (2*N*N*C flop per sample) and runs on the
+// fp32-input matrix cores: v_mfma_f32_32x32x2_f32, exact fp32, 64 FLOP/clk/SIMD (157 TF peak).  Because
+// that instruction is bit-for-bit an fmaf chain over its 2 k-steps (cdna_hip_programming.md §3), walking
+// C in ascending order makes every S[k][q] the same single fmaf chain the oracle computes, so the
+// arg-max indices match the CPU restatement exactly, not just within a tolerance.
+//
+// Tiling (64-wide waves, one wave per SIMD):
+//   workgroup = 256 threads = 4 waves in a 2x2 grid; workgroup tile 128 (k) x 128 (q); each wave owns
+//   64x64 = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs); BK = 16 channels per LDS stage.
+//   Both operands are channel-major in HBM ([C][N]), which is exactly the MFMA operand order
+//   (A[i][kk]: lane = i + 32*kk), so the LDS image is a plain copy of the global tile: 512-byte
+//   coalesced row segments in, conflict-free ds_read_b32 out (32 consecutive floats per half-wave).
+//   Double-buffered LDS, global loads for stage s+1 are in flight while stage s feeds the MFMAs.
+//   A 32x32 accumulator tile has its q column on the lane and 16 k rows in registers, so the arg-max
+//   over k is 16 in-lane compares per tile, one cross-half exchange and one LDS exchange at the very end.
+//
+// Grid: (sample, q-tile, k-split) with an XCD-aware remap so that all workgroups of a sample — which
+// share its xn and ref tiles — sit on one XCD's L2.  k-splits keep >= 2 workgroups per CU busy at the
+// batch-8 / N=1024 size; their partial (max, argmax) are merged by a tiny second kernel.
+#include "ipsr_common.h"
+
+namespace ipsr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;   // k rows (patches) per workgroup tile
+constexpr int BN = 128;   // q columns (reference positions) per workgroup tile
+constexpr int BK = 16;    // channels per LDS stage
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ bool better(float v1, int i1, float v0, int i0)
+{
+    return (v1 > v0) || (v1 == v0 && i1 < i0);
+}
+
+template <bool FAST, bool WRITE_S>
+__global__ void __launch_bounds__(NTHREADS, 2)
+corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, int C, int N,
+                   int qtiles, int ksplit, int ktiles, int kt_per_wg,
+                   float* __restrict__ S_out, float* __restrict__ pval, int32_t* __restrict__ pidx)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+    __shared__ float red_v[2][2][32];
+    __shared__ int red_i[2][2][32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = L % ksplit;
+    const int qt = (L / ksplit) % qtiles;
+    const int b = L / (ksplit * qtiles);
+    const int q0 = qt * BN;
+
+    const float* A = xn + (size_t)b * C * N;
+    const float* R = ref + (size_t)b * C * N;
+
+    // staging assignment: 16 rows x 32 float4 per operand tile = 512 float4, 2 per thread
+    const int ld_row = tid >> 5;          // 0..7  (+8 for the second)
+    const int ld_c4 = (tid & 31) * 4;     // column offset in floats
+
+    float best[2] = {-INFINITY, -INFINITY};
+    int bidx[2] = {0x7fffffff, 0x7fffffff};
+
+    const int nstage = (C + BK - 1) / BK;
+    const int kt_lo = ks * kt_per_wg, kt_hi = min(ktiles, kt_lo + kt_per_wg);
+
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int k0 = kt * BM;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+        float4 ra[2], rb[2];
+        auto gload = [&](int s) {
+            const int c0 = s * BK;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = c0 + ld_row + 8 * i;
+                if (FAST) {
+                    ra[i] = *reinterpret_cast<const float4*>(A + (size_t)c * N + k0 + ld_c4);
+                    rb[i] = *reinterpret_cast<const float4*>(R + (size_t)c * N + q0 + ld_c4);
+                } else {
+                    float va[4], vb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kc = k0 + ld_c4 + e, qc = q0 + ld_c4 + e;
+                        va[e] = (c < C && kc < N) ? A[(size_t)c * N + kc] : 0.0f;
+                        vb[e] = (c < C && qc < N) ? R[(size_t)c * N + qc] : 0.0f;
+                    }
+                    ra[i] = make_float4(va[0], va[1], va[2], va[3]);
+                    rb[i] = make_float4(vb[0], vb[1], vb[2], vb[3]);
+                }
+            }
+        };
+        auto sstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<float4*>(&As[buf][ld_row + 8 * i][ld_c4]) = ra[i];
+                *reinterpret_cast<float4*>(&Bs[buf][ld_row + 8 * i][ld_c4]) = rb[i];
+            }
+        };
+
+        gload(0);
+        sstore(0);
+        __syncthreads();
+        for (int s = 0; s < nstage; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < nstage) gload(s + 1);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const float a0 = As[cur][kk * 2 + h][wm * 64 + r];
+                const float a1 = As[cur][kk * 2 + h][wm * 64 + 32 + r];
+                const float b0 = Bs[cur][kk * 2 + h][wn * 64 + r];
+                const float b1 = Bs[cur][kk * 2 + h][wn * 64 + 32 + r];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (s + 1 < nstage) sstore(cur ^ 1);
+            __syncthreads();
+        }
+
+        // epilogue of this k-tile: fold 2x16 rows into the running (max, argmax) of the lane's 2 columns.
+        // Rows are visited in ascending k and only a strictly larger value replaces -> lowest k on ties.
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int q = q0 + wn * 64 + jn * 32 + r;
+#pragma unroll
+            for (int im = 0; im < 2; ++im) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = k0 + wm * 64 + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = acc[im][jn][e];
+                    if (FAST || k < N) {
+                        if (v > best[jn]) { best[jn] = v; bidx[jn] = k; }
+                        if (WRITE_S) { if (FAST || q < N) S_out[((size_t)b * N + k) * N + q] = v; }
+                    }
+                }
+            }
+        }
+    }
+
+    // merge the two lane halves (rows 4h..), then the two waves stacked along k
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const float ov = __shfl_xor(best[jn], 32);
+        const int oi = __shfl_xor(bidx[jn], 32);
+        if (better(ov, oi, best[jn], bidx[jn])) { best[jn] = ov; bidx[jn] = oi; }
+    }
+    if (wm == 1 && h == 0) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) { red_v[wn][jn][r] = best[jn]; red_i[wn][jn][r] = bidx[jn]; }
+    }
+    __syncthreads();
+    if (wm == 0 && h == 0) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const float ov = red_v[wn][jn][r];
+            const int oi = red_i[wn][jn][r];
+            if (better(ov, oi, best[jn], bidx[jn])) { best[jn] = ov; bidx[jn] = oi; }
+            const int q = q0 + wn * 64 + jn * 32 + r;
+            if (q < N) {
+                pval[((size_t)b * ksplit + ks) * N + q] = best[jn];
+                pidx[((size_t)b * ksplit + ks) * N + q] = bidx[jn];
+            }
+        }
+    }
+}
+
+// merge the k-split partials in ascending k order
+__global__ void __launch_bounds__(256) argmax_merge_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
+                                                           int B, int N, int ksplit, int32_t* __restrict__ ind,
+                                                           float* __restrict__ vmax)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, q = i - b * N;
+    float bv = pval[((size_t)b * ksplit) * N + q];
+    int bi = pidx[((size_t)b * ksplit) * N + q];
+    for (int s = 1; s < ksplit; ++s) {
+        const float v = pval[((size_t)b * ksplit + s) * N + q];
+        const int ii = pidx[((size_t)b * ksplit + s) * N + q];
+        if (better(v, ii, bv, bi)) { bv = v; bi = ii; }
+    }
+    ind[i] = bi;
+    vmax[i] = bv;
+}
+
+static void plan(int B, int N, int* qtiles, int* ktiles, int* ksplit, int* kt_per_wg)
+{
+    *qtiles = cdiv(N, BN);
+    *ktiles = cdiv(N, BM);
+    // aim for >= 2 workgroups per CU (512) so the chip is full and the tail is short
+    int want = cdiv(512, B * *qtiles);
+    if (want < 1) want = 1;
+    if (want > *ktiles) want = *ktiles;
+    *kt_per_wg = cdiv(*ktiles, want);
+    *ksplit = cdiv(*ktiles, *kt_per_wg);
+}
+
+size_t corr_argmax_ws_bytes(int B, int C, int N)
+{
+    (void)C;
+    int qt, kt, ks, kpw;
+    plan(B, N, &qt, &kt, &ks, &kpw);
+    return 2 * align_up((size_t)B * ks * N * 4, 256) + 256;
+}
+
+int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
+                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    int qt, kt, ks, kpw;
+    plan(B, N, &qt, &kt, &ks, &kpw);
+    if (ws_bytes < corr_argmax_ws_bytes(B, C, N))
+        return fail(IPSR_ERR_WORKSPACE, "ipsr_corr_argmax: workspace %zu < %zu", ws_bytes, corr_argmax_ws_bytes(B, C, N));
+    Carver cv(ws, ws_bytes);
+    float* pval = cv.take<float>((size_t)B * ks * N);
+    int32_t* pidx = cv.take<int32_t>((size_t)B * ks * N);
+    const bool fast = (N % BM == 0) && (C % BK == 0);
+    const int grid = B * qt * ks;
+    if (fast) {
+        if (S_out) corr_argmax_kernel<true, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
+        else corr_argmax_kernel<true, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
+    } else {
+        if (S_out) corr_argmax_kernel<false, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
+        else corr_argmax_kernel<false, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
+    }
+    if (int rc = check_launch("corr_argmax_kernel")) return rc;
+    argmax_merge_kernel<<<cdiv(B * N, 256), 256, 0, st>>>(pval, pidx, B, N, ks, ind, vmax);
+    return check_launch("argmax_merge_kernel");
+}
+
+}  // namespace ipsr

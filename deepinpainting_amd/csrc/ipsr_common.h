@@ -1,0 +1,86 @@
+// ipsr_common.h — shared helpers of libipsr_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/ipsr_hip.h"
+
+namespace ipsr {
+
+// ---- error reporting (thread-local message behind ipsr_last_error()) ----
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+// Checks the launch that was just issued on `what`.
+int check_launch(const char* what);
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Bump allocator over the caller's workspace (256-B aligned slices).
+struct Carver {
+    char* base;
+    size_t off;
+    size_t cap;
+    explicit Carver(void* p, size_t bytes) : base(static_cast<char*>(p)), off(0), cap(bytes) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t start = align_up(off, 256);
+        off = start + count * sizeof(T);
+        return reinterpret_cast<T*>(base + start);
+    }
+    bool ok() const { return off <= cap; }
+};
+
+// XCD-aware remap (cdna_hip_programming.md T1): the dispatcher deals workgroups round-robin over the 8
+// XCDs, so blocks b and b+8 share an L2.  This bijection hands each XCD a CONTIGUOUS range of logical
+// ids, so logically adjacent work (same sample / same q-tile) shares an L2.  Speed only, never
+// correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned wg, unsigned nwg)
+{
+    const unsigned q = nwg >> 3, r = nwg & 7u;
+    const unsigned xcd = wg & 7u, slot = wg >> 3;
+    const unsigned start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return start + slot;
+}
+
+// ---- device-side kernels' launchers (one per .hip file) ----
+int launch_feat_mask(const uint8_t* mask, int H, int W, int layers, float threshold, uint8_t* feat,
+                     void* ws, size_t ws_bytes, hipStream_t st);
+int launch_index_prep(const uint8_t* feat, int h, int w, int patch, int stride, int mask_thred,
+                      int32_t* flag, int32_t* mask_point_idx, int32_t* count, hipStream_t st);
+// xT may be NULL (then the patch-major copy is not produced).
+int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float* xT, int Cp, float* inv,
+                           hipStream_t st);
+size_t corr_argmax_ws_bytes(int B, int C, int N);
+int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
+                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st);
+
+struct AttnArgs {
+    const float* x;        // [B,C,N] raw features
+    const float* xT;       // [B,N,Cp] patch-major raw copy, zero padded to Cp = roundup(C,8)
+    const float* inv;      // [B,N]
+    const int32_t* ind;    // [B,N]
+    const float* vmax;     // [B,N]
+    const int32_t* mpi;    // [M]
+    int B, C, Cp, N, M;
+    float* wn;             // [B,M] ws
+    float* wo;             // [B,M] ws
+    int32_t* rowflag;      // [B,M] ws (trunc(attn row) has a non-zero)
+    float* attn;           // [B,M,N]
+    float* out;            // [B,C,N]
+    int32_t* bwd_index;    // [B, 2N+2+M]
+};
+int launch_attention(const AttnArgs& a, hipStream_t st);
+
+int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn, const int32_t* bwd_index,
+                    float triple_w, int B, int C, int N, float* gin, hipStream_t st);
+
+size_t innercos_ws_bytes(int B, int Cuse, int N);
+int launch_innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,
+                         float strength, float* loss, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_innercos_backward(const float* x, int B, int Cx, int Cuse, int N, const float* mask,
+                             const float* target, float strength, const float* grad_loss, float* grad_x,
+                             hipStream_t st);
+
+}  // namespace ipsr

@@ -1,0 +1,105 @@
+// normalize.hip — K3: patch unfold + per-patch L2 normalisation (patch size 1).
+//
+// Reference: NonparametricShift._extract_patches/_build (util/NonparametricShift.py:36-73):
+//   P[k,:] = x[:,k];   Pn[k] = P[k] * (1 / (||P[k]||_2 + 1e-8))
+//
+// Outputs (all per sample):
+//   inv [N]      1/(||x[:,k]|| + 1e-8)
+//   xn  [C,N]    x * inv, channel-major — the A operand of the correlation GEMM (its LDS image is a plain
+//                copy of the global tile, so it can be staged with wide coalesced loads)
+//   xT  [N,Cp]   raw patches, patch-major (the reference's `patches_all` [N,C,1,1]), zero padded to
+//                Cp = roundup(C,8): rows of it feed the recurrence and the reconstruction.
+//
+// Canonical summation order of the squared norm (oracle ipsr_patch_normalize_cpu): the C
+// channels are cut into 8 contiguous segments of L = ceil(C/8); each segment is one fmaf chain in
+// ascending c, and the 8 partials are added in ascending order.
+//
+// HBM-bound: reads x once from HBM (the second pass hits L2), writes xn + xT: 3*C*N*4 bytes per sample.
+#include "ipsr_common.h"
+
+namespace ipsr {
+
+constexpr int NCOL = 32;   // patches (columns) per workgroup
+constexpr int NSEG = 8;    // channel segments
+
+__global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const float* __restrict__ x, int C, int N, int Cp,
+                                                                      float* __restrict__ xn, float* __restrict__ xT,
+                                                                      float* __restrict__ inv)
+{
+    __shared__ float part[NSEG][NCOL];
+    __shared__ float inv_s[NCOL];
+    __shared__ float tile[32][NCOL + 1];
+
+    const int tid = threadIdx.x;
+    const int col = tid & (NCOL - 1), seg = tid / NCOL;
+    const int ntile = (N + NCOL - 1) / NCOL;
+    const int b = blockIdx.x / ntile, k0 = (blockIdx.x % ntile) * NCOL;
+    const int k = k0 + col;
+    const float* xb = x + (size_t)b * C * N;
+
+    // phase 1: segment partial of sum(x^2), one fmaf chain per (segment, column)
+    const int L = (C + NSEG - 1) / NSEG;
+    const int c_lo = seg * L, c_hi = min(C, c_lo + L);
+    float acc = 0.0f;
+    if (k < N) {
+        int c = c_lo;
+        for (; c + 4 <= c_hi; c += 4) {
+            const float v0 = xb[(size_t)(c + 0) * N + k], v1 = xb[(size_t)(c + 1) * N + k];
+            const float v2 = xb[(size_t)(c + 2) * N + k], v3 = xb[(size_t)(c + 3) * N + k];
+            acc = __builtin_fmaf(v0, v0, acc);
+            acc = __builtin_fmaf(v1, v1, acc);
+            acc = __builtin_fmaf(v2, v2, acc);
+            acc = __builtin_fmaf(v3, v3, acc);
+        }
+        for (; c < c_hi; ++c) { const float v = xb[(size_t)c * N + k]; acc = __builtin_fmaf(v, v, acc); }
+    }
+    part[seg][col] = acc;
+    __syncthreads();
+    if (seg == 0) {
+        float tot = part[0][col];
+#pragma unroll
+        for (int s = 1; s < NSEG; ++s) tot = tot + part[s][col];
+        const float iv = 1.0f / (sqrtf(tot) + 1e-8f);
+        inv_s[col] = iv;
+        if (k < N) inv[(size_t)b * N + k] = iv;
+    }
+    __syncthreads();
+
+    // phase 2: scale (channel-major) and transpose (patch-major), 32 channels at a time
+    const float iv = inv_s[col];
+    float* xnb = xn + (size_t)b * C * N;
+    float* xTb = xT ? xT + (size_t)b * N * Cp : nullptr;
+    const int r = seg;   // 8 channel rows per pass
+    for (int c0 = 0; c0 < Cp; c0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cl = r + 8 * i, c = c0 + cl;
+            float v = 0.0f;
+            if (c < C && k < N) {
+                v = xb[(size_t)c * N + k];
+                xnb[(size_t)c * N + k] = v * iv;
+            }
+            tile[cl][col] = v;
+        }
+        if (xTb) {
+            __syncthreads();
+            const int cc = col, c = c0 + cc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kl = r + 8 * i;
+                if (c < Cp && k0 + kl < N) xTb[(size_t)(k0 + kl) * Cp + c] = tile[cc][kl];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float* xT, int Cp, float* inv,
+                           hipStream_t st)
+{
+    const int ntile = cdiv(N, NCOL);
+    patch_normalize_kernel<<<B * ntile, NCOL * NSEG, 0, st>>>(x, C, N, Cp, xn, xT, inv);
+    return check_launch("patch_normalize_kernel");
+}
+
+}  // namespace ipsr

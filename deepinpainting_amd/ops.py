@@ -1,0 +1,168 @@
+"""Thin torch-tensor front-ends of the C-ABI entry points (device pointers + current stream).
+
+torch is used here for device memory and streams only; every computation is a HIP kernel of
+libipsr_hip.so.  All functions require CUDA(HIP) tensors and raise otherwise — no fallback.
+"""
+from collections import namedtuple
+
+import torch
+
+from . import _lib
+
+_ws_cache = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-(device, stream) scratch buffer; kernels on one stream run in order, so reuse is safe."""
+    key = (device.index, _stream())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _req(t, dtype, name):
+    if not torch.is_tensor(t) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA/HIP tensor — the IPSR layer has no CPU path" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def feat_mask_out_dim(n, layers=3):
+    for _ in range(layers):
+        n = (n + 2 - 4) // 2 + 1
+    return n
+
+
+def feat_mask(mask_hw, layers, threshold):
+    """K1.  mask_hw: [H,W] bool/uint8 CUDA tensor -> [h,w] uint8."""
+    m = mask_hw
+    if m.dtype == torch.bool:
+        m = m.to(torch.uint8)
+    m = _req(m, torch.uint8, "mask")
+    H, W = m.shape
+    out = torch.empty((feat_mask_out_dim(H, layers), feat_mask_out_dim(W, layers)), dtype=torch.uint8, device=m.device)
+    L = _lib.lib()
+    nbytes = L.ipsr_feat_mask_workspace_bytes(H, W, layers)
+    ws = _workspace(nbytes, m.device)
+    _lib.check(L.ipsr_feat_mask(m.data_ptr(), H, W, layers, float(threshold), out.data_ptr(), ws.data_ptr(),
+                                ws.numel(), _stream()), "ipsr_feat_mask")
+    return out
+
+
+def index_prep(feat_hw, patch, stride, mask_thred):
+    """K2.  feat_hw [h,w] uint8 -> (flag [N] i32, mask_point_idx [N] i32 (first M valid), count [1] i32)."""
+    f = _req(feat_hw, torch.uint8, "feature mask")
+    h, w = f.shape
+    n = ((h - patch) // stride + 1) * ((w - patch) // stride + 1)
+    flag = torch.empty(n, dtype=torch.int32, device=f.device)
+    mpi = torch.empty(n, dtype=torch.int32, device=f.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=f.device)
+    _lib.check(_lib.lib().ipsr_index_prep(f.data_ptr(), h, w, patch, stride, int(mask_thred), flag.data_ptr(),
+                                          mpi.data_ptr(), cnt.data_ptr(), _stream()), "ipsr_index_prep")
+    return flag, mpi, cnt
+
+
+def patch_normalize(x_bcn):
+    """K3.  x [B,C,N] -> (xn [B,C,N], inv [B,N])."""
+    x = _req(x_bcn, torch.float32, "x")
+    B, C, N = x.shape
+    xn = torch.empty_like(x)
+    inv = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ipsr_patch_normalize(x.data_ptr(), B, C, N, xn.data_ptr(), inv.data_ptr(), _stream()),
+               "ipsr_patch_normalize")
+    return xn, inv
+
+
+def corr_argmax(xn_bcn, ref_bcn, want_S=False):
+    """K4+K5.  -> (ind [B,N] i32, vmax [B,N], S [B,N,N] or None)."""
+    xn = _req(xn_bcn, torch.float32, "xn")
+    ref = _req(ref_bcn, torch.float32, "ref")
+    B, C, N = xn.shape
+    ind = torch.empty((B, N), dtype=torch.int32, device=xn.device)
+    vmax = torch.empty((B, N), dtype=torch.float32, device=xn.device)
+    S = torch.empty((B, N, N), dtype=torch.float32, device=xn.device) if want_S else None
+    L = _lib.lib()
+    ws = _workspace(L.ipsr_corr_argmax_workspace_bytes(B, C, N), xn.device)
+    _lib.check(L.ipsr_corr_argmax(xn.data_ptr(), ref.data_ptr(), B, C, N, ind.data_ptr(), vmax.data_ptr(),
+                                  S.data_ptr() if want_S else None, ws.data_ptr(), ws.numel(), _stream()),
+               "ipsr_corr_argmax")
+    return ind, vmax, S
+
+
+Forward = namedtuple("Forward", ["out", "ind", "vmax", "attn_rows", "bwd_index"])
+
+
+def forward(x, ref, mask_point_idx_i32, patch=1, stride=1):
+    """Whole layer forward.  x, ref [B,C,h,w] fp32; mask_point_idx_i32 [M] i32 -> Forward."""
+    x = _req(x, torch.float32, "input")
+    ref = _req(ref, torch.float32, "ref.relu4_3")
+    B, C, h, w = x.shape
+    if tuple(ref.shape) != (B, C, h, w):
+        raise RuntimeError("ref.relu4_3 %s does not match input %s" % (tuple(ref.shape), tuple(x.shape)))
+    N = h * w
+    mpi = _req(mask_point_idx_i32, torch.int32, "mask_point_idx")
+    M = int(mpi.numel())
+    L = _lib.lib()
+    dev = x.device
+    out = torch.empty_like(x)
+    ind = torch.empty((B, N), dtype=torch.int32, device=dev)
+    vmax = torch.empty((B, N), dtype=torch.float32, device=dev)
+    attn = torch.empty((B, max(M, 1), N), dtype=torch.float32, device=dev)
+    bidx = torch.empty((B, L.ipsr_bwd_index_ints(N, M)), dtype=torch.int32, device=dev)
+    nbytes = L.ipsr_forward_workspace_bytes(B, C, h, w, M, patch, stride)
+    ws = _workspace(nbytes, dev)
+    _lib.check(L.ipsr_forward(x.data_ptr(), ref.data_ptr(), mpi.data_ptr() if M else None, M, B, C, h, w,
+                              patch, stride, out.data_ptr(), ind.data_ptr(), vmax.data_ptr(), attn.data_ptr(),
+                              bidx.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ipsr_forward")
+    return Forward(out, ind, vmax, attn[:, :M], bidx)
+
+
+def backward(grad_out, mask_point_idx_i32, attn_rows, bwd_index, triple_w):
+    g = _req(grad_out, torch.float32, "grad_output")
+    B, C, h, w = g.shape
+    mpi = _req(mask_point_idx_i32, torch.int32, "mask_point_idx")
+    M = int(mpi.numel())
+    gin = torch.empty_like(g)
+    attn = attn_rows if attn_rows.is_contiguous() else attn_rows.contiguous()
+    _lib.check(_lib.lib().ipsr_backward(g.data_ptr(), mpi.data_ptr() if M else None, M,
+                                        attn.data_ptr() if M else None, bwd_index.data_ptr(), float(triple_w),
+                                        B, C, h, w, gin.data_ptr(), _stream()), "ipsr_backward")
+    return gin
+
+
+def innercos_loss(x, cuse, mask_f32, target, strength):
+    """K9.  x [B,Cx,h,w] (only the first `cuse` channels are read), target [B,cuse,h,w] -> loss [] fp32."""
+    x = _req(x, torch.float32, "in_data")
+    target = _req(target, torch.float32, "target")
+    mask = _req(mask_f32, torch.float32, "mask")
+    B, Cx = x.shape[0], x.shape[1]
+    N = x.shape[2] * x.shape[3]
+    if tuple(target.shape) != (B, cuse, x.shape[2], x.shape[3]) or mask.numel() != N:
+        raise RuntimeError("InnerCos: target %s / mask %s do not match input %s" % (tuple(target.shape), tuple(mask.shape), tuple(x.shape)))
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = _workspace(L.innercos_workspace_bytes(B, cuse, N), x.device)
+    _lib.check(L.innercos_loss(x.data_ptr(), B, Cx, cuse, N, mask.data_ptr(), target.data_ptr(), float(strength),
+                               loss.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "innercos_loss")
+    return loss
+
+
+def innercos_loss_backward(x, cuse, mask_f32, target, strength, grad_loss):
+    x = _req(x, torch.float32, "in_data")
+    target = _req(target, torch.float32, "target")
+    mask = _req(mask_f32, torch.float32, "mask")
+    gl = _req(grad_loss.reshape(1).to(torch.float32), torch.float32, "grad_loss")
+    B, Cx = x.shape[0], x.shape[1]
+    N = x.shape[2] * x.shape[3]
+    gx = torch.empty_like(x)
+    _lib.check(_lib.lib().innercos_loss_backward(x.data_ptr(), B, Cx, cuse, N, mask.data_ptr(), target.data_ptr(),
+                                                 float(strength), gl.data_ptr(), gx.data_ptr(), _stream()),
+               "innercos_loss_backward")
+    return gx

@@ -1,0 +1,310 @@
+"""HIP (through the C-ABI, via deepinpainting_amd.ops) against the CPU oracle and the golden fixtures.
+
+Bar (task ③): bit-exact for index/byte work; fp32 within the north-star tolerance 1e-4 — in fact the
+kernels follow the oracle's canonical summation order, so most fp32 outputs are asserted BIT-EXACT and
+the tolerance is only the fallback documented per assert.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases
+from oracle import ipsr_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LAYER_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "layer_*.npz")))
+ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from deepinpainting_amd import ops as _ops
+    return _ops
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def load(name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    if "x" not in d:
+        d["x"], d["ref"] = golden_cases.big_case_inputs()
+        d["grad_out"] = golden_cases.big_case_grad_out(name)
+        d["ic_target"] = golden_cases.big_case_ic_target()
+    return d
+
+
+def stroke_mask(size, seed, strokes=6):
+    rs = np.random.RandomState(seed)
+    m = np.zeros((size, size), np.uint8)
+    for _ in range(strokes):
+        y, x = rs.randint(0, size, 2)
+        wd = rs.randint(size // 20 + 1, size // 6 + 2)
+        for _ in range(rs.randint(4, 12)):
+            dy, dx = rs.randint(-size // 6, size // 6 + 1, 2)
+            steps = max(abs(dy), abs(dx), 1)
+            for s in range(steps + 1):
+                yy = int(np.clip(y + dy * s / steps, 0, size - 1))
+                xx = int(np.clip(x + dx * s / steps, 0, size - 1))
+                m[max(0, yy - wd // 2):yy + wd // 2 + 1, max(0, xx - wd // 2):xx + wd // 2 + 1] = 1
+            y = int(np.clip(y + dy, 0, size - 1))
+            x = int(np.clip(x + dx, 0, size - 1))
+    return m
+
+
+# ------------------------------------------------------------------------------------------ K1 / K2
+def test_masks_vs_golden_and_oracle(ops):
+    d = np.load(os.path.join(GOLDEN, "masks.npz"))
+    tags = sorted({k.rsplit("__", 1)[0] for k in d.files if k.endswith("__mask")})
+    for tag in tags:
+        thr = float(tag.split("__thr")[1])
+        feat = ops.feat_mask(dev(d[tag + "__mask"]), 3, thr)
+        np.testing.assert_array_equal(feat.cpu().numpy(), d[tag + "__feat"], err_msg=tag)
+        flag, mpi, cnt = ops.index_prep(feat, 1, 1, 1)
+        M = int(cnt.item())
+        np.testing.assert_array_equal(flag.cpu().numpy(), d[tag + "__flag"])
+        np.testing.assert_array_equal(mpi.cpu().numpy()[:M], d[tag + "__mask_point_idx"])
+        assert (mpi.cpu().numpy()[M:] == -1).all()
+
+
+@pytest.mark.parametrize("size,layers", [(256, 3), (512, 3), (130, 2), (67, 1), (96, 4)])
+def test_feat_mask_random_vs_oracle(ops, size, layers):
+    rs = np.random.RandomState(size)
+    for thr in (5 / 16.0, 0.1, 0.7):
+        m = (rs.rand(size, size + 6) < 0.45).astype(np.uint8)
+        want = orc.feat_mask(m, layers, thr)
+        got = ops.feat_mask(dev(m), layers, thr).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        ip = orc.index_prep(want)
+        flag, mpi, cnt = ops.index_prep(dev(want), 1, 1, 1)
+        M = int(cnt.item())
+        assert M == ip.mask_point_idx.shape[0]
+        np.testing.assert_array_equal(flag.cpu().numpy(), ip.flag)
+        np.testing.assert_array_equal(mpi.cpu().numpy()[:M], ip.mask_point_idx)
+
+
+def test_index_prep_large_N(ops):
+    rs = np.random.RandomState(5)
+    f = (rs.rand(64, 80) < 0.3).astype(np.uint8)          # N = 5120 > one 1024-chunk
+    ip = orc.index_prep(f)
+    flag, mpi, cnt = ops.index_prep(dev(f), 1, 1, 1)
+    M = int(cnt.item())
+    np.testing.assert_array_equal(mpi.cpu().numpy()[:M], ip.mask_point_idx)
+    np.testing.assert_array_equal(flag.cpu().numpy(), ip.flag)
+
+
+# ------------------------------------------------------------------------------------------ K3 / K4 / K5
+@pytest.mark.parametrize("B,C,N", [(2, 16, 64), (1, 20, 64), (2, 512, 64), (1, 32, 256), (3, 8, 100), (2, 512, 1024),
+                                   (1, 100, 384)])
+def test_normalize_corr_argmax_bit_exact(ops, B, C, N):
+    rs = np.random.RandomState(B * 1000 + C + N)
+    x = np.abs(rs.standard_normal((B, C, N))).astype(np.float32)
+    ref = rs.rand(B, C, N).astype(np.float32)
+    xn_o, inv_o = orc.patch_normalize(x)
+    xn, inv = ops.patch_normalize(dev(x))
+    np.testing.assert_array_equal(inv.cpu().numpy(), inv_o)       # same segment order, sqrt and divide correctly rounded
+    np.testing.assert_array_equal(xn.cpu().numpy(), xn_o)
+    want_S = N <= 384
+    ind_o, vmax_o, S_o = orc.corr_argmax(xn_o, ref, want_S=want_S)
+    ind, vmax, S = ops.corr_argmax(xn, dev(ref), want_S=want_S)
+    if want_S:
+        np.testing.assert_array_equal(S.cpu().numpy(), S_o)      # MFMA f32 == ascending fmaf chain
+    np.testing.assert_array_equal(ind.cpu().numpy(), ind_o)
+    np.testing.assert_array_equal(vmax.cpu().numpy(), vmax_o)
+
+
+def test_argmax_ties_lowest_index(ops):
+    # identical patches and identical reference columns: argmax must resolve to the lowest patch index
+    rs = np.random.RandomState(3)
+    B, C, N = 1, 16, 256
+    x = np.abs(rs.standard_normal((B, C, N))).astype(np.float32)
+    x[:, :, 40] = x[:, :, 7]
+    x[:, :, 128:] = x[:, :, :128]            # every patch duplicated 128 positions later (other k-tile / wave)
+    ref = rs.rand(B, C, N).astype(np.float32)
+    xn, _ = ops.patch_normalize(dev(x))
+    ind, vmax, _ = ops.corr_argmax(xn, dev(ref))
+    ind = ind.cpu().numpy()
+    assert (ind < 128).all()
+    assert not (ind == 40).any()
+    ind_o, vmax_o, _ = orc.corr_argmax(orc.patch_normalize(x)[0], ref)
+    np.testing.assert_array_equal(ind, ind_o)
+
+
+# ------------------------------------------------------------------------------------------ whole layer
+def run_hip_layer(ops, x, ref, mpi, triple_w, g):
+    f = ops.forward(dev(x), dev(ref), dev(mpi, torch.int32))
+    gin = ops.backward(dev(g), dev(mpi, torch.int32), f.attn_rows, f.bwd_index, triple_w)
+    torch.cuda.synchronize()
+    return f, gin
+
+
+@pytest.mark.parametrize("name", LAYER_CASES)
+def test_layer_vs_oracle_bit_exact_and_vs_reference(ops, name):
+    d = load(name)
+    x, ref, mpi = d["x"], d["ref"], d["mask_point_idx"]
+    tw = float(d["triple_w"])
+    fo = orc.forward(x, ref, mpi)
+    gin_o = orc.backward(d["grad_out"], mpi, fo.attn_rows, fo.bwd_index, tw)
+    f, gin = run_hip_layer(ops, x, ref, mpi, tw, d["grad_out"])
+    # --- HIP vs oracle: everything bit-exact
+    np.testing.assert_array_equal(f.ind.cpu().numpy(), fo.ind)
+    np.testing.assert_array_equal(f.vmax.cpu().numpy(), fo.vmax)
+    np.testing.assert_array_equal(f.attn_rows.cpu().numpy(), fo.attn_rows)
+    np.testing.assert_array_equal(f.bwd_index.cpu().numpy(), fo.bwd_index)
+    np.testing.assert_array_equal(f.out.cpu().numpy(), fo.out)
+    np.testing.assert_array_equal(gin.cpu().numpy(), gin_o)
+    # --- HIP vs the reference's own output (golden fixture), north-star tolerance
+    if "signed" in name:
+        return  # ill-conditioned on purpose: covered by the oracle-relative test
+    np.testing.assert_array_equal(f.ind.cpu().numpy().astype(np.int64), d["ind"])
+    out = f.out.cpu().numpy()
+    out = out if "out_channels" not in d else out[:, d["out_channels"]]
+    assert np.abs(out - d["out"]).max() <= ATOL
+    g_ = gin.cpu().numpy()
+    g_ = g_ if "grad_in_channels" not in d else g_[:, d["grad_in_channels"]]
+    assert np.abs(g_ - d["grad_in"]).max() <= ATOL
+
+
+@pytest.mark.parametrize("B,C,h,w,seed", [(2, 24, 12, 20, 1), (1, 512, 16, 16, 2), (4, 64, 32, 32, 3), (1, 520, 8, 8, 4),
+                                          (1, 1024, 8, 8, 5)])
+def test_layer_random_shapes_vs_oracle(ops, B, C, h, w, seed):
+    rs = np.random.RandomState(seed)
+    x = np.abs(rs.standard_normal((B, C, h, w))).astype(np.float32)
+    ref = rs.rand(B, C, h, w).astype(np.float32)
+    feat = (rs.rand(h, w) < 0.3).astype(np.uint8)
+    mpi = orc.index_prep(feat).mask_point_idx
+    g = rs.standard_normal((B, C, h, w)).astype(np.float32)
+    fo = orc.forward(x, ref, mpi)
+    gin_o = orc.backward(g, mpi, fo.attn_rows, fo.bwd_index, 0.75)
+    f, gin = run_hip_layer(ops, x, ref, mpi, 0.75, g)
+    np.testing.assert_array_equal(f.ind.cpu().numpy(), fo.ind)
+    np.testing.assert_array_equal(f.attn_rows.cpu().numpy(), fo.attn_rows)
+    np.testing.assert_array_equal(f.bwd_index.cpu().numpy(), fo.bwd_index)
+    np.testing.assert_array_equal(f.out.cpu().numpy(), fo.out)
+    np.testing.assert_array_equal(gin.cpu().numpy(), gin_o)
+
+
+def test_layer_truncation_survivors(ops):
+    """Signed features make |attention| >= 1 entries that survive the reference's LongTensor truncation
+    (models/IPSRFunction.py:36,134): the backward must include them exactly like the oracle."""
+    d = load("layer_c16_8x8_signed")
+    fo = orc.forward(d["x"], d["ref"], d["mask_point_idx"])
+    N = 64
+    assert (fo.bwd_index[:, 2 * N + 1] > 1).any(), "fixture should have truncation survivors beyond row 0"
+    gin_o = orc.backward(d["grad_out"], d["mask_point_idx"], fo.attn_rows, fo.bwd_index, 1.0)
+    f, gin = run_hip_layer(ops, d["x"], d["ref"], d["mask_point_idx"], 1.0, d["grad_out"])
+    np.testing.assert_array_equal(f.bwd_index.cpu().numpy(), fo.bwd_index)
+    np.testing.assert_array_equal(gin.cpu().numpy(), gin_o)
+
+
+def test_layer_full_size_properties(ops):
+    """BASELINE config 2 at full size (B=8, 512x32x32, M=256): size-independent properties."""
+    rs = np.random.RandomState(99)
+    B, C, h = 8, 512, 32
+    x = np.abs(rs.standard_normal((B, C, h, h))).astype(np.float32)
+    ref = rs.rand(B, C, h, h).astype(np.float32)
+    m = np.zeros((256, 256), np.uint8)
+    m[64:192, 64:192] = 1
+    feat = ops.feat_mask(dev(m), 3, 5 / 16.0)
+    flag, mpi_d, cnt = ops.index_prep(feat, 1, 1, 1)
+    M = int(cnt.item())
+    assert M == 256
+    mpi = mpi_d[:M].contiguous()
+    f = ops.forward(dev(x), dev(ref), mpi)
+    out, ind, attn = f.out.cpu().numpy(), f.ind.cpu().numpy(), f.attn_rows.cpu().numpy()
+    N = h * h
+    xf = x.reshape(B, C, N)
+    nonmask = np.setdiff1d(np.arange(N), mpi.cpu().numpy())
+    # 1. non-masked positions are exact copies of the best-matching patch
+    for b in range(B):
+        np.testing.assert_array_equal(out.reshape(B, C, N)[b][:, nonmask], xf[b][:, ind[b][nonmask]])
+    # 2. attention rows are convex weights here (non-negative features): sum to 1, in [0,1]
+    assert np.abs(attn.sum(-1) - 1).max() < 1e-5 and attn.min() >= 0 and attn.max() <= 1
+    # 3. masked outputs are the attention-weighted patches (checked in fp64)
+    mp = mpi.cpu().numpy()
+    for b in (0, 7):
+        want = attn[b].astype(np.float64) @ xf[b].T.astype(np.float64)        # [M,C]
+        got = out.reshape(B, C, N)[b][:, mp].T
+        assert np.abs(got - want).max() < 1e-4
+    # 4. per-sample independence: sample 3 alone gives the same bits
+    f1 = ops.forward(dev(x[3:4]), dev(ref[3:4]), mpi)
+    np.testing.assert_array_equal(f1.out.cpu().numpy()[0], out[3])
+    # 5. backward is linear in the upstream gradient, and sample 0 matches the oracle bit for bit
+    g1 = rs.standard_normal(x.shape).astype(np.float32)
+    gi1 = ops.backward(dev(g1), mpi, f.attn_rows, f.bwd_index, 1.0).cpu().numpy()
+    gi2 = ops.backward(dev(2 * g1), mpi, f.attn_rows, f.bwd_index, 1.0).cpu().numpy()
+    np.testing.assert_array_equal(gi2, 2 * gi1)
+    fo = orc.forward(x[:1], ref[:1], mp)
+    np.testing.assert_array_equal(out[0], fo.out[0])
+    np.testing.assert_array_equal(gi1[0], orc.backward(g1[:1], mp, fo.attn_rows, fo.bwd_index, 1.0)[0])
+
+
+def test_layer_stress_size_cfg4_properties(ops):
+    """BASELINE config 4 feature size (512x64x64, N=4096, M=1024), one sample: property checks."""
+    rs = np.random.RandomState(17)
+    C, h = 512, 64
+    x = np.abs(rs.standard_normal((1, C, h, h))).astype(np.float32)
+    ref = rs.rand(1, C, h, h).astype(np.float32)
+    feat = np.zeros((h, h), np.uint8)
+    feat[16:48, 16:48] = 1
+    mp = orc.index_prep(feat).mask_point_idx
+    f = ops.forward(dev(x), dev(ref), dev(mp, torch.int32))
+    N = h * h
+    out, ind, attn = f.out.cpu().numpy().reshape(C, N), f.ind.cpu().numpy()[0], f.attn_rows.cpu().numpy()[0]
+    nonmask = np.setdiff1d(np.arange(N), mp)
+    np.testing.assert_array_equal(out[:, nonmask], x.reshape(C, N)[:, ind[nonmask]])
+    assert np.abs(attn.sum(-1) - 1).max() < 1e-5
+    # arg-max against an fp64 recomputation on a subset of columns
+    xn = orc.patch_normalize(x.reshape(1, C, N))[0][0].astype(np.float64)
+    cols = rs.choice(N, 64, replace=False)
+    S = xn.T @ ref.reshape(C, N)[:, cols].astype(np.float64)
+    top = S.max(0)
+    assert np.abs(S[ind[cols], np.arange(64)] - top).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ K9
+@pytest.mark.parametrize("name", LAYER_CASES + ["innercos2_c1024_8x8"])
+def test_innercos_vs_golden(ops, name):
+    d = load(name)
+    cuse = d["ic_target"].shape[1]
+    mask = dev(d["feat_mask"].astype(np.float32).reshape(-1))
+    loss = ops.innercos_loss(dev(d["x"]), cuse, mask, dev(d["ic_target"]), float(d["strength"]))
+    np.testing.assert_allclose(loss.item(), d["ic_loss"], rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), orc.innercos_loss(d["x"], d["feat_mask"], d["ic_target"], float(d["strength"])), rtol=1e-6)
+    if "ic_grad" in d:
+        one = torch.ones((), device="cuda")
+        g = ops.innercos_loss_backward(dev(d["x"]), cuse, mask, dev(d["ic_target"]), float(d["strength"]), one)
+        np.testing.assert_allclose(g.cpu().numpy(), d["ic_grad"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_array_equal(g.cpu().numpy(), orc.innercos_loss_backward(d["x"], d["feat_mask"], d["ic_target"], float(d["strength"])))
+
+
+def test_innercos_full_size(ops):
+    rs = np.random.RandomState(8)
+    x = rs.standard_normal((8, 1024, 32, 32)).astype(np.float32)
+    t = rs.rand(8, 512, 32, 32).astype(np.float32)
+    m = (rs.rand(32, 32) < 0.25).astype(np.float32)
+    loss = ops.innercos_loss(dev(x), 512, dev(m.reshape(-1)), dev(t), 1.0).item()
+    want = np.mean((x[:, :512].astype(np.float64) * m - t) ** 2)
+    assert abs(loss - want) <= 1e-6 * want
+
+
+# ------------------------------------------------------------------------------------------ errors
+def test_error_behaviour(ops):
+    x = torch.zeros(1, 8, 8, 8, device="cuda")
+    mpi = torch.zeros(4, dtype=torch.int32, device="cuda")
+    with pytest.raises(NotImplementedError):      # reference raises for shift_sz=3 too (IPSRFunction.py:134)
+        ops.forward(x, x, mpi, patch=3, stride=1)
+    with pytest.raises(RuntimeError):
+        ops.forward(x.cpu(), x.cpu(), mpi)
+    with pytest.raises(RuntimeError):
+        ops.forward(x, torch.zeros(1, 8, 4, 4, device="cuda"), mpi)
