@@ -1,0 +1,153 @@
+"""Data-parallel gradient exchange for the IPSR trainer: one process per GPU, RCCL over xGMI.
+
+The reference is single-GPU (no torch.distributed anywhere); this is the only exchange step
+data parallelism needs: the gradients of (netD, netF) after backward_D and of (netG, netP) after
+backward_G are summed over ranks and divided by the world size (models/IPSR.py:271-278 is where the
+optimizer steps consume them).  Gradients that backward_G deposits in netD/netF are dropped by the next
+zero_grad and therefore NOT exchanged.
+
+Design for the MI355X node (8 GPUs, full xGMI mesh, 7 links x ~153 GB/s per GPU):
+  * parameters are packed — in reverse registration order, roughly the order autograd produces their
+    gradients — into a few large flat fp32 buckets (64 MiB default: 528 MB of G+P gradients -> 8-9
+    all-reduces, each big enough to be bandwidth- not latency-bound on the mesh);
+  * a bucket's all-reduce is launched asynchronously from the post-accumulate-grad hook of its last
+    parameter, i.e. while autograd is still producing earlier layers' gradients (overlap with backward);
+  * `finish()` waits, scales by 1/world and scatters the flat result back into the .grad tensors.
+Works with any torch.distributed backend ("nccl" == RCCL on ROCm; "gloo" for the CPU tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank); a no-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def broadcast_module(module, src=0, group=None):
+    """Make every rank start from rank `src`'s parameters and buffers (one flat broadcast per dtype)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b.is_floating_point()]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+        off += n
+
+
+class GradBucketReducer(object):
+    """Bucketed, overlapped all-reduce(mean) of the gradients of a fixed set of modules."""
+
+    def __init__(self, modules, bucket_bytes=64 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        params = [p for m in modules for p in m.parameters() if p.requires_grad]
+        params.reverse()
+        self.buckets = []          # list of dicts: params, numel, flat
+        cur, cur_n = [], 0
+        cap = max(1, bucket_bytes // 4)
+        for p in params:
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append({"params": cur, "numel": cur_n})
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append({"params": cur, "numel": cur_n})
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            b["flat"] = None
+            for p in b["params"]:
+                self._bucket_of[p] = bi
+        self.armed = False
+        self._pending = None
+        self._work = []
+        self._hooks = []
+        if self.world > 1:
+            for p in params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # -- life cycle of one backward pass ------------------------------------------------------------
+    def arm(self):
+        """Call right before the backward whose gradients should be exchanged."""
+        self.armed = self.world > 1
+        self._pending = [len(b["params"]) for b in self.buckets]
+        self._work = []
+
+    def _on_grad(self, p):
+        if not self.armed:
+            return
+        bi = self._bucket_of[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        dev = b["params"][0].device
+        if b["flat"] is None or b["flat"].device != dev:
+            b["flat"] = torch.empty(b["numel"], dtype=torch.float32, device=dev)
+        flat = b["flat"]
+        views, off = [], 0
+        for p in b["params"]:
+            n = p.numel()
+            views.append(flat[off:off + n].view_as(p))
+            off += n
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b["params"]]
+        torch._foreach_copy_(views, grads)
+        self._work.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), views))
+
+    def finish(self):
+        """Call after the backward, before optimizer.step(): waits for the collectives and writes the
+        rank-averaged gradients back.  Buckets whose hooks never fired (unused parameters) are reduced
+        here synchronously so every rank issues the same collectives in the same order."""
+        if not self.armed:
+            return
+        launched = {bi for bi, _, _ in self._work}
+        for bi in range(len(self.buckets)):
+            if bi not in launched:
+                self._launch(bi)
+        inv = 1.0 / self.world
+        for bi, work, views in self._work:
+            work.wait()
+            b = self.buckets[bi]
+            b["flat"].mul_(inv)
+            for p, v in zip(b["params"], views):
+                if p.grad is None:
+                    p.grad = v.clone()
+                else:
+                    p.grad.copy_(v)
+        self._work = []
+        self.armed = False
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def all_reduce_mean_scalars(values, device, group=None):
+    """Average a few python floats over ranks (logging only)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, group=group)
+    return (t / dist.get_world_size(group)).tolist()

@@ -1,0 +1,44 @@
+"""IPSRFunction — the reference's autograd surface (models/IPSRFunction.py) on libipsr_hip.so.
+
+    out = IPSRFunction.apply(input, mask, ref, shift_sz, stride, triple_w, flag, nonmask_point_idx,
+                             mask_point_idx, flatten_offsets, sp_x, sp_y)
+
+Same 12 arguments, same output [B,C,h,w], backward returns (grad_input, None x 11) exactly like the
+reference (:178).  What differs is only HOW: the reference loops over positions in Python and
+materialises the N x N attention matrix `kbar` per sample (:36,78,134); here one C-ABI call launches the
+fused kernels (normalise -> MFMA correlation + arg-max -> recurrence -> reconstruction) and keeps `kbar`
+in sparse form (the masked rows + a CSR of the one-hot rows).
+"""
+import torch
+
+from .. import ops
+
+
+class IPSRFunction(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, input, mask, ref, shift_sz, stride, triple_w, flag, nonmask_point_idx, mask_point_idx,
+                flatten_offsets, sp_x, sp_y):
+        assert input.dim() == 4, "Input Dim has to be 4"
+        assert mask.dim() == 2, "Mask dimension must be 2"
+        ctx.triple_w = triple_w
+        ctx.flag = flag
+        ctx.flatten_offsets = flatten_offsets
+        ctx.bz, _, ctx.h, ctx.w = input.size()
+
+        mpi32 = getattr(mask_point_idx, "_ipsr_i32", None)
+        if mpi32 is None or mpi32.device != input.device:
+            mpi32 = mask_point_idx.to(device=input.device, dtype=torch.int32)
+        # `ref` is the VGG namedtuple; only relu4_3 is read (reference :49)
+        f = ops.forward(input.detach(), ref.relu4_3.detach(), mpi32, int(shift_sz), int(stride))
+        ctx.mpi32 = mpi32
+        ctx.attn_rows = f.attn_rows        # the reference's `in_attention` rows [B,M,N]
+        ctx.bwd_index = f.bwd_index        # sparse trunc(kbar)  (reference ctx.ind_lst, :139)
+        ctx.ind = f.ind
+        ctx.vmax = f.vmax
+        return f.out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        grad_input = ops.backward(grad_output, ctx.mpi32, ctx.attn_rows, ctx.bwd_index, ctx.triple_w)
+        return grad_input, None, None, None, None, None, None, None, None, None, None, None

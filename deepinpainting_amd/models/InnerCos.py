@@ -1,0 +1,78 @@
+"""InnerCos / InnerCos2 — feature-consistency loss taps (reference models/InnerCos.py, models/InnerCos2.py).
+
+Pass-through modules: forward returns its input unchanged and stashes
+    loss = MSE( (x * mask) * strength , target )
+(InnerCos2 on the first 512 channels of the skip-concatenated tensor, InnerCos2.py:38).  The value is
+computed by ONE fused HIP reduction (K9) instead of three element-wise passes + a reduction; it is an
+autograd node (so the reference's `.backward()` method keeps working) although the trainer only ever
+adds it detached (models/IPSR.py:258,262).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..util import util
+
+
+class _InnerCosLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cuse, mask, target, strength):
+        ctx.save_for_backward(x, mask, target)
+        ctx.cuse, ctx.strength = cuse, strength
+        return ops.innercos_loss(x.detach(), cuse, mask, target, strength)
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        x, mask, target = ctx.saved_tensors
+        return ops.innercos_loss_backward(x, ctx.cuse, mask, target, ctx.strength, grad_loss), None, None, None, None
+
+
+class InnerCos(nn.Module):
+    _narrow = None      # InnerCos2 narrows the channel dim to 512
+
+    def __init__(self, crit='MSE', strength=1, skip=0):
+        super(InnerCos, self).__init__()
+        self.crit = crit
+        if crit != 'MSE':
+            raise NotImplementedError("InnerCos: only the MSE criterion (the reference default, models/networks.py:312) "
+                                      "has a HIP kernel")
+        self.criterion = torch.nn.MSELoss()     # kept for attribute parity; the fused kernel computes the value
+        self.strength = strength
+        self.target = None
+        self.skip = skip
+        self.mask = None
+        self.loss = 0
+
+    def set_mask(self, mask_global, opt, feat_mask=None):
+        """reference InnerCos.py:16-21: the 3-level feature mask as a float [h,w] tensor."""
+        mask = feat_mask if feat_mask is not None else util.cal_feat_mask(mask_global, 3, opt.threshold)
+        self.mask = mask.squeeze().float()
+
+    def set_target(self, targetIn):
+        self.target = targetIn
+
+    def get_target(self):
+        return self.target
+
+    def forward(self, in_data):
+        if not self.skip:
+            cuse = in_data.size(1) if self._narrow is None else self._narrow
+            self.bs, self.c = in_data.size(0), cuse
+            self.former = in_data if self._narrow is None else in_data.narrow(1, 0, cuse)
+            self.loss = _InnerCosLoss.apply(in_data, cuse, self.mask, self.target, float(self.strength))
+            self.output = in_data
+        else:
+            self.loss = 0
+            self.output = in_data
+        return self.output
+
+    def backward(self, retain_graph=True):
+        if not self.skip:
+            self.loss.backward(retain_graph=retain_graph)
+        return self.loss
+
+    def __repr__(self):
+        skip_str = 'True' if not self.skip else 'False'
+        return self.__class__.__name__ + '(' \
+            + 'skip: ' + skip_str \
+            + ' ,strength: ' + str(self.strength) + ')'

@@ -1,0 +1,85 @@
+"""Vgg16 feature extractor — mirror of the reference's models/vgg16.py WITHOUT torchvision and WITHOUT
+any network access.
+
+The reference builds torchvision's vgg16(pretrained=True).features (which downloads ImageNet weights)
+and cuts it into four slices [0:5) [5:10) [10:17) [17:23) (:9-21).  Each of the first three slices ENDS
+with its max-pool, so "relu3_3" is 256 ch @ H/8 and "relu4_3" is 512 ch @ H/8 — the map the IPSR layer
+matches against.  Same slice names and in-slice indices here, so a torchvision `features.*` state_dict
+can be loaded with `load_torchvision_state_dict`.  Weights: `IPSR_VGG16_WEIGHTS=/path/to/vgg16.pth`
+(or the `weights_path` argument); without it the net is seeded-random (He normal) — "parity unpinned",
+see DESIGN.md.
+"""
+import os
+from collections import namedtuple
+
+import torch
+import torch.nn as nn
+
+# torchvision vgg16 'D' configuration up to features[22]
+_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512]
+_SLICES = ((0, 5), (5, 10), (10, 17), (17, 23))
+
+VggOutputs = namedtuple("VggOutputs", ['relu1_2', 'relu2_2', 'relu3_3', 'relu4_3'])
+
+
+def _feature_layers():
+    layers, cin = [], 3
+    for v in _CFG:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return layers
+
+
+class Vgg16(torch.nn.Module):
+    def __init__(self, requires_grad=False, weights_path=None, seed=1234):
+        super(Vgg16, self).__init__()
+        feats = _feature_layers()
+        assert len(feats) == 23
+        for si, (lo, hi) in enumerate(_SLICES, start=1):
+            seq = torch.nn.Sequential()
+            for idx in range(lo, hi):
+                seq.add_module(str(idx), feats[idx])
+            setattr(self, 'slice%d' % si, seq)
+        weights_path = weights_path or os.environ.get('IPSR_VGG16_WEIGHTS')
+        if weights_path:
+            self.load_torchvision_state_dict(torch.load(weights_path, map_location='cpu'))
+            self.pretrained = True
+        else:
+            gen = torch.Generator().manual_seed(seed)
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    fan_out = m.weight.size(0) * m.weight.size(2) * m.weight.size(3)
+                    with torch.no_grad():
+                        m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (2.0 / fan_out) ** 0.5)
+                        m.bias.zero_()
+            self.pretrained = False
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def load_torchvision_state_dict(self, sd):
+        """Accepts torchvision's vgg16 state_dict ('features.N.weight') or this module's own."""
+        own = self.state_dict()
+        mapped = {}
+        for k, v in sd.items():
+            if k.startswith('features.'):
+                idx = int(k.split('.')[1])
+                for si, (lo, hi) in enumerate(_SLICES, start=1):
+                    if lo <= idx < hi:
+                        mapped['slice%d.%d.%s' % (si, idx, k.split('.')[2])] = v
+            elif k in own:
+                mapped[k] = v
+        missing = [k for k in own if k not in mapped]
+        if missing:
+            raise RuntimeError("VGG16 weights file lacks %s" % missing[:4])
+        self.load_state_dict(mapped)
+
+    def forward(self, X):
+        h1 = self.slice1(X)
+        h2 = self.slice2(h1)
+        h3 = self.slice3(h2)
+        h4 = self.slice4(h3)
+        return VggOutputs(h1, h2, h3, h4)

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-from golden_cases import big_case_inputs, grad_seed  # noqa: E402
+from golden_cases import big_case_inputs, grad_seed, reinit_deterministic, trainer_inputs, net_input  # noqa: E402
 
 REF = os.environ.get("IPSR_REFERENCE", "/root/reference")
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
@@ -248,6 +248,144 @@ def run_mask_cases(R, name):
     print("%-28s %d masks -> %s (%.1f KB)" % (name, len(cases) * 2, os.path.relpath(path), os.path.getsize(path) / 1024.0))
 
 
+class _Opt(object):
+    """train.ipynb cell 0 defaults (the fields the models read)."""
+    def __init__(self, **kw):
+        d = dict(batchSize=1, fineSize=256, input_nc=3, input_nc_g=6, output_nc=3, ngf=64, ndf=64,
+                 which_model_netD='basic', which_model_netF='feature', which_model_netG='unet_ipsr',
+                 which_model_netP='unet_256', triple_weight=1, name='golden', n_layers_D='3', gpu_ids=[],
+                 model='ipsr_net', checkpoints_dir='/tmp/ipsr_golden_ckpt', norm='instance', fixed_mask=1,
+                 use_dropout=False, init_type='normal', mask_type='random', lambda_A=100, threshold=5 / 16.0,
+                 stride=1, shift_sz=1, mask_thred=1, bottleneck=512, gp_lambda=10.0, ncritic=5, constrain='MSE',
+                 strength=1, init_gain=0.02, cosis=1, gan_type='lsgan', gan_weight=0.2, overlap=4, skip=0,
+                 continue_train=False, epoch_count=1, phase='train', which_epoch='', niter=20, niter_decay=100,
+                 beta1=0.5, lr=0.0002, lr_policy='lambda', lr_decay_iters=50, isTrain=True)
+        d.update(kw)
+        self.__dict__.update(d)
+
+
+def _sub(t):
+    """Keep fixtures small: every 5th pixel of every channel."""
+    return t.detach().numpy()[..., ::5, ::5].copy()
+
+
+def run_network_cases(name):
+    """Module tree (state_dict keys + shapes), parameter counts (train.ipynb cell 1 output) and forward
+    outputs of the reference's four nets under deterministic weights."""
+    import io
+    import contextlib
+    from models import networks as rnet
+    opt = _Opt()
+    mask_global = torch.zeros(1, 1, 256, 256, dtype=torch.bool)
+    mask_global[:, :, 64:192, 64:192] = 1
+    d = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        netG, cos1, cos2, csa = rnet.define_G(6, 3, 64, 'unet_ipsr', opt, mask_global, 'instance', False, 'normal', [], 0.02)
+        netP, _, _, _ = rnet.define_G(3, 3, 64, 'unet_256', opt, mask_global, 'instance', False, 'normal', [], 0.02)
+        netD = rnet.define_D(3, 64, 'basic', '3', 'instance', False, 'normal', [], 0.02)
+        netF = rnet.define_D(3, 64, 'feature', '3', 'instance', False, 'normal', [], 0.02)
+    for tag, net in (("G", netG), ("P", netP), ("D", netD), ("F", netF)):
+        sd = net.state_dict()
+        d["keys_" + tag] = np.array(list(sd.keys()))
+        d["shapes_" + tag] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        d["nparams_" + tag] = np.int64(sum(p.numel() for p in net.parameters()))
+        reinit_deterministic(net, 100 + ord(tag))
+        net.eval()
+    assert [int(d["nparams_" + t]) for t in "GPDF"] == [77692291, 54419459, 2766529, 10487296]
+    with torch.no_grad():
+        d["out_P"] = _sub(netP(net_input((1, 3, 256, 256), 1)))
+        d["out_D"] = netD(net_input((1, 3, 256, 256), 2)).numpy()
+        d["out_F"] = netF(net_input((1, 256, 32, 32), 3)).numpy()
+        # netG needs the layer state: ref features + InnerCos targets (values unused by the forward output)
+        ref_feat = net_input((1, 512, 32, 32), 4).abs()
+        csa[0].set_ref(Vgg(None, None, None, ref_feat))
+        cos1[0].set_target(ref_feat)
+        cos2[0].set_target(ref_feat)
+        out_G = netG(net_input((1, 6, 256, 256), 5))
+        d["out_G"] = _sub(out_G)
+        d["ic_loss_G"] = np.array([cos1[0].loss.item(), cos2[0].loss.item()], np.float32)
+    # GANLoss known answers
+    gl = rnet.GANLoss(gan_type='lsgan', tensor=torch.FloatTensor)
+    a, b = net_input((2, 1, 30, 30), 6), net_input((2, 1, 30, 30), 7)
+    d["ganloss"] = np.array([gl(a, b, True).item(), gl(a, b, False).item()], np.float32)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("%-28s -> %s (%.1f KB)" % (name, os.path.relpath(path), os.path.getsize(path) / 1024.0))
+
+
+def run_trainer_case(name):
+    """One optimize_parameters() of the reference's IPSR trainer on CPU.  models/vgg16.py imports
+    torchvision, absent from this image; a minimal `torchvision.models.vgg16` with the standard VGG16-D
+    `features` layout (random init, no download) is registered for this process so the import succeeds.
+    All weights (4 nets + VGG) are then overwritten deterministically, so the stand-in's init is moot."""
+    import io
+    import contextlib
+    import types as _types
+    import torch.nn as nn
+
+    def vgg16(pretrained=False, **kw):
+        cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+        layers, cin = [], 3
+        for v in cfg:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        return _types.SimpleNamespace(features=nn.Sequential(*layers))
+
+    tv = _types.ModuleType("torchvision")
+    tv.models = _types.ModuleType("torchvision.models")
+    tv.models.vgg16 = vgg16
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tv.models
+    from models.models import create_model
+    import models.IPSR as rIPSR
+
+    opt = _Opt(batchSize=1)
+    # models/IPSR.py:19 hard-codes torch.device('cuda'); build, then point the object at the CPU
+    orig_device = torch.device
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(opt)
+    model.device = orig_device('cpu')
+    for i, net in enumerate((model.netG, model.netP, model.netD, model.netF, model.vgg)):
+        reinit_deterministic(net, 500 + i)
+    img, mask, ref = trainer_inputs()
+    model.set_input(img, mask, ref)
+    model.set_ref_latent()
+    model.set_gt_latent()
+    model.optimize_parameters()
+    errs = model.get_current_errors()
+    d = dict(
+        errors=np.array([errs['G_GAN'], errs['G_L1'], errs['D'], errs['F']], np.float64),
+        ng_loss=np.array([float(model.ng_loss_value), float(model.ng_loss_value2)], np.float64),
+        loss_G=np.float64(model.loss_G.item()), loss_D=np.float64(model.loss_D.item()),
+        get_loss=np.float64(model.get_loss()['GAN']),
+        fake_B=_sub(model.fake_B), fake_P=_sub(model.fake_P), real_A=_sub(model.real_A),
+        n_visuals=np.int64(len(model.get_current_visuals())),
+    )
+    # a few post-step parameter values: pins the Adam update + the gradient paths (incl. IPSRFunction.backward)
+    for tag, net in (("G", model.netG), ("P", model.netP), ("D", model.netD), ("F", model.netF)):
+        sd = net.state_dict()
+        ks = [k for k in sd if k.endswith("weight")]
+        pick = [ks[0], ks[len(ks) // 2], ks[-1]]
+        d["post_keys_" + tag] = np.array(pick)
+        named = dict(net.named_parameters())
+        for j, k in enumerate(pick):
+            d["post_%s_%d" % (tag, j)] = sd[k].detach().numpy().reshape(-1)[:256].copy()
+            d["grad_%s_%d" % (tag, j)] = named[k].grad.detach().numpy().reshape(-1)[:256].copy()
+    # second iteration's losses: depend on every updated weight
+    model.set_input(img, mask, ref)
+    model.set_ref_latent()
+    model.set_gt_latent()
+    model.optimize_parameters()
+    e2 = model.get_current_errors()
+    d["errors_iter2"] = np.array([e2['G_GAN'], e2['G_L1'], e2['D'], e2['F']], np.float64)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("%-28s -> %s (%.1f KB)  errors=%s" % (name, os.path.relpath(path), os.path.getsize(path) / 1024.0, dict(errs)))
+
+
 def main():
     _install_cpu_aliases()
     R = _import_reference()
@@ -299,6 +437,8 @@ def main():
                    keep_channels=np.arange(0, 512, 37), note="BASELINE config 2, one sample")
 
     run_innercos2_case(R, "innercos2_c1024_8x8")
+    run_network_cases("networks")
+    run_trainer_case("trainer_step")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,216 @@
+"""GPU tests of the Python drop-in surface (IPSRFunction.apply / IPSR_model / InnerCos / util.* /
+create_model + IPSR trainer) against the fixtures captured from the reference."""
+import contextlib
+import glob
+import io
+import os
+from collections import namedtuple
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LAYER_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "layer_*.npz")))
+Vgg = namedtuple("VggOutputs", ["relu1_2", "relu2_2", "relu3_3", "relu4_3"])
+ATOL = 1e-4
+
+
+def load(name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    if "x" not in d:
+        d["x"], d["ref"] = golden_cases.big_case_inputs()
+        d["grad_out"] = golden_cases.big_case_grad_out(name)
+        d["ic_target"] = golden_cases.big_case_ic_target()
+    return d
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_util_mirrors_vs_reference():
+    from deepinpainting_amd.util import util
+    d = np.load(os.path.join(GOLDEN, "masks.npz"))
+    tags = sorted({k.rsplit("__", 1)[0] for k in d.files if k.endswith("__mask")})
+    for tag in tags:
+        thr = float(tag.split("__thr")[1])
+        mg = cu(d[tag + "__mask"].astype(bool))[None, None]
+        feat = util.cal_feat_mask(mg, 3, thr)
+        assert feat.dtype == torch.uint8 and feat.dim() == 4
+        np.testing.assert_array_equal(feat[0, 0].cpu().numpy(), d[tag + "__feat"])
+        h, w = feat.shape[2:]
+        flag, nonmask, fo, midx = util.cal_mask_given_mask_thred(torch.zeros(1, h, w, device="cuda"), feat[0, 0], 1, 1, 1)
+        assert flag.dtype == nonmask.dtype == fo.dtype == midx.dtype == torch.int64
+        np.testing.assert_array_equal(flag.cpu().numpy(), d[tag + "__flag"])
+        np.testing.assert_array_equal(nonmask.cpu().numpy(), d[tag + "__nonmask"])
+        np.testing.assert_array_equal(fo.cpu().numpy(), d[tag + "__flatten_offsets"])
+        np.testing.assert_array_equal(midx.cpu().numpy(), d[tag + "__mask_point_idx"])
+    sx, sy = util.cal_sps_for_Advanced_Indexing(5, 7)
+    np.testing.assert_array_equal(sx.numpy(), d["sps_5x7__sp_x"])
+    np.testing.assert_array_equal(sy.numpy(), d["sps_5x7__sp_y"])
+    with pytest.raises(AssertionError, match="mask must be 4 dimensions"):
+        util.cal_feat_mask(torch.zeros(8, 8, device="cuda"), 3, 0.3)
+    with pytest.raises(AssertionError, match="img has to be 3"):
+        util.cal_mask_given_mask_thred(torch.zeros(8, 8, device="cuda"), torch.zeros(8, 8, dtype=torch.uint8, device="cuda"), 1, 1, 1)
+
+
+@pytest.mark.parametrize("name", [c for c in LAYER_CASES if "signed" not in c])
+def test_ipsr_model_autograd_vs_reference(name):
+    """IPSR_model.set_mask/set_ref/forward + autograd backward == the reference's numbers (1e-4)."""
+    from deepinpainting_amd.models.IPSR_model import IPSR_model
+    d = load(name)
+    layer = IPSR_model(float(d["threshold"]), 1, 1, 1, 1, float(d["triple_w"]))
+    feat = layer.set_mask(cu(d["mask_img"].astype(bool))[None, None], 3, float(d["threshold"]))
+    np.testing.assert_array_equal(feat.cpu().numpy(), d["feat_mask"])
+    layer.set_ref(Vgg(None, None, None, cu(d["ref"])))
+    x = cu(d["x"]).requires_grad_(True)
+    y = layer(x)
+    assert y.shape == x.shape and y.requires_grad
+    y.backward(cu(d["grad_out"]))
+    np.testing.assert_array_equal(layer.mask_point_idx.cpu().numpy(), d["mask_point_idx"])
+    np.testing.assert_array_equal(layer.flag.cpu().numpy(), d["flag"])
+    np.testing.assert_array_equal(layer.flatten_offsets.cpu().numpy(), d["flatten_offsets"])
+    out, gin = y.detach().cpu().numpy(), x.grad.cpu().numpy()
+    if "out_channels" in d:
+        out, gin = out[:, d["out_channels"]], gin[:, d["grad_in_channels"]]
+    assert np.abs(out - d["out"]).max() <= ATOL
+    assert np.abs(gin - d["grad_in"]).max() <= ATOL
+    # a second forward reuses the cached index tensors (mask unchanged) and gives the same bits
+    y2 = layer(x.detach())
+    assert torch.equal(y2, y.detach())
+    assert "IPSR_model(threshold:" in repr(layer)
+
+
+def test_ipsr_function_12_arg_surface():
+    from deepinpainting_amd.models.IPSRFunction import IPSRFunction
+    from deepinpainting_amd.util import util
+    d = load("layer_c16_8x8_center")
+    feat = cu(d["feat_mask"])
+    x = cu(d["x"]).requires_grad_(True)
+    flag, nonmask, fo, midx = util.cal_mask_given_mask_thred(x[0].detach(), feat, 1, 1, 1)
+    sx, sy = util.cal_sps_for_Advanced_Indexing(8, 8)
+    # plain int64 index tensor without the cached int32 twin must work too (what a foreign caller passes)
+    midx_plain = midx.clone()
+    out = IPSRFunction.apply(x, feat, Vgg(None, None, None, cu(d["ref"])), 1, 1, 1.0, flag, nonmask, midx_plain, fo, sx, sy)
+    assert np.abs(out.detach().cpu().numpy() - d["out"]).max() <= ATOL
+    grads = torch.autograd.grad(out, x, cu(d["grad_out"]))
+    assert np.abs(grads[0].cpu().numpy() - d["grad_in"]).max() <= ATOL
+    with pytest.raises(AssertionError, match="Input Dim has to be 4"):
+        IPSRFunction.apply(x[0], feat, Vgg(None, None, None, cu(d["ref"])), 1, 1, 1.0, flag, nonmask, midx, fo, sx, sy)
+    with pytest.raises(AssertionError, match="Mask dimension must be 2"):
+        IPSRFunction.apply(x, feat[None], Vgg(None, None, None, cu(d["ref"])), 1, 1, 1.0, flag, nonmask, midx, fo, sx, sy)
+    with pytest.raises(NotImplementedError):     # shift_sz = 3: the reference fails too (IPSRFunction.py:134)
+        IPSRFunction.apply(x, feat, Vgg(None, None, None, cu(d["ref"])), 3, 1, 1.0, flag, nonmask, midx, fo, sx, sy)
+
+
+@pytest.mark.parametrize("name", ["layer_c16_8x8_center", "layer_c32_16x16_stroke", "layer_c512_8x8_cfg1"])
+def test_innercos_module_vs_reference(name):
+    from deepinpainting_amd.models.InnerCos import InnerCos
+    import types
+    d = load(name)
+    ic = InnerCos(strength=float(d["strength"]), skip=0)
+    ic.set_mask(cu(d["mask_img"].astype(bool))[None, None], types.SimpleNamespace(threshold=float(d["threshold"])))
+    ic.set_target(cu(d["ic_target"]))
+    x = cu(d["x"]).requires_grad_(True)
+    y = ic(x)
+    assert y is x and ic.output is x and ic.get_target() is ic.target
+    np.testing.assert_allclose(ic.loss.item(), d["ic_loss"], rtol=1e-5)
+    ic.backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), d["ic_grad"], rtol=1e-5, atol=1e-9)
+    skip = InnerCos(skip=1)
+    assert skip(x) is x and skip.loss == 0
+    with pytest.raises(NotImplementedError):
+        InnerCos(crit='L1')
+
+
+def test_innercos2_module_vs_reference():
+    from deepinpainting_amd.models.InnerCos2 import InnerCos2
+    import types
+    d = np.load(os.path.join(GOLDEN, "innercos2_c1024_8x8.npz"))
+    ic = InnerCos2(strength=float(d["strength"]))
+    ic.set_mask(cu(d["mask_img"].astype(bool))[None, None], types.SimpleNamespace(threshold=float(d["threshold"])))
+    ic.set_target(cu(d["ic_target"]))
+    x = cu(d["x"]).requires_grad_(True)
+    assert ic(x) is x
+    np.testing.assert_allclose(ic.loss.item(), d["ic_loss"], rtol=1e-5)
+    ic.backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), d["ic_grad"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.fixture(scope="module")
+def gpu_trainer(tmp_path_factory):
+    from deepinpainting_amd.options import Option
+    from deepinpainting_amd.models.models import create_model
+    opt = Option(gpu_ids=[0], batchSize=1, use_dropout=False, quiet=True, checkpoints_dir=str(tmp_path_factory.mktemp("ckpt")))
+    m = quiet(create_model, opt)
+    for i, net in enumerate((m.netG, m.netP, m.netD, m.netF, m.vgg)):
+        golden_cases.reinit_deterministic(net, 500 + i)
+    return m
+
+
+def test_trainer_step_on_gpu_vs_reference(gpu_trainer):
+    """create_model + set_input/set_ref_latent/set_gt_latent/optimize_parameters on the MI355X against
+    the reference's own CPU run of the same step (tests/golden/trainer_step.npz)."""
+    d = np.load(os.path.join(GOLDEN, "trainer_step.npz"))
+    m = gpu_trainer
+    assert m.name() == 'IPSRModel'
+    img, mask, ref = golden_cases.trainer_inputs()
+    m.set_input(img.cuda(), mask.cuda(), ref)            # ref may arrive on the host (train.ipynb never moves it)
+    m.set_ref_latent()
+    m.set_gt_latent()
+    m.optimize_parameters()
+    e = m.get_current_errors()
+    got = [e['G_GAN'], e['G_L1'], e['D'], e['F']]
+    np.testing.assert_allclose(got, d["errors"], rtol=2e-3)
+    np.testing.assert_allclose([float(m.ng_loss_value), float(m.ng_loss_value2)], d["ng_loss"], rtol=2e-3)
+    np.testing.assert_allclose(m.get_loss()['GAN'], d["get_loss"], rtol=2e-3)
+    assert np.abs(m.fake_P.detach().cpu().numpy()[..., ::5, ::5] - d["fake_P"]).max() < 2e-3
+    assert np.abs(m.fake_B.detach().cpu().numpy()[..., ::5, ::5] - d["fake_B"]).max() < 2e-3
+    np.testing.assert_array_equal(m.real_A.cpu().numpy()[..., ::5, ::5], d["real_A"])
+    assert len(m.get_current_visuals()) == 5
+    named = dict(m.netP.named_parameters())
+    k = str(d["post_keys_P"][0])
+    g, r = named[k].grad.cpu().numpy().reshape(-1)[:256], d["grad_P_0"]
+    assert np.abs(g - r).max() <= 2e-3 * np.abs(r).max()
+    # validation path
+    m.set_input(img.cuda(), mask.cuda(), ref.cuda())
+    m.set_ref_latent()
+    m.set_gt_latent()
+    with torch.no_grad():
+        m.test()
+    assert np.isfinite(m.get_error().item()) and np.isfinite(m.get_loss()['GAN'])
+    m.update_learning_rate()
+
+
+def test_trainer_batch8_dropout_runs(tmp_path):
+    """BASELINE config 2 shape: batch 8, dropout on (train.ipynb default): losses finite, weights move."""
+    from deepinpainting_amd.options import Option
+    from deepinpainting_amd.models.models import create_model
+    opt = Option(gpu_ids=[0], batchSize=8, use_dropout=True, quiet=True, checkpoints_dir=str(tmp_path))
+    torch.manual_seed(3)
+    m = quiet(create_model, opt)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.rand(8, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    ref = torch.rand(8, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    mask = torch.zeros(1, 1, 256, 256, dtype=torch.bool, device="cuda")
+    mask[:, :, 64:192, 64:192] = 1
+    w0 = m.netG.model.model[0].weight.detach().clone()
+    for _ in range(2):
+        m.set_input(img, mask, ref)
+        m.set_ref_latent()
+        m.set_gt_latent()
+        m.optimize_parameters()
+    e = m.get_current_errors()
+    assert all(np.isfinite(v) for v in e.values())
+    assert not torch.equal(w0, m.netG.model.model[0].weight.detach())
+    assert m.CSA_model[0].mask_point_idx.numel() == 256
