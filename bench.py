@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — training throughput of the IPSR inpainting step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = the reference's training iteration (train.ipynb cell 2:24-27) on device-resident synthetic
+tensors of BASELINE.json config 2:  set_input + set_ref_latent + set_gt_latent + optimize_parameters,
+256x256, 128x128 centre hole (M = 256 masked feature positions), batch 8 per GPU, fp32, dropout on
+(train.ipynb default), random-init nets and a seeded random VGG16 (no network access).  Nothing is
+skipped inside the timed region: 4 nets forward/backward, 3 VGG passes (the reference's 4th is a
+recomputation of identical features and is reused), 4 Adam steps, the IPSR layer forward/backward.
+
+Rank 0 prints ONE JSON line.  `value` = images/s of the whole job (all ranks).  Extra objects:
+  roofline      the layer's dominant kernel (fp32-MFMA correlation + arg-max): algorithmic FLOPs per launch
+                (2*N*N*C per sample) over its mean duration, measured live with HIP events on
+                the launch stream inside the timed steps (C-ABI hook ipsr_profile_*).
+  cpu_baseline  the CPU twin (oracle C restatement of the layer + PyTorch-CPU convs, oracle/cpu_model.py)
+                timed on this host's cores on a bounded sample (rank 0, N=1 only).
+  ipsr_layer_ms IPSR layer forward+backward at the same shape (second half of BASELINE.json's metric).
+"""
+import argparse
+import contextlib
+import ctypes
+import io
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "train images/sec at 256x256, batch 8/GPU, 1/2/4/8 MI355X; IPSR layer ms"
+FINE, BATCH, C_FEAT, H_FEAT = 256, 8, 512, 32
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32-input MFMA = 64 FLOP/clk/SIMD
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_corr_argmax.json")
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def synthetic_batch(device, batch, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    img = torch.rand(batch, 3, FINE, FINE, device=device, generator=g) * 2 - 1
+    ref = torch.rand(batch, 3, FINE, FINE, device=device, generator=g) * 2 - 1
+    mask = torch.zeros(1, 1, FINE, FINE, dtype=torch.bool, device=device)
+    mask[:, :, FINE // 4:3 * FINE // 4, FINE // 4:3 * FINE // 4] = 1
+    return img, mask, ref
+
+
+def train_step(model, img, mask, ref):
+    model.set_input(img, mask, ref)
+    model.set_ref_latent()
+    model.set_gt_latent()
+    model.optimize_parameters()
+
+
+def layer_timing(device, iters=50):
+    """IPSR layer forward+backward (ms, median) at [8,512,32,32], M=256 — `x = |N(0,1)|`, `ref = relu(N(0,1))`."""
+    from deepinpainting_amd import ops
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.randn(BATCH, C_FEAT, H_FEAT, H_FEAT, device=device, generator=g).abs()
+    ref = torch.relu(torch.randn(BATCH, C_FEAT, H_FEAT, H_FEAT, device=device, generator=g))
+    grad = torch.randn(BATCH, C_FEAT, H_FEAT, H_FEAT, device=device, generator=g)
+    m = torch.zeros(FINE, FINE, dtype=torch.uint8, device=device)
+    m[FINE // 4:3 * FINE // 4, FINE // 4:3 * FINE // 4] = 1
+    feat = ops.feat_mask(m, 3, 5 / 16.0)
+    _, mpi, cnt = ops.index_prep(feat, 1, 1, 1)
+    mpi = mpi[:int(cnt.item())].contiguous()
+    for _ in range(5):
+        f = ops.forward(x, ref, mpi)
+        ops.backward(grad, mpi, f.attn_rows, f.bwd_index, 1.0)
+    torch.cuda.synchronize()
+    fwd, bwd = [], []
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for _ in range(iters):
+        ev[0].record()
+        f = ops.forward(x, ref, mpi)
+        ev[1].record()
+        ops.backward(grad, mpi, f.attn_rows, f.bwd_index, 1.0)
+        ev[2].record()
+        torch.cuda.synchronize()
+        fwd.append(ev[0].elapsed_time(ev[1]))
+        bwd.append(ev[1].elapsed_time(ev[2]))
+    return statistics.median(fwd), statistics.median(bwd)
+
+
+def cpu_baseline(sample_batch=2, steps=1):
+    """The CPU twin on this host's cores: same trainer class, PyTorch-CPU convs, oracle-backed IPSR layer."""
+    from deepinpainting_amd.options import Option
+    from oracle import cpu_model, ipsr_oracle as orc
+    orc.build()
+    cores = torch.get_num_threads()
+    opt = Option(gpu_ids=[], batchSize=sample_batch, use_dropout=True, quiet=True,
+                 checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_cpu"))
+    torch.manual_seed(1234)
+    model = quiet(cpu_model.create_cpu_model, opt)
+    img, mask, ref = synthetic_batch(torch.device("cpu"), sample_batch, 1234)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train_step(model, img, mask, ref)
+    dt = time.perf_counter() - t0
+    # layer alone (oracle C restatement), one sample of the same shape, forward + backward
+    import numpy as np
+    rs = np.random.RandomState(7)
+    x = np.abs(rs.standard_normal((1, C_FEAT, H_FEAT, H_FEAT))).astype(np.float32)
+    rf = np.maximum(rs.standard_normal((1, C_FEAT, H_FEAT, H_FEAT)), 0).astype(np.float32)
+    mpi = model.CSA_model[0].mask_point_idx
+    t1 = time.perf_counter()
+    f = orc.forward(x, rf, mpi)
+    orc.backward(x, mpi, f.attn_rows, f.bwd_index, 1.0)
+    layer_ms = (time.perf_counter() - t1) * 1e3
+    return {
+        "value": round(sample_batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+        "sample": "%d full training step(s) at batch %d (same 256x256 workload, oracle-backed IPSR layer + "
+                  "PyTorch-CPU convs, torch %s, %d threads): %.1f s" % (steps, sample_batch, torch.__version__, cores, dt),
+        "ipsr_layer_ms_per_sample": round(layer_ms, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE config 2 = 8)")
+    args = ap.parse_args()
+
+    from deepinpainting_amd import _lib, dist as idist
+    from deepinpainting_amd.models.models import create_model
+    from deepinpainting_amd.options import Option
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the IPSR layer has no CPU path (the CPU twin is only the reported baseline)")
+    rank, world, local_rank = idist.init_distributed(backend="nccl")
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    torch.backends.cudnn.benchmark = True        # let MIOpen pick its fastest fp32 solvers during warm-up
+
+    opt = Option(gpu_ids=[local_rank], batchSize=args.batch, use_dropout=True, quiet=True,
+                 checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
+    torch.manual_seed(1234)                       # identical init on every rank (rank 0 is broadcast anyway)
+    model = quiet(create_model, opt)
+    img, mask, ref = synthetic_batch(device, args.batch, 1234 + rank)
+
+    lib = _lib.lib()
+    for _ in range(args.warmup):
+        train_step(model, img, mask, ref)
+    lib.ipsr_profile_enable(max(args.steps, 1))
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_step(model, img, mask, ref)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    buf = (ctypes.c_float * max(args.steps, 1))()
+    n_ev = lib.ipsr_profile_read(ctypes.cast(buf, ctypes.c_void_p), args.steps)
+    lib.ipsr_profile_enable(0)
+    kern_ms = [buf[i] for i in range(n_ev)]
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    errs = model.get_current_errors()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+    n_feat = H_FEAT * H_FEAT
+    flops = 2.0 * n_feat * n_feat * C_FEAT * args.batch
+    kms = statistics.mean(kern_ms) if kern_ms else float("nan")
+    achieved = flops / (kms * 1e-3) / 1e12 if kern_ms else None
+    traffic = None
+    if os.path.exists(TRAFFIC_FILE):
+        with open(TRAFFIC_FILE) as fh:
+            traffic = json.load(fh).get("hbm_bytes_per_launch")
+    fwd_ms, bwd_ms = layer_timing(device)
+    out = {
+        "metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: 256x256 synthetic images, 128x128 centre mask (M=256 of N=1024 "
+                               "feature positions), batch %d/GPU, fp32, full IPSR training step" % args.batch,
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "dropout": True,
+                   "vgg16": "seeded random init (no pretrained weights offline)"},
+        "ipsr_layer_ms": {"forward": round(fwd_ms, 4), "backward": round(bwd_ms, 4), "total": round(fwd_ms + bwd_ms, 4),
+                          "shape": "[%d,%d,%d,%d], M=256" % (BATCH, C_FEAT, H_FEAT, H_FEAT)},
+        "roofline": {"kernel": "ipsr::corr_argmax_kernel (fp32 MFMA correlation + arg-max)", "bound": "mfma",
+                     "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,
+                     "traffic": traffic, "flops_per_launch": flops, "kernel_ms": round(kms, 5), "launches_timed": len(kern_ms)},
+        "losses_last_step": {k: round(v, 4) for k, v in errs.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,8 @@ SIGNATURES = {
                               c_void_p, c_size_t, c_void_p]),
     "innercos_loss_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p]),
+    "ipsr_profile_enable": (c_int, [c_int]),
+    "ipsr_profile_read": (c_int, [c_void_p, c_int]),
 }
 
 

@@ -34,6 +34,26 @@ int check_launch(const char* what)
     return IPSR_OK;
 }
 
+// ---- opt-in profiling ring --------------------------------------------------------------------------
+static hipEvent_t* g_ev = nullptr;      // 2*capacity events: start0, stop0, start1, ...
+static int g_ev_cap = 0, g_ev_n = 0;
+static bool g_ev_open = false;
+
+void profile_mark_start(hipStream_t st)
+{
+    if (g_ev_cap == 0 || g_ev_n >= g_ev_cap) return;
+    (void)hipEventRecord(g_ev[2 * g_ev_n], st);
+    g_ev_open = true;
+}
+
+void profile_mark_stop(hipStream_t st)
+{
+    if (!g_ev_open) return;
+    (void)hipEventRecord(g_ev[2 * g_ev_n + 1], st);
+    g_ev_open = false;
+    ++g_ev_n;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 struct FwdPlan {
@@ -67,6 +87,35 @@ extern "C" {
 int ipsr_abi_version(void) { return 1; }
 
 const char* ipsr_last_error(void) { return g_err; }
+
+int ipsr_profile_enable(int capacity)
+{
+    for (int i = 0; i < 2 * g_ev_cap; ++i) (void)hipEventDestroy(g_ev[i]);
+    delete[] g_ev;
+    g_ev = nullptr;
+    g_ev_cap = g_ev_n = 0;
+    g_ev_open = false;
+    if (capacity <= 0) return IPSR_OK;
+    g_ev = new hipEvent_t[2 * (size_t)capacity];
+    for (int i = 0; i < 2 * capacity; ++i)
+        if (hipEventCreate(&g_ev[i]) != hipSuccess) return fail(IPSR_ERR_LAUNCH, "ipsr_profile_enable: hipEventCreate failed");
+    g_ev_cap = capacity;
+    return IPSR_OK;
+}
+
+int ipsr_profile_read(float* ms, int max_n)
+{
+    if (!ms || max_n < 0) return fail(IPSR_ERR_INVALID, "ipsr_profile_read: bad arguments");
+    int n = 0;
+    for (int i = 0; i < g_ev_n && n < max_n; ++i) {
+        float t = 0.0f;
+        if (hipEventSynchronize(g_ev[2 * i + 1]) != hipSuccess) break;
+        if (hipEventElapsedTime(&t, g_ev[2 * i], g_ev[2 * i + 1]) != hipSuccess) break;
+        ms[n++] = t;
+    }
+    g_ev_n = 0;
+    return n;
+}
 
 size_t ipsr_feat_mask_workspace_bytes(int H, int W, int layers)
 {

@@ -234,8 +234,9 @@ int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, i
     Carver cv(ws, ws_bytes);
     float* pval = cv.take<float>((size_t)B * ks * N);
     int32_t* pidx = cv.take<int32_t>((size_t)B * ks * N);
-    const bool fast = (N % BM == 0) && (C % BK == 0);
+    const bool fast = (N % BM == 0) && (C % BK == 0) && ((reinterpret_cast<uintptr_t>(xn) | reinterpret_cast<uintptr_t>(ref)) & 15u) == 0;
     const int grid = B * qt * ks;
+    profile_mark_start(st);
     if (fast) {
         if (S_out) corr_argmax_kernel<true, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
         else corr_argmax_kernel<true, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
@@ -243,6 +244,7 @@ int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, i
         if (S_out) corr_argmax_kernel<false, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
         else corr_argmax_kernel<false, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
     }
+    profile_mark_stop(st);
     if (int rc = check_launch("corr_argmax_kernel")) return rc;
     argmax_merge_kernel<<<cdiv(B * N, 256), 256, 0, st>>>(pval, pidx, B, N, ks, ind, vmax);
     return check_launch("argmax_merge_kernel");

@@ -14,6 +14,10 @@ int fail(int code, const char* fmt, ...);
 // Checks the launch that was just issued on `what`.
 int check_launch(const char* what);
 
+// opt-in event bracketing of the dominant kernel (see ipsr_profile_enable in ipsr_hip.h)
+void profile_mark_start(hipStream_t st);
+void profile_mark_stop(hipStream_t st);
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -112,6 +112,16 @@ int innercos_loss_backward(const float* x, int B, int Cx, int Cuse, int N, const
                            const float* target, float strength, const float* grad_loss /*[1]*/,
                            float* grad_x /*[B,Cx,N]*/, void* stream);
 
+/* ---- measurement hook (bench.py) -----------------------------------------------------------------
+ * Opt-in: when enabled, every launch of the correlation+arg-max kernel (the layer's dominant kernel,
+ * inside ipsr_forward / ipsr_corr_argmax) is bracketed by a pair of HIP events recorded on the SAME
+ * stream the kernel is launched on.  ipsr_profile_read synchronises the recorded pairs, writes their
+ * elapsed times (ms) to the HOST array `ms` and resets the ring; it returns the number written.
+ * ipsr_profile_enable(0) disables and frees.  This is the only global state in the library and it is
+ * off by default; enable/read are not re-entrant (call them from one thread, outside a timed step). */
+int ipsr_profile_enable(int capacity);
+int ipsr_profile_read(float* ms /*[host]*/, int max_n);
+
 #ifdef __cplusplus
 }
 #endif
