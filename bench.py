@@ -126,6 +126,9 @@ def cpu_baseline(sample_batch=2, steps=1):
     }
 
 
+T_START = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,7 +150,9 @@ def main():
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    torch.backends.cudnn.benchmark = True        # let MIOpen pick its fastest fp32 solvers during warm-up
+    # MIOpen exhaustive find (cudnn.benchmark) costs minutes on a fresh box for the ~60 conv shapes of the
+    # step; off by default so the run finishes quickly, opt in with IPSR_BENCH_MIOPEN_FIND=1
+    torch.backends.cudnn.benchmark = os.environ.get("IPSR_BENCH_MIOPEN_FIND", "0") == "1"
 
     opt = Option(gpu_ids=[local_rank], batchSize=args.batch, use_dropout=True, quiet=True,
                  checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
@@ -156,8 +161,12 @@ def main():
     img, mask, ref = synthetic_batch(device, args.batch, 1234 + rank)
 
     lib = _lib.lib()
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         train_step(model, img, mask, ref)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print("[bench] warm-up step %d/%d done (%.1f s since start)" % (i + 1, args.warmup, time.perf_counter() - T_START),
+                  file=sys.stderr, flush=True)
     lib.ipsr_profile_enable(max(args.steps, 1))
     torch.cuda.synchronize()
     if world > 1:
@@ -214,6 +223,7 @@ def main():
         "losses_last_step": {k: round(v, 4) for k, v in errs.items()},
     }
     if world == 1 and not args.no_cpu_baseline:
+        print("[bench] GPU part done: %.2f images/s; timing the CPU twin ..." % value, file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
     if world > 1:
