@@ -73,7 +73,7 @@ static FwdPlan plan_forward(int B, int C, int h, int w, int M)
     p.corr = align_up(corr_argmax_ws_bytes(B, C, p.N), 256);
     p.wn = align_up((size_t)B * Mx * 4, 256);
     p.wo = p.wn;
-    p.flags = align_up((size_t)2 * B * Mx * 4, 256);   // rowflag [B,M] followed by kq [B,M]
+    p.flags = align_up((size_t)B * Mx * 4, 256) + align_up((size_t)B * p.N * 4, 256);   // kq [B,M], col_cnt [B,N]
     p.total = p.xn + p.xT + p.inv + p.corr + p.wn + p.wo + p.flags + 256;
     return p;
 }
@@ -164,7 +164,12 @@ int ipsr_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int
     return launch_corr_argmax(xn, ref, B, C, N, ind, vmax, S_out, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
-size_t ipsr_bwd_index_ints(int N, int M) { return (size_t)2 * N + 2 + (size_t)(M > 0 ? M : 0); }
+size_t ipsr_bwd_index_ints(int N, int M)
+{
+    if (N < 1 || M < 0 || M > N) return 0;
+    const size_t cap = (size_t)(N - M) + (size_t)M * (M + 1) / 2;
+    return (size_t)N + 1 + 2 * cap;
+}
 
 size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride)
 {
@@ -195,7 +200,8 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     void* corr_ws = base; base += p.corr;
     float* wn = reinterpret_cast<float*>(base); base += p.wn;
     float* wo = reinterpret_cast<float*>(base); base += p.wo;
-    int32_t* flags = reinterpret_cast<int32_t*>(base);
+    int32_t* kq = reinterpret_cast<int32_t*>(base); base += align_up((size_t)B * (M > 0 ? M : 1) * 4, 256);
+    int32_t* col_cnt = reinterpret_cast<int32_t*>(base);
 
     if (int rc = launch_patch_normalize(x, B, C, p.N, xn, xT, p.Cp, inv, st)) return rc;
     if (int rc = launch_corr_argmax(xn, ref, B, C, p.N, ind, vmax, nullptr, corr_ws, p.corr, st)) return rc;
@@ -203,7 +209,7 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     AttnArgs a;
     a.x = x; a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
     a.B = B; a.C = C; a.Cp = p.Cp; a.N = p.N; a.M = M;
-    a.wn = wn; a.wo = wo; a.rowflag = flags; a.attn = attn_rows; a.out = out; a.bwd_index = bwd_index;
+    a.wn = wn; a.wo = wo; a.kq = kq; a.col_cnt = col_cnt; a.attn = attn_rows; a.out = out; a.bwd_index = bwd_index;
     return launch_attention(a, st);
 }
 
@@ -212,7 +218,6 @@ int ipsr_backward(const float* grad_out, const int32_t* mask_point_idx, int M, c
 {
     if (!grad_out || !grad_in || !bwd_index) return fail(IPSR_ERR_INVALID, "ipsr_backward: null pointer");
     if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return fail(IPSR_ERR_INVALID, "ipsr_backward: bad size");
-    if (M > 0 && (!mask_point_idx || !attn_rows)) return fail(IPSR_ERR_INVALID, "ipsr_backward: M > 0 needs mask_point_idx and attn_rows");
     return launch_backward(grad_out, mask_point_idx, M, attn_rows, bwd_index, triple_w, B, C, h * w, grad_in, static_cast<hipStream_t>(stream));
 }
 

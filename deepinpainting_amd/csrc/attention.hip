@@ -11,16 +11,17 @@
 //     registers (8 channels per lane per 512), reads patch rows from the patch-major copy xT through a
 //     4-deep register prefetch ring, reduces the dot with DPP + readlane (no LDS, no barrier) and emits
 //     only the scalars (wn_l, wo_l).  Latency-bound by construction: M dependent steps.
-//   * attn_rows_kernel   — a_l[k] is a scalar recurrence per k, independent across k: one thread per k
-//     replays (wn_l, wo_l) and writes the reference's `in_attention` rows [M,N], coalesced.
+//   * column_fill_kernel — a_l[k] is a scalar recurrence per k, independent across k: one thread per k
+//     replays (wn_l, wo_l) from LDS and writes the reference's `in_attention` rows [M,N], coalesced.
 //   * recon_gather_kernel — non-masked q: kbar column is one-hot, so out[:,q] = P[ind[q]] is a row
 //     gather (LDS-transposed so that both the read of xT rows and the write of out rows are coalesced).
 //   * recon_masked_kernel — masked q: out[:,q_l] = sum_k a_l[k] * P[k,:], the dense part of the
 //     reference's second GEMM, on fp32 MFMA with k walked in ascending order (one fmaf chain per
 //     output, same bits as the oracle).
-//   * bwd_index_kernel   — kbar is kept by the reference in a LongTensor (:36,134), i.e. truncated:
-//     non-masked columns are exact one-hots -> a CSR "who points at k" index in ascending q;
-//     masked rows survive truncation only where |a_l[k]| >= 1 -> list of such rows.
+//   * column_count / index_scan / column_fill — kbar is kept by the reference in a LongTensor (:36,134), i.e.
+//     truncated toward zero.  What survives is stored as a CSR over the patch index k: the non-masked q
+//     with ind[q] == k (weight 1, ascending q) followed by the masked rows whose |a_l[k]| >= 1 (weight
+//     trunc(a_l[k]), ascending l).  That is all the backward needs.
 #include "ipsr_common.h"
 
 namespace ipsr {
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(64) recurrence_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ ind, const float* __restrict__ vmax,
                                                         const int32_t* __restrict__ mpi, int Cp, int N, int M,
                                                         float* __restrict__ wn_out, float* __restrict__ wo_out,
-                                                        int32_t* __restrict__ kq_out, int32_t* __restrict__ rowflag)
+                                                        int32_t* __restrict__ kq_out)
 {
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
     int* q_s = lds_raw;                 // [M]
@@ -78,7 +79,6 @@ __global__ void __launch_bounds__(64) recurrence_kernel(const float* __restrict_
         iv_s[l] = inv[(size_t)b * N + q];
         vm_s[l] = vmax[(size_t)b * N + q];
         kq_out[(size_t)b * M + l] = kq;
-        rowflag[(size_t)b * M + l] = 0;
     }
     __syncthreads();
 
@@ -139,29 +139,6 @@ __global__ void __launch_bounds__(64) recurrence_kernel(const float* __restrict_
                 if (ln < M) { load_row(pu[d], q_s[ln]); load_row(pk[d], kq_s[ln]); }
             }
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// a_l[k] for all l: one thread per k (IPSRFunction.py:100,123-125).  Also flags rows whose truncation
-// toward zero is not all-zero (what survives `ind_lst[idx] = kbar.squeeze()` into a LongTensor, :134).
-__global__ void __launch_bounds__(256) attn_rows_kernel(const float* __restrict__ wn, const float* __restrict__ wo,
-                                                        const int32_t* __restrict__ kq, int N, int M,
-                                                        float* __restrict__ attn, int32_t* __restrict__ rowflag)
-{
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
-    const float* wnb = wn + (size_t)b * M;
-    const float* wob = wo + (size_t)b * M;
-    const int32_t* kqb = kq + (size_t)b * M;
-    float* ab = attn + (size_t)b * M * N;
-    float a = 0.0f;
-    for (int l = 0; l < M; ++l) {
-        a = a * wnb[l];
-        if (kqb[l] == k) a = a + wob[l];
-        ab[(size_t)l * N + k] = a;
-        if (truncf(a) != 0.0f) atomicOr(&rowflag[(size_t)b * M + l], 1);
     }
 }
 
@@ -279,41 +256,78 @@ __global__ void __launch_bounds__(256) recon_masked_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Sparse form of trunc(kbar) per sample:
-//   col_off[N+1], col_q[N] : CSR over k of the NON-masked q with ind[q] == k, q ascending (unused tail = -1)
-//   nz_count, nz_rows[M]   : masked rows l (ascending) whose truncated attention row is not all zero
-__global__ void __launch_bounds__(1024) bwd_index_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
-                                                         const int32_t* __restrict__ rowflag, int N, int M,
-                                                         int32_t* __restrict__ bwd_index, size_t ints_per_sample)
+// Attention rows + the sparse form of trunc(kbar).
+//
+// a_l[k] (the reference's `in_attention`, IPSRFunction.py:100,123-125) is a scalar recurrence per column k,
+// independent across k:  a = a*wn_l;  if (kq_l == k) a += wo_l.  One thread owns one column and replays the
+// M steps from an LDS copy of (wn, wo, kq) — M LDS broadcasts, no global latency in the loop.
+//
+// trunc(kbar) per sample (int32 words; layout shared with the oracle):
+//   col_off[N+1] | ent_q[cap] | ent_w[cap] (fp32 bits),   cap = (N-M) + M(M+1)/2
+// Column k = the non-masked q with ind[q] == k (weight 1, ascending q: found by scanning an LDS copy of the
+// keys ind[q], -1 for masked q) followed by the masked rows with |a_l[k]| >= 1 (weight trunc(a_l[k]),
+// ascending l: found while replaying the recurrence).  Three launches:
+//   column_count_kernel  per column: #one-hot + #survivors
+//   index_scan_kernel    exclusive scan over k -> col_off
+//   column_fill_kernel   writes the attention rows [M,N] (coalesced over k) and the CSR entries in order
+constexpr int IX_COLS = 128;
+
+struct ColumnLds {
+    int* key;        // [Npad]
+    float4* step;    // [M]  {wn, wo, kq bits, 0}
+};
+
+__device__ __forceinline__ ColumnLds load_column_lds(int* lds, const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
+                                                     const float* __restrict__ wn, const float* __restrict__ wo,
+                                                     const int32_t* __restrict__ kq, int N, int Npad, int M)
 {
-    extern __shared__ __attribute__((aligned(16))) int key[];   // [Npad] ind[q], or -1 for masked q / padding
+    ColumnLds L;
+    L.step = reinterpret_cast<float4*>(lds);
+    L.key = lds + 4 * M;
+    for (int q = threadIdx.x; q < Npad; q += IX_COLS) L.key[q] = q < N ? ind[q] : -1;
+    for (int l = threadIdx.x; l < M; l += IX_COLS) L.step[l] = make_float4(wn[l], wo[l], __int_as_float(kq[l]), 0.0f);
+    __syncthreads();
+    for (int l = threadIdx.x; l < M; l += IX_COLS) L.key[mpi[l]] = -1;
+    __syncthreads();
+    return L;
+}
+
+__global__ void __launch_bounds__(IX_COLS) column_count_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
+                                                               const float* __restrict__ wn, const float* __restrict__ wo,
+                                                               const int32_t* __restrict__ kq, int N, int M,
+                                                               int32_t* __restrict__ col_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds[];
+    const int b = blockIdx.y, Npad = (N + 3) & ~3;
+    const ColumnLds L = load_column_lds(lds, ind + (size_t)b * N, mpi, wn + (size_t)b * M, wo + (size_t)b * M, kq + (size_t)b * M, N, Npad, M);
+    const int k = blockIdx.x * IX_COLS + threadIdx.x;
+    if (k >= N) return;
+    int cnt = 0;
+    for (int q = 0; q < Npad; q += 4) {
+        const int4 v = *reinterpret_cast<const int4*>(&L.key[q]);
+        cnt += (v.x == k) + (v.y == k) + (v.z == k) + (v.w == k);
+    }
+    float a = 0.0f;
+    for (int l = 0; l < M; ++l) {
+        const float4 s = L.step[l];
+        a = a * s.x;
+        if (__float_as_int(s.z) == k) a = a + s.y;
+        cnt += (truncf(a) != 0.0f) ? 1 : 0;
+    }
+    col_cnt[(size_t)b * N + k] = cnt;
+}
+
+// exclusive scan of col_cnt over k -> col_off[0..N]; one workgroup per sample
+__global__ void __launch_bounds__(1024) index_scan_kernel(const int32_t* __restrict__ col_cnt, int N,
+                                                          int32_t* __restrict__ bwd_index, size_t ints_per_sample)
+{
     __shared__ int wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = blockIdx.x;
-    const int Npad = (N + 3) & ~3;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
     int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
-    int32_t* col_q = col_off + N + 1;
-    int32_t* nz_count = col_q + N;
-    int32_t* nz_rows = nz_count + 1;
-
-    for (int q = tid; q < Npad; q += 1024) key[q] = q < N ? ind[(size_t)b * N + q] : -1;
-    __syncthreads();
-    for (int l = tid; l < M; l += 1024) key[mpi[l]] = -1;
-    __syncthreads();
-
-    // contiguous ownership: thread t owns k in [t*KPT, (t+1)*KPT)
     const int KPT = (N + 1023) / 1024;
     const int k_lo = tid * KPT, k_hi = min(N, k_lo + KPT);
     int total = 0;
-    for (int k = k_lo; k < k_hi; ++k) {
-        int cnt = 0;
-        for (int q = 0; q < Npad; q += 4) {
-            const int4 v = *reinterpret_cast<const int4*>(&key[q]);
-            cnt += (v.x == k) + (v.y == k) + (v.z == k) + (v.w == k);
-        }
-        total += cnt;
-    }
-    // exclusive scan of `total` over the 1024 threads
+    for (int k = k_lo; k < k_hi; ++k) total += col_cnt[(size_t)b * N + k];
     int incl = total;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
@@ -322,35 +336,54 @@ __global__ void __launch_bounds__(1024) bwd_index_kernel(const int32_t* __restri
     }
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
-    int base = 0;
-    for (int j = 0; j < wv; ++j) base += wave_tot[j];
-    int off = base + incl - total;
-
+    int off = incl - total;
+    for (int j = 0; j < wv; ++j) off += wave_tot[j];
     for (int k = k_lo; k < k_hi; ++k) {
         col_off[k] = off;
+        off += col_cnt[(size_t)b * N + k];
+    }
+    if (tid == 1023) col_off[N] = off;
+}
+
+template <bool WITH_INDEX>
+__global__ void __launch_bounds__(IX_COLS) column_fill_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
+                                                              const float* __restrict__ wn, const float* __restrict__ wo,
+                                                              const int32_t* __restrict__ kq, int N, int M,
+                                                              float* __restrict__ attn, int32_t* __restrict__ bwd_index,
+                                                              size_t ints_per_sample, size_t cap)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds[];
+    const int b = blockIdx.y, Npad = (N + 3) & ~3;
+    const ColumnLds L = load_column_lds(lds, ind + (size_t)b * N, mpi, wn + (size_t)b * M, wo + (size_t)b * M, kq + (size_t)b * M, N, Npad, M);
+    const int k = blockIdx.x * IX_COLS + threadIdx.x;
+    if (k >= N) return;
+    int32_t* ent_q = nullptr;
+    float* ent_w = nullptr;
+    int e = 0;
+    if (WITH_INDEX) {
+        int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
+        ent_q = col_off + N + 1;
+        ent_w = reinterpret_cast<float*>(ent_q + cap);
+        e = col_off[k];
         for (int q = 0; q < Npad; q += 4) {
-            const int4 v = *reinterpret_cast<const int4*>(&key[q]);
-            if (v.x == k) col_q[off++] = q;
-            if (v.y == k) col_q[off++] = q + 1;
-            if (v.z == k) col_q[off++] = q + 2;
-            if (v.w == k) col_q[off++] = q + 3;
+            const int4 v = *reinterpret_cast<const int4*>(&L.key[q]);
+            if (v.x == k) { ent_q[e] = q;     ent_w[e] = 1.0f; ++e; }
+            if (v.y == k) { ent_q[e] = q + 1; ent_w[e] = 1.0f; ++e; }
+            if (v.z == k) { ent_q[e] = q + 2; ent_w[e] = 1.0f; ++e; }
+            if (v.w == k) { ent_q[e] = q + 3; ent_w[e] = 1.0f; ++e; }
         }
     }
-    if (tid == 1023) col_off[N] = off;     // the last thread's running offset is the grand total (N - M)
-    for (int i = N - M + tid; i < N; i += 1024) col_q[i] = -1;
-
-    // ordered compaction of the flagged masked rows (wave 0)
-    if (wv == 0) {
-        int nbase = 0;
-        for (int l0 = 0; l0 < M; l0 += 64) {
-            const int l = l0 + lane;
-            const int f = (l < M) ? (rowflag[(size_t)b * M + l] != 0) : 0;
-            const unsigned long long bal = __ballot(f);
-            if (f) nz_rows[nbase + __popcll(bal & ((1ull << lane) - 1ull))] = l;
-            nbase += __popcll(bal);
+    float* ab = attn + (size_t)b * M * N;
+    float a = 0.0f;
+    for (int l = 0; l < M; ++l) {
+        const float4 s = L.step[l];
+        a = a * s.x;                                            // (:123)
+        if (__float_as_int(s.z) == k) a = a + s.y;              // (:124)
+        ab[(size_t)l * N + k] = a;                              // (:125) row l of in_attention
+        if (WITH_INDEX) {
+            const float t = truncf(a);
+            if (t != 0.0f) { ent_q[e] = mpi[l]; ent_w[e] = t; ++e; }
         }
-        for (int i = nbase + lane; i < M; i += 64) nz_rows[i] = -1;
-        if (lane == 0) *nz_count = nbase;
     }
 }
 
@@ -358,8 +391,8 @@ __global__ void __launch_bounds__(1024) bwd_index_kernel(const int32_t* __restri
 int launch_attention(const AttnArgs& a, hipStream_t st)
 {
     const int B = a.B, C = a.C, Cp = a.Cp, N = a.N, M = a.M;
-    const size_t ints = (size_t)2 * N + 2 + M;
-    int32_t* kq = a.rowflag + (size_t)B * (M > 0 ? M : 1);   // [B,M] right behind rowflag (see ipsr_forward carve)
+    const size_t cap = (size_t)(N - M) + (size_t)M * (M + 1) / 2;
+    const size_t ints = (size_t)N + 1 + 2 * cap;
     if (M > 0) {
         const int nch = cdiv(Cp, 512);
         const size_t lds = (size_t)4 * M * sizeof(int);
@@ -369,7 +402,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
         if (lds > 48 * 1024)                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&recurrence_kernel<NCH>),                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
-        recurrence_kernel<NCH><<<B, 64, lds, st>>>(a.xT, a.inv, a.ind, a.vmax, a.mpi, Cp, N, M, a.wn, a.wo, kq, a.rowflag); \
+        recurrence_kernel<NCH><<<B, 64, lds, st>>>(a.xT, a.inv, a.ind, a.vmax, a.mpi, Cp, N, M, a.wn, a.wo, a.kq);   \
     } while (0)
         switch (nch) {
             case 1: LAUNCH_REC(1); break;
@@ -380,22 +413,33 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
         }
 #undef LAUNCH_REC
         if (int rc = check_launch("recurrence_kernel")) return rc;
-        attn_rows_kernel<<<dim3(cdiv(N, 256), B), 256, 0, st>>>(a.wn, a.wo, kq, N, M, a.attn, a.rowflag);
-        if (int rc = check_launch("attn_rows_kernel")) return rc;
+    }
+    {
+        const size_t lds = ((size_t)((N + 3) & ~3) + 4 * (size_t)M) * sizeof(int);
+        if (lds > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: N=%d, M=%d too large for the column kernels' LDS", N, M);
+        if (lds > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&column_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&column_fill_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&column_fill_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        const dim3 grid(cdiv(N, IX_COLS), B);
+        if (a.bwd_index) {
+            column_count_kernel<<<grid, IX_COLS, lds, st>>>(a.ind, a.mpi, a.wn, a.wo, a.kq, N, M, a.col_cnt);
+            if (int rc = check_launch("column_count_kernel")) return rc;
+            index_scan_kernel<<<B, 1024, 0, st>>>(a.col_cnt, N, a.bwd_index, ints);
+            if (int rc = check_launch("index_scan_kernel")) return rc;
+            column_fill_kernel<true><<<grid, IX_COLS, lds, st>>>(a.ind, a.mpi, a.wn, a.wo, a.kq, N, M, a.attn, a.bwd_index, ints, cap);
+            if (int rc = check_launch("column_fill_kernel")) return rc;
+        } else if (M > 0) {
+            column_fill_kernel<false><<<grid, IX_COLS, lds, st>>>(a.ind, a.mpi, a.wn, a.wo, a.kq, N, M, a.attn, nullptr, ints, cap);
+            if (int rc = check_launch("column_fill_kernel")) return rc;
+        }
     }
     recon_gather_kernel<<<dim3(cdiv(N, 32), cdiv(C, 32), B), 256, 0, st>>>(a.xT, a.ind, C, Cp, N, a.out);
     if (int rc = check_launch("recon_gather_kernel")) return rc;
     if (M > 0) {
         recon_masked_kernel<<<dim3(cdiv(M, RM_BL), cdiv(C, RM_BC), B), 256, 0, st>>>(a.xT, a.attn, a.mpi, C, Cp, N, M, a.out);
         if (int rc = check_launch("recon_masked_kernel")) return rc;
-    }
-    if (a.bwd_index) {
-        const size_t lds = (size_t)((N + 3) & ~3) * sizeof(int);
-        if (lds > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: N=%d too large for bwd_index_kernel", N);
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        bwd_index_kernel<<<B, 1024, lds, st>>>(a.ind, a.mpi, a.rowflag, N, M, a.bwd_index, ints);
-        if (int rc = check_launch("bwd_index_kernel")) return rc;
     }
     return IPSR_OK;
 }

@@ -14,51 +14,49 @@
 namespace ipsr {
 
 constexpr int BW_KT = 256;   // k columns per workgroup (one per thread)
-constexpr int BW_CT = 16;    // channel rows per workgroup
-constexpr int BW_MAXE = 4;   // CSR entries cached in registers per column
+constexpr int BW_CT = 16;    // channel rows per workgroup (accumulators in registers)
 
-__global__ void __launch_bounds__(BW_KT) ipsr_backward_kernel(const float* __restrict__ g, const int32_t* __restrict__ mpi,
-                                                              int M, const float* __restrict__ attn,
-                                                              const int32_t* __restrict__ bwd_index, size_t ints_per_sample,
-                                                              float triple_w, int C, int N, float* __restrict__ gin)
+__global__ void __launch_bounds__(BW_KT) ipsr_backward_kernel(const float* __restrict__ g, const int32_t* __restrict__ bwd_index,
+                                                              size_t ints_per_sample, size_t cap, float triple_w, int C, int N,
+                                                              float* __restrict__ gin)
 {
     const int k = blockIdx.x * BW_KT + threadIdx.x;
     const int c0 = blockIdx.y * BW_CT, b = blockIdx.z;
     if (k >= N) return;
     const int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
-    const int32_t* col_q = col_off + N + 1;
-    const int nz = col_q[N];
-    const int32_t* nz_rows = col_q + N + 1;
-    const float* ab = attn + (size_t)b * M * N;
-
+    const int32_t* ent_q = col_off + N + 1;
+    const float* ent_w = reinterpret_cast<const float*>(ent_q + cap);
     const int e0 = col_off[k], e1 = col_off[k + 1];
-    int qe[BW_MAXE];
-#pragma unroll
-    for (int i = 0; i < BW_MAXE; ++i) qe[i] = (e0 + i < e1) ? col_q[e0 + i] : -1;
-
     const int c_hi = min(C, c0 + BW_CT);
-    for (int c = c0; c < c_hi; ++c) {
-        const float* gr = g + ((size_t)b * C + c) * N;
-        float acc = 0.0f;
+    const float* gb = g + ((size_t)b * C + c0) * N;
+    float acc[BW_CT];
 #pragma unroll
-        for (int i = 0; i < BW_MAXE; ++i)
-            if (qe[i] >= 0) acc = acc + gr[qe[i]];
-        for (int e = e0 + BW_MAXE; e < e1; ++e) acc = acc + gr[col_q[e]];
-        for (int i = 0; i < nz; ++i) {
-            const int l = nz_rows[i];
-            acc = __builtin_fmaf(truncf(ab[(size_t)l * N + k]), gr[mpi[l]], acc);
-        }
-        const float t = acc * triple_w;                    // (:173) mul then add, separately rounded
-        gin[((size_t)b * C + c) * N + k] = gr[k] + t;
+    for (int i = 0; i < BW_CT; ++i) acc[i] = 0.0f;
+    // column k of trunc(kbar)^T: one-hot rows first (weight 1, ascending q), then the masked rows that survive
+    // the truncation (ascending l) — one fmaf chain per output, the same order as the oracle
+#pragma unroll 4
+    for (int e = e0; e < e1; ++e) {
+        const int q = ent_q[e];
+        const float wgt = ent_w[e];
+#pragma unroll
+        for (int i = 0; i < BW_CT; ++i)
+            if (c0 + i < c_hi) acc[i] = __builtin_fmaf(wgt, gb[(size_t)i * N + q], acc[i]);
     }
+#pragma unroll
+    for (int i = 0; i < BW_CT; ++i)
+        if (c0 + i < c_hi) {
+            const float t = acc[i] * triple_w;                 // (:173) mul then add, separately rounded
+            gin[((size_t)b * C + c0 + i) * N + k] = gb[(size_t)i * N + k] + t;
+        }
 }
 
 int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn, const int32_t* bwd_index,
                     float triple_w, int B, int C, int N, float* gin, hipStream_t st)
 {
-    const size_t ints = (size_t)2 * N + 2 + M;
-    ipsr_backward_kernel<<<dim3(cdiv(N, BW_KT), cdiv(C, BW_CT), B), BW_KT, 0, st>>>(g, mpi, M, attn, bwd_index, ints,
-                                                                                  triple_w, C, N, gin);
+    (void)mpi; (void)attn;      // everything the backward needs is in bwd_index
+    const size_t cap = (size_t)(N - M) + (size_t)M * (M + 1) / 2;
+    const size_t ints = (size_t)N + 1 + 2 * cap;
+    ipsr_backward_kernel<<<dim3(cdiv(N, BW_KT), cdiv(C, BW_CT), B), BW_KT, 0, st>>>(g, bwd_index, ints, cap, triple_w, C, N, gin);
     return check_launch("ipsr_backward_kernel");
 }
 

@@ -70,10 +70,11 @@ struct AttnArgs {
     int B, C, Cp, N, M;
     float* wn;             // [B,M] ws
     float* wo;             // [B,M] ws
-    int32_t* rowflag;      // [B,M] ws (trunc(attn row) has a non-zero)
+    int32_t* kq;           // [B,M] ws: ind[mpi[l]]
+    int32_t* col_cnt;      // [B,N] ws: entries of trunc(kbar) per column k
     float* attn;           // [B,M,N]
     float* out;            // [B,C,N]
-    int32_t* bwd_index;    // [B, 2N+2+M]
+    int32_t* bwd_index;    // [B, ipsr_bwd_index_ints(N,M)]
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 

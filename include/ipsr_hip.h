@@ -82,8 +82,12 @@ int ipsr_corr_argmax(const float* xn, const float* ref, int B, int C, int N,
  *   out               [B,C,h,w] fp32
  *   ind, vmax         [B,N]     arg-max / max of the correlation (kept for inspection + backward)
  *   attn_rows         [B,M,N]   the reference's `in_attention` rows (IPSRFunction.py:76,123-125)
- *   bwd_index         [B, ipsr_bwd_index_ints(N,M)] i32: what ipsr_backward needs of
- *                     trunc(kbar) (IPSRFunction.py:36,134) in sparse form. */
+ *   bwd_index         [B, ipsr_bwd_index_ints(N,M)] i32: trunc(kbar) (the reference keeps kbar in a
+ *                     LongTensor, IPSRFunction.py:36,134) in sparse form, per sample:
+ *                       col_off[N+1] | ent_q[cap] | ent_w[cap] (fp32 bits),  cap = (N-M) + M(M+1)/2
+ *                     column k lists every (q, W[q][k] != 0): first the non-masked q with ind[q]==k
+ *                     (weight 1, ascending q), then the masked rows with |a_l[k]| >= 1 (weight
+ *                     trunc(a_l[k]), ascending l).  Only the first col_off[N] entries are defined. */
 size_t ipsr_bwd_index_ints(int N, int M);
 size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride);
 int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
@@ -93,7 +97,9 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
 
 /* ---- K8  backward -----------------------------------------------------------------------------
  * replaces IPSRFunction.backward (models/IPSRFunction.py:144-178):
- * grad_in[b,:,k] = g[b,:,k] + triple_w * sum_q trunc(A[b])[q][k] * g[b,:,q]. */
+ * grad_in[b,:,k] = g[b,:,k] + triple_w * sum_q trunc(A[b])[q][k] * g[b,:,q].
+ * Reads only grad_out and bwd_index; mask_point_idx / attn_rows are accepted for symmetry with
+ * ipsr_forward (and the oracle twin) and may be NULL. */
 int ipsr_backward(const float* grad_out, const int32_t* mask_point_idx, int M,
                   const float* attn_rows, const int32_t* bwd_index, float triple_w,
                   int B, int C, int h, int w, float* grad_in, void* stream);

@@ -21,10 +21,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--signed", action="store_true", help="signed features (what the conv stack really feeds the "
+                    "layer): attention weights leave [0,1] and many survive the backward's truncation")
     a = ap.parse_args()
     B, C, h, size, lo, hi = CFG[a.cfg]
     g = torch.Generator(device="cuda").manual_seed(1234)
-    x = torch.randn(B, C, h, h, device="cuda", generator=g).abs()
+    x = torch.randn(B, C, h, h, device="cuda", generator=g)
+    if not a.signed:
+        x = x.abs()
     ref = torch.relu(torch.randn(B, C, h, h, device="cuda", generator=g))
     grad = torch.randn(B, C, h, h, device="cuda", generator=g)
     m = torch.zeros(size, size, dtype=torch.uint8, device="cuda")
@@ -48,8 +52,8 @@ def main():
         torch.cuda.synchronize()
         tf += e[0].elapsed_time(e[1])
         tb += e[1].elapsed_time(e[2])
-    print("cfg%d B=%d C=%d %dx%d M=%d: forward %.3f ms  backward %.3f ms (mean of %d)" %
-          (a.cfg, B, C, h, h, M, tf / a.iters, tb / a.iters, a.iters))
+    print("cfg%d%s B=%d C=%d %dx%d M=%d: forward %.3f ms  backward %.3f ms (mean of %d)" %
+          (a.cfg, " signed" if a.signed else "", B, C, h, h, M, tf / a.iters, tb / a.iters, a.iters))
 
 
 if __name__ == "__main__":
