@@ -51,95 +51,176 @@ __device__ __forceinline__ float wave_sum_canonical(float p)
 
 // ---------------------------------------------------------------------------------------------------
 // K6 serial part.  NCH = ceil(Cp / 512): lane j owns the 8-channel chunks j, j+64, ...
+//
+// Latency engineering (this kernel is M dependent steps on ONE wave per sample, nothing else matters):
+//   * the index chain mpi -> ind -> (inv, vmax) is resolved for all steps up front into LDS, stored by step
+//     so that the 4 steps of a ring turn are one aligned ds_read_b128 per array;
+//   * patch rows come through a RING-deep register ring; the steady-state loop is branch-free, so the
+//     compiler can wait with a counted vmcnt for exactly the rows of the current step while the rows of the
+//     next RING-1 steps stay in flight (a conditional in the loop degrades that to vmcnt(0) = one full memory
+//     round trip per step);
+//   * (wn_l, wo_l) are parked in the lane l%64 and written 64 at a time, so the loop has no stores either.
 constexpr int RING = 4;
 
 template <int NCH>
+struct RowRegs { float v[NCH][8]; };
+
+// Branch-free row load: lanes whose chunk lies past Cp read chunk 0 instead (a valid address); the loaded
+// registers are NOT touched here (any use would force the compiler to wait for the load right away) — the
+// consumer zeroes such chunks with `live_mask` when it finally reads them.
+template <int NCH>
+__device__ __forceinline__ void load_row(RowRegs<NCH>& dst, const float* __restrict__ xTb, int row, int Cp, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int base = (lane + 64 * i) * 8;
+        const float* p = xTb + (size_t)row * Cp + (base < Cp ? base : 0);
+        const float4 v0 = *reinterpret_cast<const float4*>(p);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+        dst.v[i][0] = v0.x; dst.v[i][1] = v0.y; dst.v[i][2] = v0.z; dst.v[i][3] = v0.w;
+        dst.v[i][4] = v1.x; dst.v[i][5] = v1.y; dst.v[i][6] = v1.z; dst.v[i][7] = v1.w;
+    }
+}
+
+// one step of IPSRFunction.py:105-125 on the wave-distributed state o.  FULL: Cp == 512*NCH, every lane chunk is
+// live and no masking is needed; otherwise chunks past Cp contribute exact zeros.
+template <int NCH, bool FULL>
+__device__ __forceinline__ void rec_step(RowRegs<NCH>& o, const RowRegs<NCH>& pu, const RowRegs<NCH>& pk, float iq, float v,
+                                         int Cp, int lane, float& wn, float& wo)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const bool live = FULL || ((lane + 64 * i) * 8 < Cp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float u = (live ? pu.v[i][e] : 0.0f) * iq;                                 // u = P[q]*inv  (:109)
+            acc = __builtin_fmaf(u, o.v[i][e], acc);
+        }
+    }
+    const float at = wave_sum_canonical(acc);                                                // (:116)
+    const float s = at + v;
+    wn = at / s;                                                                             // (:120)
+    wo = v / s;                                                                              // (:121)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const bool live = FULL || ((lane + 64 * i) * 8 < Cp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t0 = wn * o.v[i][e];
+            const float t1 = wo * (live ? pk.v[i][e] : 0.0f);
+            o.v[i][e] = t0 + t1;                                                             // (:122)
+        }
+    }
+}
+
+template <int NCH, bool FULL>
 __global__ void __launch_bounds__(64) recurrence_kernel(const float* __restrict__ xT, const float* __restrict__ inv,
                                                         const int32_t* __restrict__ ind, const float* __restrict__ vmax,
                                                         const int32_t* __restrict__ mpi, int Cp, int N, int M,
                                                         float* __restrict__ wn_out, float* __restrict__ wo_out,
                                                         int32_t* __restrict__ kq_out)
 {
+    // step-indexed LDS arrays: entry s describes step l = s + 1 (so a ring turn l = 1+4j.. is 16-byte aligned);
+    // padded by 3*RING entries that repeat a valid row index so that run-ahead prefetches stay in bounds
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-    int* q_s = lds_raw;                 // [M]
-    int* kq_s = q_s + M;                // [M]
-    float* iv_s = reinterpret_cast<float*>(kq_s + M);   // [M]
-    float* vm_s = iv_s + M;             // [M]
+    const int Mp = ((M + 3) & ~3) + 3 * RING;
+    int* q_s = lds_raw;
+    int* kq_s = q_s + Mp;
+    float* iv_s = reinterpret_cast<float*>(kq_s + Mp);
+    float* vm_s = iv_s + Mp;
+    float* wn_s = vm_s + Mp;      // (wn_l, wo_l) indexed by l, copied out in one coalesced pass at the end
+    float* wo_s = wn_s + Mp;
 
     const int b = blockIdx.x, lane = threadIdx.x;
     const float* xTb = xT + (size_t)b * N * Cp;
     const int32_t* indb = ind + (size_t)b * N;
 
-    // resolve the index chain mpi -> ind -> (inv, vmax) for all steps up front, 64 steps at a time
     for (int l = lane; l < M; l += 64) {
         const int q = mpi[l];
         const int kq = indb[q];
-        q_s[l] = q;
-        kq_s[l] = kq;
-        iv_s[l] = inv[(size_t)b * N + q];
-        vm_s[l] = vmax[(size_t)b * N + q];
         kq_out[(size_t)b * M + l] = kq;
+        if (l >= 1) {
+            q_s[l - 1] = q;
+            kq_s[l - 1] = kq;
+            iv_s[l - 1] = inv[(size_t)b * N + q];
+            vm_s[l - 1] = vmax[(size_t)b * N + q];
+        }
     }
+    const int q0 = mpi[0];
+    const int kq0 = indb[q0];
+    for (int s = M - 1 + lane; s < Mp; s += 64) { q_s[s] = q0; kq_s[s] = kq0; iv_s[s] = 0.0f; vm_s[s] = 1.0f; }
+    if (lane == 0) { wn_s[0] = 0.0f; wo_s[0] = 1.0f; }      // step 0: (wn, wo) = (0, 1) makes a_0 = onehot(kq_0)
     __syncthreads();
 
-    float o[NCH][8];
-    float pu[RING][NCH][8], pk[RING][NCH][8];
-
-    auto load_row = [&](float (&dst)[NCH][8], int row) {
+    // Two register sets of RING slots: set A serves even ring turns, set B odd ones.  A slot is refilled right
+    // after it is consumed with the row of the step TWO turns ahead, so every load has a full turn (4 steps)
+    // of compute to land in, wherever the scheduler places it inside the turn.
+    RowRegs<NCH> o, puA[RING], pkA[RING], puB[RING], pkB[RING];
+    load_row<NCH>(o, xTb, kq0, Cp, lane);              // step 0: o_0 = P[kq_0]   (IPSRFunction.py:98-101)
+    if (!FULL) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int base = (lane + 64 * i) * 8;
-            if (base < Cp) {
-                const float4 v0 = *reinterpret_cast<const float4*>(xTb + (size_t)row * Cp + base);
-                const float4 v1 = *reinterpret_cast<const float4*>(xTb + (size_t)row * Cp + base + 4);
-                dst[i][0] = v0.x; dst[i][1] = v0.y; dst[i][2] = v0.z; dst[i][3] = v0.w;
-                dst[i][4] = v1.x; dst[i][5] = v1.y; dst[i][6] = v1.z; dst[i][7] = v1.w;
-            } else {
+        for (int i = 0; i < NCH; ++i)
+            if ((lane + 64 * i) * 8 >= Cp) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dst[i][e] = 0.0f;
+                for (int e = 0; e < 8; ++e) o.v[i][e] = 0.0f;
             }
-        }
-    };
-
-    // step 0: o_0 = P[kq_0]   (IPSRFunction.py:98-101)
-    load_row(o, kq_s[0]);
-    if (lane == 0) { wn_out[(size_t)b * M] = 0.0f; wo_out[(size_t)b * M] = 1.0f; }
-
-    // prime the ring with steps 1..RING
+    }
 #pragma unroll
     for (int d = 0; d < RING; ++d) {
-        const int l = 1 + d;
-        if (l < M) { load_row(pu[d], q_s[l]); load_row(pk[d], kq_s[l]); }
+        load_row<NCH>(puA[d], xTb, q_s[d], Cp, lane);        load_row<NCH>(pkA[d], xTb, kq_s[d], Cp, lane);
+        load_row<NCH>(puB[d], xTb, q_s[RING + d], Cp, lane); load_row<NCH>(pkB[d], xTb, kq_s[RING + d], Cp, lane);
     }
 
-    for (int l0 = 1; l0 < M; l0 += RING) {
-#pragma unroll
-        for (int d = 0; d < RING; ++d) {
-            const int l = l0 + d;
-            if (l < M) {
-                const float iq = iv_s[l], v = vm_s[l];
-                float acc = 0.0f;
-#pragma unroll
-                for (int i = 0; i < NCH; ++i)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(pu[d][i][e] * iq, o[i][e], acc);   // u = P[q]*inv  (:109)
-                const float at = wave_sum_canonical(acc);                                                // (:116)
-                const float s = at + v;
-                const float wn = at / s, wo = v / s;                                                     // (:120-121)
-#pragma unroll
-                for (int i = 0; i < NCH; ++i)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float t0 = wn * o[i][e];
-                        const float t1 = wo * pk[d][i][e];
-                        o[i][e] = t0 + t1;                                                               // (:122)
-                    }
-                if (lane == 0) { wn_out[(size_t)b * M + l] = wn; wo_out[(size_t)b * M + l] = wo; }
-                const int ln = l + RING;
-                if (ln < M) { load_row(pu[d], q_s[ln]); load_row(pk[d], kq_s[ln]); }
-            }
-        }
+    const int nsteps = M - 1;                          // steps l = 1 .. M-1  <->  s = 0 .. nsteps-1
+    const int nfull = nsteps / RING;                   // branch-free ring turns
+
+#define IPSR_TURN(PU, PK, S0)                                                                                   \
+    do {                                                                                                        \
+        const int s0_ = (S0);                                                                                   \
+        const int4 qn = *reinterpret_cast<const int4*>(&q_s[s0_ + 2 * RING]);                                   \
+        const int4 kn = *reinterpret_cast<const int4*>(&kq_s[s0_ + 2 * RING]);                                  \
+        const float4 iv4 = *reinterpret_cast<const float4*>(&iv_s[s0_]);                                        \
+        const float4 vm4 = *reinterpret_cast<const float4*>(&vm_s[s0_]);                                        \
+        const int qn_[4] = {qn.x, qn.y, qn.z, qn.w}, kn_[4] = {kn.x, kn.y, kn.z, kn.w};                         \
+        const float iv_[4] = {iv4.x, iv4.y, iv4.z, iv4.w}, vm_[4] = {vm4.x, vm4.y, vm4.z, vm4.w};               \
+        _Pragma("unroll") for (int d = 0; d < RING; ++d) {                                                      \
+            float wn, wo;                                                                                       \
+            rec_step<NCH, FULL>(o, PU[d], PK[d], iv_[d], vm_[d], Cp, lane, wn, wo);                                             \
+            wn_s[s0_ + d + 1] = wn;                                                                             \
+            wo_s[s0_ + d + 1] = wo;                                                                             \
+            load_row<NCH>(PU[d], xTb, qn_[d], Cp, lane);                                                        \
+            load_row<NCH>(PK[d], xTb, kn_[d], Cp, lane);                                                        \
+        }                                                                                                       \
+    } while (0)
+#define IPSR_TAIL(PU, PK, S0)                                                                                   \
+    do {                                                                                                        \
+        const int s0_ = (S0);                                                                                   \
+        _Pragma("unroll") for (int d = 0; d < RING - 1; ++d) {                                                  \
+            if (s0_ + d < nsteps) {                                                                             \
+                float wn, wo;                                                                                   \
+                rec_step<NCH, FULL>(o, PU[d], PK[d], iv_s[s0_ + d], vm_s[s0_ + d], Cp, lane, wn, wo);                           \
+                wn_s[s0_ + d + 1] = wn;                                                                         \
+                wo_s[s0_ + d + 1] = wo;                                                                         \
+            }                                                                                                   \
+        }                                                                                                       \
+    } while (0)
+
+    int t = 0;
+    for (; t + 2 <= nfull; t += 2) {
+        IPSR_TURN(puA, pkA, t * RING);
+        IPSR_TURN(puB, pkB, (t + 1) * RING);
     }
+    if (t < nfull) {                                   // odd number of full turns: one more on A, partial turn on B
+        IPSR_TURN(puA, pkA, t * RING);
+        IPSR_TAIL(puB, pkB, (t + 1) * RING);
+    } else {
+        IPSR_TAIL(puA, pkA, t * RING);
+    }
+#undef IPSR_TURN
+#undef IPSR_TAIL
+    __syncthreads();
+    for (int l = lane; l < M; l += 64) { wn_out[(size_t)b * M + l] = wn_s[l]; wo_out[(size_t)b * M + l] = wo_s[l]; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -284,10 +365,32 @@ __device__ __forceinline__ ColumnLds load_column_lds(int* lds, const int32_t* __
     ColumnLds L;
     L.step = reinterpret_cast<float4*>(lds);
     L.key = lds + 4 * M;
-    for (int q = threadIdx.x; q < Npad; q += IX_COLS) L.key[q] = q < N ? ind[q] : -1;
-    for (int l = threadIdx.x; l < M; l += IX_COLS) L.step[l] = make_float4(wn[l], wo[l], __int_as_float(kq[l]), 0.0f);
+    // batches of 4 independent global loads per thread (a plain strided loop would serialise the round trips)
+    for (int q0 = 0; q0 < Npad; q0 += 4 * IX_COLS) {
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int q = q0 + j * IX_COLS + threadIdx.x; v[j] = q < N ? ind[q] : -1; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int q = q0 + j * IX_COLS + threadIdx.x; if (q < Npad) L.key[q] = v[j]; }
+    }
+    for (int l0 = 0; l0 < M; l0 += 2 * IX_COLS) {
+        float4 v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int l = l0 + j * IX_COLS + threadIdx.x;
+            v[j] = l < M ? make_float4(wn[l], wo[l], __int_as_float(kq[l]), 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int l = l0 + j * IX_COLS + threadIdx.x; if (l < M) L.step[l] = v[j]; }
+    }
     __syncthreads();
-    for (int l = threadIdx.x; l < M; l += IX_COLS) L.key[mpi[l]] = -1;
+    for (int l0 = 0; l0 < M; l0 += 4 * IX_COLS) {
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int l = l0 + j * IX_COLS + threadIdx.x; v[j] = l < M ? mpi[l] : -1; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (v[j] >= 0) L.key[v[j]] = -1;
+    }
     __syncthreads();
     return L;
 }
@@ -303,15 +406,17 @@ __global__ void __launch_bounds__(IX_COLS) column_count_kernel(const int32_t* __
     const int k = blockIdx.x * IX_COLS + threadIdx.x;
     if (k >= N) return;
     int cnt = 0;
+#pragma unroll 8
     for (int q = 0; q < Npad; q += 4) {
         const int4 v = *reinterpret_cast<const int4*>(&L.key[q]);
         cnt += (v.x == k) + (v.y == k) + (v.z == k) + (v.w == k);
     }
     float a = 0.0f;
+#pragma unroll 8
     for (int l = 0; l < M; ++l) {
         const float4 s = L.step[l];
         a = a * s.x;
-        if (__float_as_int(s.z) == k) a = a + s.y;
+        a = (__float_as_int(s.z) == k) ? a + s.y : a;
         cnt += (truncf(a) != 0.0f) ? 1 : 0;
     }
     col_cnt[(size_t)b * N + k] = cnt;
@@ -365,6 +470,7 @@ __global__ void __launch_bounds__(IX_COLS) column_fill_kernel(const int32_t* __r
         ent_q = col_off + N + 1;
         ent_w = reinterpret_cast<float*>(ent_q + cap);
         e = col_off[k];
+#pragma unroll 8
         for (int q = 0; q < Npad; q += 4) {
             const int4 v = *reinterpret_cast<const int4*>(&L.key[q]);
             if (v.x == k) { ent_q[e] = q;     ent_w[e] = 1.0f; ++e; }
@@ -375,10 +481,11 @@ __global__ void __launch_bounds__(IX_COLS) column_fill_kernel(const int32_t* __r
     }
     float* ab = attn + (size_t)b * M * N;
     float a = 0.0f;
+#pragma unroll 8
     for (int l = 0; l < M; ++l) {
         const float4 s = L.step[l];
         a = a * s.x;                                            // (:123)
-        if (__float_as_int(s.z) == k) a = a + s.y;              // (:124)
+        a = (__float_as_int(s.z) == k) ? a + s.y : a;           // (:124)
         ab[(size_t)l * N + k] = a;                              // (:125) row l of in_attention
         if (WITH_INDEX) {
             const float t = truncf(a);
@@ -395,14 +502,19 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
     const size_t ints = (size_t)N + 1 + 2 * cap;
     if (M > 0) {
         const int nch = cdiv(Cp, 512);
-        const size_t lds = (size_t)4 * M * sizeof(int);
+        const size_t lds = (size_t)6 * (((M + 3) & ~3) + 3 * RING) * sizeof(int);
         if (lds > 160 * 1024 - 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: M=%d too large for the recurrence's LDS index cache", M);
-#define LAUNCH_REC(NCH)                                                                                              \
+#define LAUNCH_REC2(NCH, FULL)                                                                                       \
     do {                                                                                                             \
         if (lds > 48 * 1024)                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&recurrence_kernel<NCH>),                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&recurrence_kernel<NCH, FULL>),                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
-        recurrence_kernel<NCH><<<B, 64, lds, st>>>(a.xT, a.inv, a.ind, a.vmax, a.mpi, Cp, N, M, a.wn, a.wo, a.kq);   \
+        recurrence_kernel<NCH, FULL><<<B, 64, lds, st>>>(a.xT, a.inv, a.ind, a.vmax, a.mpi, Cp, N, M, a.wn, a.wo, a.kq); \
+    } while (0)
+#define LAUNCH_REC(NCH)                                                                                              \
+    do {                                                                                                             \
+        if (Cp == 512 * (NCH)) LAUNCH_REC2(NCH, true);                                                               \
+        else LAUNCH_REC2(NCH, false);                                                                                \
     } while (0)
         switch (nch) {
             case 1: LAUNCH_REC(1); break;
@@ -412,6 +524,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
             default: return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: C=%d > 2048 channels not supported", C);
         }
 #undef LAUNCH_REC
+#undef LAUNCH_REC2
         if (int rc = check_launch("recurrence_kernel")) return rc;
     }
     {
