@@ -34,8 +34,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;   // k rows (patches) per workgroup tile
 constexpr int BN = 128;   // q columns (reference positions) per workgroup tile
-constexpr int BK = 16;    // channels per LDS stage
+constexpr int BK = 16;    // channels per LDS stage (generic kernel)
+constexpr int FBK = 32;   // channels per LDS stage (fast kernel: direct-to-LDS loads)
 constexpr int NTHREADS = 256;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ bool better(float v1, int i1, float v0, int i0)
 {
@@ -185,6 +189,139 @@ corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fast path (N % 128 == 0, C % 32 == 0, 16-byte aligned operands): same tiling and the same arithmetic, but
+//   * operand tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4: 64 lanes x 16 B = two 512-byte tile rows
+//     per wave-instruction, no staging VGPRs, no ds_write pass); the tile of stage s+1 is in flight while the
+//     64 MFMAs per wave of stage s run; FBK = 32 channels per stage halves the barriers;
+//   * the MFMA operand fragments of k-step kk+1 are read from LDS while the 4 MFMAs of kk execute.
+template <bool WRITE_S>
+__global__ void __launch_bounds__(NTHREADS, 2)
+corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ ref, int C, int N,
+                        int qtiles, int ksplit, int ktiles, int kt_per_wg,
+                        float* __restrict__ S_out, float* __restrict__ pval, int32_t* __restrict__ pidx)
+{
+    // one array (a second __shared__ object next to an LDS-DMA target can make hipcc drain vmcnt early)
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * FBK * BM + 2 * 2 * 32 * 2];
+    float* const tiles = lds;                                  // [buf][A|B][FBK][128]
+    float* const red_v = lds + 2 * 2 * FBK * BM;               // [wn][jn][32]
+    int* const red_i = reinterpret_cast<int*>(red_v + 2 * 2 * 32);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = L % ksplit;
+    const int qt = (L / ksplit) % qtiles;
+    const int b = L / (ksplit * qtiles);
+    const int q0 = qt * BN;
+
+    const float* A = xn + (size_t)b * C * N;
+    const float* R = ref + (size_t)b * C * N;
+
+    float best[2] = {-INFINITY, -INFINITY};
+    int bidx[2] = {0x7fffffff, 0x7fffffff};
+
+    const int nstage = C / FBK;
+    const int kt_lo = ks * kt_per_wg, kt_hi = min(ktiles, kt_lo + kt_per_wg);
+
+    // LDS-DMA assignment: a stage = 2 operands x FBK rows x 512 B = 32 wave-instructions of 1 KiB (2 rows);
+    // wave w issues instructions w, w+4, ...: 4 for A then 4 for B.  Lane -> (row parity, 16-byte column).
+    const int dma_row = lane >> 5, dma_col = (lane & 31) * 4;
+
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int k0 = kt * BM;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+        auto stage_dma = [&](int s, int buf) {
+            const int c0 = s * FBK;
+            float* ta = tiles + (size_t)buf * (2 * FBK * BM);
+            float* tb = ta + FBK * BM;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pair = wave + 4 * j;                 // rows 2*pair, 2*pair+1
+                const int row = 2 * pair + dma_row;
+                __builtin_amdgcn_global_load_lds((gptr_t)(A + (size_t)(c0 + row) * N + k0 + dma_col),
+                                                 (lptr_t)(ta + pair * 2 * BM), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(R + (size_t)(c0 + row) * N + q0 + dma_col),
+                                                 (lptr_t)(tb + pair * 2 * BM), 16, 0, 0);
+            }
+        };
+
+        stage_dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int s = 0; s < nstage; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < nstage) stage_dma(s + 1, cur ^ 1);
+            const float* ta = tiles + (size_t)cur * (2 * FBK * BM) + wm * 64 + r;
+            const float* tb = tiles + (size_t)cur * (2 * FBK * BM) + FBK * BM + wn * 64 + r;
+            float a0 = ta[h * BM], a1 = ta[h * BM + 32], b0 = tb[h * BM], b1 = tb[h * BM + 32];
+#pragma unroll
+            for (int kk = 0; kk < FBK / 2; ++kk) {
+                float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                if (kk + 1 < FBK / 2) {
+                    const int ro = ((kk + 1) * 2 + h) * BM;
+                    na0 = ta[ro]; na1 = ta[ro + 32]; nb0 = tb[ro]; nb1 = tb[ro + 32];
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int q = q0 + wn * 64 + jn * 32 + r;
+#pragma unroll
+            for (int im = 0; im < 2; ++im) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = k0 + wm * 64 + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = acc[im][jn][e];
+                    if (v > best[jn]) { best[jn] = v; bidx[jn] = k; }
+                    if (WRITE_S) S_out[((size_t)b * N + k) * N + q] = v;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const float ov = __shfl_xor(best[jn], 32);
+        const int oi = __shfl_xor(bidx[jn], 32);
+        if (better(ov, oi, best[jn], bidx[jn])) { best[jn] = ov; bidx[jn] = oi; }
+    }
+    if (wm == 1 && h == 0) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) { red_v[(wn * 2 + jn) * 32 + r] = best[jn]; red_i[(wn * 2 + jn) * 32 + r] = bidx[jn]; }
+    }
+    __syncthreads();
+    if (wm == 0 && h == 0) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const float ov = red_v[(wn * 2 + jn) * 32 + r];
+            const int oi = red_i[(wn * 2 + jn) * 32 + r];
+            if (better(ov, oi, best[jn], bidx[jn])) { best[jn] = ov; bidx[jn] = oi; }
+            const int q = q0 + wn * 64 + jn * 32 + r;
+            pval[((size_t)b * ksplit + ks) * N + q] = best[jn];
+            pidx[((size_t)b * ksplit + ks) * N + q] = bidx[jn];
+        }
+    }
+}
+
 // merge the k-split partials in ascending k order
 __global__ void __launch_bounds__(256) argmax_merge_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
                                                            int B, int N, int ksplit, int32_t* __restrict__ ind,
@@ -234,12 +371,12 @@ int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, i
     Carver cv(ws, ws_bytes);
     float* pval = cv.take<float>((size_t)B * ks * N);
     int32_t* pidx = cv.take<int32_t>((size_t)B * ks * N);
-    const bool fast = (N % BM == 0) && (C % BK == 0) && ((reinterpret_cast<uintptr_t>(xn) | reinterpret_cast<uintptr_t>(ref)) & 15u) == 0;
+    const bool fast = (N % BM == 0) && (C % FBK == 0) && ((reinterpret_cast<uintptr_t>(xn) | reinterpret_cast<uintptr_t>(ref)) & 15u) == 0;
     const int grid = B * qt * ks;
     profile_mark_start(st);
     if (fast) {
-        if (S_out) corr_argmax_kernel<true, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
-        else corr_argmax_kernel<true, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
+        if (S_out) corr_argmax_fast_kernel<true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
+        else corr_argmax_fast_kernel<false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
     } else {
         if (S_out) corr_argmax_kernel<false, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
         else corr_argmax_kernel<false, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
