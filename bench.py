@@ -74,10 +74,11 @@ def layer_timing(device, iters=50):
     m[FINE // 4:3 * FINE // 4, FINE // 4:3 * FINE // 4] = 1
     feat = ops.feat_mask(m, 3, 5 / 16.0)
     _, mpi, cnt = ops.index_prep(feat, 1, 1, 1)
-    mpi = mpi[:int(cnt.item())].contiguous()
+    M = int(cnt.item())
+    mpi = mpi[:M].contiguous()
     for _ in range(5):
         f = ops.forward(x, ref, mpi)
-        ops.backward(grad, mpi, f.attn_rows, f.bwd_index, 1.0)
+        ops.backward(grad, f.bwd_index, 1.0, M)
     torch.cuda.synchronize()
     fwd, bwd = [], []
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -85,7 +86,7 @@ def layer_timing(device, iters=50):
         ev[0].record()
         f = ops.forward(x, ref, mpi)
         ev[1].record()
-        ops.backward(grad, mpi, f.attn_rows, f.bwd_index, 1.0)
+        ops.backward(grad, f.bwd_index, 1.0, M)
         ev[2].record()
         torch.cuda.synchronize()
         fwd.append(ev[0].elapsed_time(ev[1]))
@@ -158,6 +159,9 @@ def main():
                  checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
     torch.manual_seed(1234)                       # identical init on every rank (rank 0 is broadcast anyway)
     model = quiet(create_model, opt)
+    if os.environ.get("IPSR_BENCH_CHANNELS_LAST", "0") == "1":      # experiment knob, not the default
+        for net in (model.netG, model.netP, model.netD, model.netF, model.vgg):
+            net.to(memory_format=torch.channels_last)
     img, mask, ref = synthetic_batch(device, args.batch, 1234 + rank)
 
     lib = _lib.lib()

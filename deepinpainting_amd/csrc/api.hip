@@ -57,24 +57,37 @@ void profile_mark_stop(hipStream_t st)
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 struct FwdPlan {
-    int N, Cp;
-    size_t xn, xT, inv, corr, wn, wo, flags, total;   // byte sizes of the workspace slices
+    int N, Cp, Mc;
+    size_t total;
 };
 
-static FwdPlan plan_forward(int B, int C, int h, int w, int M)
+// workspace slices in carve order (all 256-B aligned)
+enum { WS_XN, WS_XT, WS_INV, WS_CORR, WS_WN, WS_WO, WS_KQ, WS_JQ, WS_DLIST, WS_MPRIME, WS_RANKFLAG, WS_ONEHOT, WS_SURV,
+       WS_COLCNT, WS_AC, WS_COUNT };
+
+static FwdPlan plan_forward(int B, int C, int h, int w, int M, size_t* sizes)
 {
     FwdPlan p;
     p.N = h * w;
     p.Cp = (C + 7) & ~7;
+    p.Mc = M > 0 ? (M + 31) & ~31 : 32;
     const size_t Mx = M > 0 ? M : 1;
-    p.xn = align_up((size_t)B * C * p.N * 4, 256);
-    p.xT = align_up((size_t)B * p.N * p.Cp * 4, 256);
-    p.inv = align_up((size_t)B * p.N * 4, 256);
-    p.corr = align_up(corr_argmax_ws_bytes(B, C, p.N), 256);
-    p.wn = align_up((size_t)B * Mx * 4, 256);
-    p.wo = p.wn;
-    p.flags = align_up((size_t)B * Mx * 4, 256) + align_up((size_t)B * p.N * 4, 256);   // kq [B,M], col_cnt [B,N]
-    p.total = p.xn + p.xT + p.inv + p.corr + p.wn + p.wo + p.flags + 256;
+    size_t sz[WS_COUNT];
+    sz[WS_XN] = (size_t)B * C * p.N * 4;
+    sz[WS_XT] = (size_t)B * p.N * p.Cp * 4;
+    sz[WS_INV] = (size_t)B * p.N * 4;
+    sz[WS_CORR] = corr_argmax_ws_bytes(B, C, p.N);
+    sz[WS_WN] = sz[WS_WO] = sz[WS_KQ] = sz[WS_JQ] = (size_t)B * Mx * 4;
+    sz[WS_DLIST] = sz[WS_SURV] = (size_t)B * p.Mc * 4;
+    sz[WS_MPRIME] = (size_t)B * 4;
+    sz[WS_RANKFLAG] = sz[WS_ONEHOT] = sz[WS_COLCNT] = (size_t)B * p.N * 4;
+    sz[WS_AC] = (size_t)B * Mx * p.Mc * 4;
+    p.total = 256;
+    for (int i = 0; i < WS_COUNT; ++i) {
+        sz[i] = align_up(sz[i], 256);
+        p.total += sz[i];
+        if (sizes) sizes[i] = sz[i];
+    }
     return p;
 }
 
@@ -174,7 +187,7 @@ size_t ipsr_bwd_index_ints(int N, int M)
 size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride)
 {
     if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0 || patch != 1 || stride != 1) return 0;
-    return plan_forward(B, C, h, w, M).total;
+    return plan_forward(B, C, h, w, M, nullptr).total;
 }
 
 int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
@@ -186,30 +199,39 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0 || M > h * w) return fail(IPSR_ERR_INVALID, "ipsr_forward: bad size B=%d C=%d h=%d w=%d M=%d", B, C, h, w, M);
     if (patch != 1 || stride != 1)
         return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: only shift_sz=1, stride=1 is implemented (got %d, %d); the reference raises for these too (models/IPSRFunction.py:134)", patch, stride);
-    if (M > 0 && (!mask_point_idx || !attn_rows)) return fail(IPSR_ERR_INVALID, "ipsr_forward: M > 0 needs mask_point_idx and attn_rows");
+    if (M > 0 && !mask_point_idx) return fail(IPSR_ERR_INVALID, "ipsr_forward: M > 0 needs mask_point_idx");
     if (!aligned16(x) || !aligned16(ref) || !aligned16(out) || !aligned16(ws) || (attn_rows && !aligned16(attn_rows)))
         return fail(IPSR_ERR_INVALID, "ipsr_forward: x/ref/out/attn_rows/ws must be 16-byte aligned");
-    const FwdPlan p = plan_forward(B, C, h, w, M);
+    size_t sz[WS_COUNT];
+    const FwdPlan p = plan_forward(B, C, h, w, M, sz);
     if (ws_bytes < p.total) return fail(IPSR_ERR_WORKSPACE, "ipsr_forward: workspace %zu < %zu", ws_bytes, p.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
 
+    char* slice[WS_COUNT];
     char* base = static_cast<char*>(ws);
-    float* xn = reinterpret_cast<float*>(base); base += p.xn;
-    float* xT = reinterpret_cast<float*>(base); base += p.xT;
-    float* inv = reinterpret_cast<float*>(base); base += p.inv;
-    void* corr_ws = base; base += p.corr;
-    float* wn = reinterpret_cast<float*>(base); base += p.wn;
-    float* wo = reinterpret_cast<float*>(base); base += p.wo;
-    int32_t* kq = reinterpret_cast<int32_t*>(base); base += align_up((size_t)B * (M > 0 ? M : 1) * 4, 256);
-    int32_t* col_cnt = reinterpret_cast<int32_t*>(base);
+    for (int i = 0; i < WS_COUNT; ++i) { slice[i] = base; base += sz[i]; }
+    float* xn = reinterpret_cast<float*>(slice[WS_XN]);
+    float* xT = reinterpret_cast<float*>(slice[WS_XT]);
+    float* inv = reinterpret_cast<float*>(slice[WS_INV]);
 
     if (int rc = launch_patch_normalize(x, B, C, p.N, xn, xT, p.Cp, inv, st)) return rc;
-    if (int rc = launch_corr_argmax(xn, ref, B, C, p.N, ind, vmax, nullptr, corr_ws, p.corr, st)) return rc;
+    if (int rc = launch_corr_argmax(xn, ref, B, C, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st)) return rc;
 
     AttnArgs a;
     a.x = x; a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
-    a.B = B; a.C = C; a.Cp = p.Cp; a.N = p.N; a.M = M;
-    a.wn = wn; a.wo = wo; a.kq = kq; a.col_cnt = col_cnt; a.attn = attn_rows; a.out = out; a.bwd_index = bwd_index;
+    a.B = B; a.C = C; a.Cp = p.Cp; a.N = p.N; a.M = M; a.Mc = p.Mc;
+    a.wn = reinterpret_cast<float*>(slice[WS_WN]);
+    a.wo = reinterpret_cast<float*>(slice[WS_WO]);
+    a.kq = reinterpret_cast<int32_t*>(slice[WS_KQ]);
+    a.jq = reinterpret_cast<int32_t*>(slice[WS_JQ]);
+    a.dlist = reinterpret_cast<int32_t*>(slice[WS_DLIST]);
+    a.mprime = reinterpret_cast<int32_t*>(slice[WS_MPRIME]);
+    a.rankflag = reinterpret_cast<int32_t*>(slice[WS_RANKFLAG]);
+    a.onehot_cnt = reinterpret_cast<int32_t*>(slice[WS_ONEHOT]);
+    a.surv_cnt = reinterpret_cast<int32_t*>(slice[WS_SURV]);
+    a.col_cnt = reinterpret_cast<int32_t*>(slice[WS_COLCNT]);
+    a.ac = reinterpret_cast<float*>(slice[WS_AC]);
+    a.attn = attn_rows; a.out = out; a.bwd_index = bwd_index;
     return launch_attention(a, st);
 }
 

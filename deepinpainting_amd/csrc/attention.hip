@@ -11,14 +11,14 @@
 //     registers (8 channels per lane per 512), reads patch rows from the patch-major copy xT through a
 //     4-deep register prefetch ring, reduces the dot with DPP + readlane (no LDS, no barrier) and emits
 //     only the scalars (wn_l, wo_l).  Latency-bound by construction: M dependent steps.
-//   * column_fill_kernel — a_l[k] is a scalar recurrence per k, independent across k: one thread per k
-//     replays (wn_l, wo_l) from LDS and writes the reference's `in_attention` rows [M,N], coalesced.
+//   * attn_compress_kernel — a_l[k] is a scalar recurrence per k, independent across k, and non-zero only in
+//     the columns {kq_l}: one thread per ACTIVE column replays (wn_l, wo_l) from LDS (see "Compressed attention").
 //   * recon_gather_kernel — non-masked q: kbar column is one-hot, so out[:,q] = P[ind[q]] is a row
 //     gather (LDS-transposed so that both the read of xT rows and the write of out rows are coalesced).
 //   * recon_masked_kernel — masked q: out[:,q_l] = sum_k a_l[k] * P[k,:], the dense part of the
-//     reference's second GEMM, on fp32 MFMA with k walked in ascending order (one fmaf chain per
-//     output, same bits as the oracle).
-//   * column_count / index_scan / column_fill — kbar is kept by the reference in a LongTensor (:36,134), i.e.
+//     reference's second GEMM, on fp32 MFMA over the active columns in ascending k (one fmaf chain per
+//     output; the skipped terms are exact zeros, so the bits equal the oracle's dense chain).
+//   * attn_prepare / index_scan / csr_fill — kbar is kept by the reference in a LongTensor (:36,134), i.e.
 //     truncated toward zero.  What survives is stored as a CSR over the patch index k: the non-masked q
 //     with ind[q] == k (weight 1, ascending q) followed by the masked rows whose |a_l[k]| >= 1 (weight
 //     trunc(a_l[k]), ascending l).  That is all the backward needs.
@@ -249,177 +249,121 @@ __global__ void __launch_bounds__(256) recon_gather_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
-// masked columns on the matrix cores:  D[c][l] = sum_k xT[k][c] * attn[l][k],  out[c][mpi[l]] = D[c][l].
-// A[i=c][kk=k] = xT[k][c] is patch-major = MFMA operand order (plain LDS copy); B[kk=k][j=l] = attn[l][k]
-// is k-contiguous, so its LDS image is [l][k] with a padded row (33) for conflict-free column reads.
-constexpr int RM_BC = 64, RM_BL = 64, RM_BK = 32;
+// Compressed attention.
+//
+// Row l of the reference's `in_attention` [M,N] (IPSRFunction.py:76,123-125) is non-zero only in the columns
+// kq_0..kq_l it has touched, so all M rows live in the M' <= M "active" columns D = sorted{kq_l}.  Everything
+// downstream works on the compressed matrix Ac[l][j] = a_l[D_j] (zero terms of the dense sums are exact no-ops):
+//   attn_prepare_kernel     per sample: active-column list D (ascending k), rank of every column, jq_l = rank(kq_l),
+//                           and the one-hot column counts of trunc(kbar) (non-masked q with ind[q] == k)
+//   attn_compress_kernel    thread per active column j replays the scalar recurrence  a = a*wn_l (+ wo_l if jq_l == j)
+//                           from LDS, writes Ac coalesced over j and counts the entries with |a| >= 1 that survive the
+//                           reference's LongTensor truncation (:36,134)
+//   index_scan_kernel       exclusive scan of the per-column entry counts -> col_off
+//   csr_fill_kernel         block 0: one wave ranks the non-masked q by (ind[q], q) with ballot-based matching and
+//                           writes the one-hot entries in ascending q; other blocks: the survivors, ascending l
+//   attn_expand_kernel      only when the caller asks for the dense [M,N] rows (tests / inspection)
+//   recon_masked_kernel     out[:,q_l] = sum_j Ac[l][j] * P[D_j,:]  on fp32 MFMA, j ascending == k ascending
 
-__global__ void __launch_bounds__(256) recon_masked_kernel(const float* __restrict__ xT, const float* __restrict__ attn,
-                                                           const int32_t* __restrict__ mpi, int C, int Cp, int N, int M,
-                                                           float* __restrict__ out)
+__global__ void __launch_bounds__(1024) attn_prepare_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
+                                                            const int32_t* __restrict__ kq, int N, int M, int Mc,
+                                                            int32_t* __restrict__ dlist, int32_t* __restrict__ mprime,
+                                                            int32_t* __restrict__ jq, int32_t* __restrict__ rankflag,
+                                                            int32_t* __restrict__ onehot_cnt, int32_t* __restrict__ col_cnt)
 {
-    __shared__ __attribute__((aligned(16))) float As[2][RM_BK][RM_BC];
-    __shared__ float Bs[2][RM_BL][RM_BK + 1];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-    const int l0 = blockIdx.x * RM_BL, c0 = blockIdx.y * RM_BC, b = blockIdx.z;
-    const float* xTb = xT + (size_t)b * N * Cp;
-    const float* ab = attn + (size_t)b * M * N;
-    const bool vec_ok = (N % 4 == 0);
-
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-
-    float4 ra[2], rb[2];
-    auto gload = [&](int s) {
-        const int k0 = s * RM_BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            {   // A: 32 rows (k) x 16 float4 (c)
-                const int kk = idx >> 4, c4 = (idx & 15) * 4;
-                const int k = k0 + kk, c = c0 + c4;
-                if (k < N && c + 4 <= Cp) ra[i] = *reinterpret_cast<const float4*>(xTb + (size_t)k * Cp + c);
-                else ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            {   // B: 64 rows (l) x 8 float4 (k)
-                const int j = idx >> 3, k4 = (idx & 7) * 4;
-                const int l = l0 + j, k = k0 + k4;
-                if (l < M && vec_ok && k + 4 <= N) rb[i] = *reinterpret_cast<const float4*>(ab + (size_t)l * N + k);
-                else {
-                    float t[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = (l < M && k + e < N) ? ab[(size_t)l * N + k + e] : 0.0f;
-                    rb[i] = make_float4(t[0], t[1], t[2], t[3]);
-                }
-            }
-        }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            *reinterpret_cast<float4*>(&As[buf][idx >> 4][(idx & 15) * 4]) = ra[i];
-            const int j = idx >> 3, k4 = (idx & 7) * 4;
-            Bs[buf][j][k4 + 0] = rb[i].x; Bs[buf][j][k4 + 1] = rb[i].y;
-            Bs[buf][j][k4 + 2] = rb[i].z; Bs[buf][j][k4 + 3] = rb[i].w;
-        }
-    };
-
-    const int nstage = (N + RM_BK - 1) / RM_BK;
-    gload(0);
-    sstore(0);
+    extern __shared__ __attribute__((aligned(16))) int lds[];
+    int* flag = lds;            // [N] 1 = active column
+    int* cnt = lds + N;         // [N] one-hot count
+    int* ismask = lds + 2 * N;  // [N]
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    const int32_t* indb = ind + (size_t)b * N;
+    const int32_t* kqb = kq + (size_t)b * M;
+    for (int k = tid; k < N; k += 1024) { flag[k] = 0; cnt[k] = 0; ismask[k] = 0; }
     __syncthreads();
-    for (int s = 0; s < nstage; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < nstage) gload(s + 1);
+    for (int l = tid; l < M; l += 1024) { flag[kqb[l]] = 1; ismask[mpi[l]] = 1; }
+    __syncthreads();
+    for (int q = tid; q < N; q += 1024)
+        if (!ismask[q]) atomicAdd(&cnt[indb[q]], 1);
+    // ordered compaction of the active columns: thread t owns k in [t*KPT, (t+1)*KPT)
+    const int KPT = (N + 1023) / 1024;
+    const int k_lo = tid * KPT, k_hi = min(N, k_lo + KPT);
+    int total = 0;
+    for (int k = k_lo; k < k_hi; ++k) total += flag[k];
+    int incl = total;
 #pragma unroll
-        for (int kk = 0; kk < RM_BK / 2; ++kk) {
-            const float a = As[cur][kk * 2 + h][wm * 32 + r];
-            const float bb = Bs[cur][wn * 32 + r][kk * 2 + h];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
-        }
-        if (s + 1 < nstage) sstore(cur ^ 1);
-        __syncthreads();
+    for (int s = 1; s < 64; s <<= 1) {
+        const int t = __shfl_up(incl, s);
+        if (lane >= s) incl += t;
     }
-
-    const int l = l0 + wn * 32 + r;
-    if (l < M) {
-        const int q = mpi[l];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int c = c0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (c < C) out[((size_t)b * C + c) * N + q] = acc[e];
-        }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int rank = incl - total;
+    for (int j = 0; j < wv; ++j) rank += wave_tot[j];
+    for (int k = k_lo; k < k_hi; ++k) {
+        const int f = flag[k];
+        rankflag[(size_t)b * N + k] = f ? rank : -1;
+        if (f) { dlist[(size_t)b * Mc + rank] = k; flag[k] = rank + 1; }     // flag now holds rank+1 for the jq lookup
+        rank += f;
+        const int c = cnt[k];
+        onehot_cnt[(size_t)b * N + k] = c;
+        col_cnt[(size_t)b * N + k] = c;
     }
+    if (tid == 1023) mprime[b] = rank;
+    __syncthreads();
+    int mp = 0;
+    for (int j = 0; j < 16; ++j) mp += wave_tot[j];
+    for (int j = mp + tid; j < Mc; j += 1024) dlist[(size_t)b * Mc + j] = 0;     // padding rows of the GEMM: any valid patch
+    for (int l = tid; l < M; l += 1024) jq[(size_t)b * M + l] = flag[kqb[l]] - 1;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Attention rows + the sparse form of trunc(kbar).
-//
-// a_l[k] (the reference's `in_attention`, IPSRFunction.py:100,123-125) is a scalar recurrence per column k,
-// independent across k:  a = a*wn_l;  if (kq_l == k) a += wo_l.  One thread owns one column and replays the
-// M steps from an LDS copy of (wn, wo, kq) — M LDS broadcasts, no global latency in the loop.
-//
-// trunc(kbar) per sample (int32 words; layout shared with the oracle):
-//   col_off[N+1] | ent_q[cap] | ent_w[cap] (fp32 bits),   cap = (N-M) + M(M+1)/2
-// Column k = the non-masked q with ind[q] == k (weight 1, ascending q: found by scanning an LDS copy of the
-// keys ind[q], -1 for masked q) followed by the masked rows with |a_l[k]| >= 1 (weight trunc(a_l[k]),
-// ascending l: found while replaying the recurrence).  Three launches:
-//   column_count_kernel  per column: #one-hot + #survivors
-//   index_scan_kernel    exclusive scan over k -> col_off
-//   column_fill_kernel   writes the attention rows [M,N] (coalesced over k) and the CSR entries in order
-constexpr int IX_COLS = 128;
+constexpr int AC_COLS = 128;
 
-struct ColumnLds {
-    int* key;        // [Npad]
-    float4* step;    // [M]  {wn, wo, kq bits, 0}
-};
-
-__device__ __forceinline__ ColumnLds load_column_lds(int* lds, const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
-                                                     const float* __restrict__ wn, const float* __restrict__ wo,
-                                                     const int32_t* __restrict__ kq, int N, int Npad, int M)
+// (wn, wo, jq) of all steps into LDS as float4, 2 independent loads per thread per batch
+__device__ __forceinline__ float4* load_steps_lds(int* lds, const float* __restrict__ wn, const float* __restrict__ wo,
+                                                  const int32_t* __restrict__ jq, int M)
 {
-    ColumnLds L;
-    L.step = reinterpret_cast<float4*>(lds);
-    L.key = lds + 4 * M;
-    // batches of 4 independent global loads per thread (a plain strided loop would serialise the round trips)
-    for (int q0 = 0; q0 < Npad; q0 += 4 * IX_COLS) {
-        int v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int q = q0 + j * IX_COLS + threadIdx.x; v[j] = q < N ? ind[q] : -1; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int q = q0 + j * IX_COLS + threadIdx.x; if (q < Npad) L.key[q] = v[j]; }
-    }
-    for (int l0 = 0; l0 < M; l0 += 2 * IX_COLS) {
+    float4* step = reinterpret_cast<float4*>(lds);
+    for (int l0 = 0; l0 < M; l0 += 2 * AC_COLS) {
         float4 v[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int l = l0 + j * IX_COLS + threadIdx.x;
-            v[j] = l < M ? make_float4(wn[l], wo[l], __int_as_float(kq[l]), 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int l = l0 + j * AC_COLS + threadIdx.x;
+            v[j] = l < M ? make_float4(wn[l], wo[l], __int_as_float(jq[l]), 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const int l = l0 + j * IX_COLS + threadIdx.x; if (l < M) L.step[l] = v[j]; }
+        for (int j = 0; j < 2; ++j) { const int l = l0 + j * AC_COLS + threadIdx.x; if (l < M) step[l] = v[j]; }
     }
     __syncthreads();
-    for (int l0 = 0; l0 < M; l0 += 4 * IX_COLS) {
-        int v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int l = l0 + j * IX_COLS + threadIdx.x; v[j] = l < M ? mpi[l] : -1; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (v[j] >= 0) L.key[v[j]] = -1;
-    }
-    __syncthreads();
-    return L;
+    return step;
 }
 
-__global__ void __launch_bounds__(IX_COLS) column_count_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
-                                                               const float* __restrict__ wn, const float* __restrict__ wo,
-                                                               const int32_t* __restrict__ kq, int N, int M,
-                                                               int32_t* __restrict__ col_cnt)
+__global__ void __launch_bounds__(AC_COLS) attn_compress_kernel(const float* __restrict__ wn, const float* __restrict__ wo,
+                                                                const int32_t* __restrict__ jq, const int32_t* __restrict__ dlist,
+                                                                const int32_t* __restrict__ mprime, int N, int M, int Mc,
+                                                                float* __restrict__ ac, int32_t* __restrict__ surv_cnt,
+                                                                int32_t* __restrict__ col_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) int lds[];
-    const int b = blockIdx.y, Npad = (N + 3) & ~3;
-    const ColumnLds L = load_column_lds(lds, ind + (size_t)b * N, mpi, wn + (size_t)b * M, wo + (size_t)b * M, kq + (size_t)b * M, N, Npad, M);
-    const int k = blockIdx.x * IX_COLS + threadIdx.x;
-    if (k >= N) return;
+    const int b = blockIdx.y;
+    const float4* step = load_steps_lds(lds, wn + (size_t)b * M, wo + (size_t)b * M, jq + (size_t)b * M, M);
+    const int j = blockIdx.x * AC_COLS + threadIdx.x;
+    if (j >= Mc) return;
+    float* acb = ac + (size_t)b * M * Mc;
+    float a = 0.0f;
     int cnt = 0;
 #pragma unroll 8
-    for (int q = 0; q < Npad; q += 4) {
-        const int4 v = *reinterpret_cast<const int4*>(&L.key[q]);
-        cnt += (v.x == k) + (v.y == k) + (v.z == k) + (v.w == k);
-    }
-    float a = 0.0f;
-#pragma unroll 8
     for (int l = 0; l < M; ++l) {
-        const float4 s = L.step[l];
-        a = a * s.x;
-        a = (__float_as_int(s.z) == k) ? a + s.y : a;
+        const float4 s = step[l];
+        a = a * s.x;                                            // (:123)
+        a = (__float_as_int(s.z) == j) ? a + s.y : a;           // (:124)
+        acb[(size_t)l * Mc + j] = a;                            // (:125) compressed row l
         cnt += (truncf(a) != 0.0f) ? 1 : 0;
     }
-    col_cnt[(size_t)b * N + k] = cnt;
+    if (j < mprime[b]) {
+        surv_cnt[(size_t)b * Mc + j] = cnt;
+        if (cnt) col_cnt[(size_t)b * N + dlist[(size_t)b * Mc + j]] += cnt;     // single writer per column
+    }
 }
 
 // exclusive scan of col_cnt over k -> col_off[0..N]; one workgroup per sample
@@ -450,46 +394,164 @@ __global__ void __launch_bounds__(1024) index_scan_kernel(const int32_t* __restr
     if (tid == 1023) col_off[N] = off;
 }
 
-template <bool WITH_INDEX>
-__global__ void __launch_bounds__(IX_COLS) column_fill_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
-                                                              const float* __restrict__ wn, const float* __restrict__ wo,
-                                                              const int32_t* __restrict__ kq, int N, int M,
-                                                              float* __restrict__ attn, int32_t* __restrict__ bwd_index,
-                                                              size_t ints_per_sample, size_t cap)
+__global__ void __launch_bounds__(AC_COLS) csr_fill_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
+                                                           const float* __restrict__ wn, const float* __restrict__ wo,
+                                                           const int32_t* __restrict__ jq, const int32_t* __restrict__ dlist,
+                                                           const int32_t* __restrict__ mprime, const int32_t* __restrict__ onehot_cnt,
+                                                           const int32_t* __restrict__ surv_cnt, int N, int M, int Mc, int nbits,
+                                                           int32_t* __restrict__ bwd_index, size_t ints_per_sample, size_t cap)
 {
     extern __shared__ __attribute__((aligned(16))) int lds[];
-    const int b = blockIdx.y, Npad = (N + 3) & ~3;
-    const ColumnLds L = load_column_lds(lds, ind + (size_t)b * N, mpi, wn + (size_t)b * M, wo + (size_t)b * M, kq + (size_t)b * M, N, Npad, M);
-    const int k = blockIdx.x * IX_COLS + threadIdx.x;
-    if (k >= N) return;
-    int32_t* ent_q = nullptr;
-    float* ent_w = nullptr;
-    int e = 0;
-    if (WITH_INDEX) {
-        int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
-        ent_q = col_off + N + 1;
-        ent_w = reinterpret_cast<float*>(ent_q + cap);
-        e = col_off[k];
-#pragma unroll 8
-        for (int q = 0; q < Npad; q += 4) {
-            const int4 v = *reinterpret_cast<const int4*>(&L.key[q]);
-            if (v.x == k) { ent_q[e] = q;     ent_w[e] = 1.0f; ++e; }
-            if (v.y == k) { ent_q[e] = q + 1; ent_w[e] = 1.0f; ++e; }
-            if (v.z == k) { ent_q[e] = q + 2; ent_w[e] = 1.0f; ++e; }
-            if (v.w == k) { ent_q[e] = q + 3; ent_w[e] = 1.0f; ++e; }
+    const int b = blockIdx.y;
+    int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
+    int32_t* ent_q = col_off + N + 1;
+    float* ent_w = reinterpret_cast<float*>(ent_q + cap);
+
+    if (blockIdx.x == 0) {
+        // ---- one-hot rows: non-masked q, grouped by k = ind[q], ascending q inside a group.  One wave walks the
+        // positions 64 at a time; lanes with equal keys find each other with one ballot per key bit.
+        int* cursor = lds;           // [N] entries already written per column
+        int* ismask = lds + N;       // [N]
+        for (int k = threadIdx.x; k < N; k += AC_COLS) { cursor[k] = 0; ismask[k] = 0; }
+        __syncthreads();
+        for (int l = threadIdx.x; l < M; l += AC_COLS) ismask[mpi[l]] = 1;
+        __syncthreads();
+        if (threadIdx.x >= 64) return;
+        const int lane = threadIdx.x;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int32_t* indb = ind + (size_t)b * N;
+        for (int q0 = 0; q0 < N; q0 += 64) {
+            const int q = q0 + lane;
+            const bool valid = q < N && !ismask[q];
+            const int key = valid ? indb[q] : 0;
+            unsigned long long m = __ballot(valid);
+            for (int bit = 0; bit < nbits; ++bit) {
+                const bool one = (key >> bit) & 1;
+                const unsigned long long bal = __ballot(valid && one);
+                m &= one ? bal : ~bal;
+            }
+            if (valid) {
+                const int base = cursor[key];
+                const int rank = __popcll(m & lt);
+                const int e = col_off[key] + base + rank;
+                ent_q[e] = q;
+                ent_w[e] = 1.0f;
+                if (rank == 0) cursor[key] = base + __popcll(m);     // one leader per key; reads above precede this write
+            }
         }
+        return;
     }
-    float* ab = attn + (size_t)b * M * N;
+    // ---- masked rows that survive the truncation: thread per active column replays the recurrence
+    const float4* step = load_steps_lds(lds, wn + (size_t)b * M, wo + (size_t)b * M, jq + (size_t)b * M, M);
+    const int j = (blockIdx.x - 1) * AC_COLS + threadIdx.x;
+    if (j >= mprime[b] || surv_cnt[(size_t)b * Mc + j] == 0) return;
+    const int k = dlist[(size_t)b * Mc + j];
+    int e = col_off[k] + onehot_cnt[(size_t)b * N + k];
     float a = 0.0f;
-#pragma unroll 8
     for (int l = 0; l < M; ++l) {
-        const float4 s = L.step[l];
-        a = a * s.x;                                            // (:123)
-        a = (__float_as_int(s.z) == k) ? a + s.y : a;           // (:124)
-        ab[(size_t)l * N + k] = a;                              // (:125) row l of in_attention
-        if (WITH_INDEX) {
-            const float t = truncf(a);
-            if (t != 0.0f) { ent_q[e] = mpi[l]; ent_w[e] = t; ++e; }
+        const float4 s = step[l];
+        a = a * s.x;
+        a = (__float_as_int(s.z) == j) ? a + s.y : a;
+        const float t = truncf(a);
+        if (t != 0.0f) { ent_q[e] = mpi[l]; ent_w[e] = t; ++e; }
+    }
+}
+
+// dense rows of `in_attention` (optional output): attn[l][k] = active(k) ? Ac[l][rank(k)] : 0
+__global__ void __launch_bounds__(256) attn_expand_kernel(const float* __restrict__ ac, const int32_t* __restrict__ rankflag,
+                                                          int N, int M, int Mc, float* __restrict__ attn)
+{
+    const int b = blockIdx.z, l = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    const int r = rankflag[(size_t)b * N + k];
+    attn[((size_t)b * M + l) * N + k] = r >= 0 ? ac[((size_t)b * M + l) * Mc + r] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// masked columns on the matrix cores:  Dm[c][l] = sum_j xT[D_j][c] * Ac[l][j],  out[c][mpi[l]] = Dm[c][l].
+// A[i=c][kk=j] = xT[D_j][c]: patch-major rows = MFMA operand order (plain LDS copy, rows picked through D);
+// B[kk=j][jn=l] = Ac[l][j] is j-contiguous, so its LDS image is [l][j] with a padded row (33) for conflict-free
+// column reads.  The K loop runs over the M' active columns only (vs N for the reference's dense GEMM).
+constexpr int RM_BC = 64, RM_BL = 64, RM_BK = 32;
+
+__global__ void __launch_bounds__(256) recon_masked_kernel(const float* __restrict__ xT, const float* __restrict__ ac,
+                                                           const int32_t* __restrict__ dlist, const int32_t* __restrict__ mprime,
+                                                           const int32_t* __restrict__ mpi, int C, int Cp, int N, int M, int Mc,
+                                                           float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][RM_BK][RM_BC];
+    __shared__ float Bs[2][RM_BL][RM_BK + 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int l0 = blockIdx.x * RM_BL, c0 = blockIdx.y * RM_BC, b = blockIdx.z;
+    const float* xTb = xT + (size_t)b * N * Cp;
+    const float* acb = ac + (size_t)b * M * Mc;
+    const int32_t* db = dlist + (size_t)b * Mc;
+    const int mp = mprime[b];
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+
+    float4 ra[2], rb[2];
+    auto gload = [&](int s) {
+        const int j0 = s * RM_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            {   // A: 32 rows (j) x 16 float4 (c); dlist is padded to Mc with valid rows, Ac is zero there
+                const int kk = idx >> 4, c4 = (idx & 15) * 4;
+                const int j = j0 + kk, c = c0 + c4;
+                if (j < Mc && c + 4 <= Cp) ra[i] = *reinterpret_cast<const float4*>(xTb + (size_t)db[j] * Cp + c);
+                else ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            {   // B: 64 rows (l) x 8 float4 (j)   (Mc % 4 == 0)
+                const int jl = idx >> 3, k4 = (idx & 7) * 4;
+                const int l = l0 + jl, j = j0 + k4;
+                if (l < M && j + 4 <= Mc) rb[i] = *reinterpret_cast<const float4*>(acb + (size_t)l * Mc + j);
+                else rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<float4*>(&As[buf][idx >> 4][(idx & 15) * 4]) = ra[i];
+            const int jl = idx >> 3, k4 = (idx & 7) * 4;
+            Bs[buf][jl][k4 + 0] = rb[i].x; Bs[buf][jl][k4 + 1] = rb[i].y;
+            Bs[buf][jl][k4 + 2] = rb[i].z; Bs[buf][jl][k4 + 3] = rb[i].w;
+        }
+    };
+
+    const int nstage = (mp + RM_BK - 1) / RM_BK;
+    if (nstage > 0) {
+        gload(0);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nstage) gload(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < RM_BK / 2; ++kk) {
+            const float a = As[cur][kk * 2 + h][wm * 32 + r];
+            const float bb = Bs[cur][wn * 32 + r][kk * 2 + h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+        }
+        if (s + 1 < nstage) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    const int l = l0 + wn * 32 + r;
+    if (l < M) {
+        const int q = mpi[l];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = c0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (c < C) out[((size_t)b * C + c) * N + q] = acc[e];
         }
     }
 }
@@ -497,7 +559,7 @@ __global__ void __launch_bounds__(IX_COLS) column_fill_kernel(const int32_t* __r
 // ---------------------------------------------------------------------------------------------------
 int launch_attention(const AttnArgs& a, hipStream_t st)
 {
-    const int B = a.B, C = a.C, Cp = a.Cp, N = a.N, M = a.M;
+    const int B = a.B, C = a.C, Cp = a.Cp, N = a.N, M = a.M, Mc = a.Mc;
     const size_t cap = (size_t)(N - M) + (size_t)M * (M + 1) / 2;
     const size_t ints = (size_t)N + 1 + 2 * cap;
     if (M > 0) {
@@ -527,32 +589,45 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
 #undef LAUNCH_REC2
         if (int rc = check_launch("recurrence_kernel")) return rc;
     }
-    {
-        const size_t lds = ((size_t)((N + 3) & ~3) + 4 * (size_t)M) * sizeof(int);
-        if (lds > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: N=%d, M=%d too large for the column kernels' LDS", N, M);
-        if (lds > 48 * 1024) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&column_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&column_fill_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&column_fill_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        }
-        const dim3 grid(cdiv(N, IX_COLS), B);
-        if (a.bwd_index) {
-            column_count_kernel<<<grid, IX_COLS, lds, st>>>(a.ind, a.mpi, a.wn, a.wo, a.kq, N, M, a.col_cnt);
-            if (int rc = check_launch("column_count_kernel")) return rc;
-            index_scan_kernel<<<B, 1024, 0, st>>>(a.col_cnt, N, a.bwd_index, ints);
-            if (int rc = check_launch("index_scan_kernel")) return rc;
-            column_fill_kernel<true><<<grid, IX_COLS, lds, st>>>(a.ind, a.mpi, a.wn, a.wo, a.kq, N, M, a.attn, a.bwd_index, ints, cap);
-            if (int rc = check_launch("column_fill_kernel")) return rc;
-        } else if (M > 0) {
-            column_fill_kernel<false><<<grid, IX_COLS, lds, st>>>(a.ind, a.mpi, a.wn, a.wo, a.kq, N, M, a.attn, nullptr, ints, cap);
-            if (int rc = check_launch("column_fill_kernel")) return rc;
-        }
-    }
+    // non-masked columns first (masked ones are overwritten below)
     recon_gather_kernel<<<dim3(cdiv(N, 32), cdiv(C, 32), B), 256, 0, st>>>(a.xT, a.ind, C, Cp, N, a.out);
     if (int rc = check_launch("recon_gather_kernel")) return rc;
+
+    const bool need_index = a.bwd_index != nullptr;
+    if (M > 0 || need_index) {
+        const size_t lds_prep = (size_t)3 * N * sizeof(int);
+        if (lds_prep > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: N=%d too large for attn_prepare_kernel", N);
+        if (lds_prep > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
+        attn_prepare_kernel<<<B, 1024, lds_prep, st>>>(a.ind, a.mpi, a.kq, N, M, Mc, a.dlist, a.mprime, a.jq, a.rankflag, a.onehot_cnt, a.col_cnt);
+        if (int rc = check_launch("attn_prepare_kernel")) return rc;
+    }
+    const size_t lds_steps = (size_t)4 * (M > 0 ? M : 1) * sizeof(int);
     if (M > 0) {
-        recon_masked_kernel<<<dim3(cdiv(M, RM_BL), cdiv(C, RM_BC), B), 256, 0, st>>>(a.xT, a.attn, a.mpi, C, Cp, N, M, a.out);
+        if (lds_steps > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: M=%d too large for attn_compress_kernel", M);
+        if (lds_steps > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_compress_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_steps);
+        attn_compress_kernel<<<dim3(cdiv(Mc, AC_COLS), B), AC_COLS, lds_steps, st>>>(a.wn, a.wo, a.jq, a.dlist, a.mprime, N, M, Mc, a.ac, a.surv_cnt, a.col_cnt);
+        if (int rc = check_launch("attn_compress_kernel")) return rc;
+        recon_masked_kernel<<<dim3(cdiv(M, RM_BL), cdiv(C, RM_BC), B), 256, 0, st>>>(a.xT, a.ac, a.dlist, a.mprime, a.mpi, C, Cp, N, M, Mc, a.out);
         if (int rc = check_launch("recon_masked_kernel")) return rc;
+        if (a.attn) {
+            attn_expand_kernel<<<dim3(cdiv(N, 256), M, B), 256, 0, st>>>(a.ac, a.rankflag, N, M, Mc, a.attn);
+            if (int rc = check_launch("attn_expand_kernel")) return rc;
+        }
+    }
+    if (need_index) {
+        index_scan_kernel<<<B, 1024, 0, st>>>(a.col_cnt, N, a.bwd_index, ints);
+        if (int rc = check_launch("index_scan_kernel")) return rc;
+        const size_t lds_fill = (size_t)(2 * N > 4 * M ? 2 * N : 4 * M) * sizeof(int);
+        if (lds_fill > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: N=%d too large for csr_fill_kernel", N);
+        if (lds_fill > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill);
+        int nbits = 1;
+        while ((1 << nbits) < N) ++nbits;
+        csr_fill_kernel<<<dim3(1 + (M > 0 ? cdiv(Mc, AC_COLS) : 0), B), AC_COLS, lds_fill, st>>>(
+            a.ind, a.mpi, a.wn, a.wo, a.jq, a.dlist, a.mprime, a.onehot_cnt, a.surv_cnt, N, M, Mc, nbits, a.bwd_index, ints, cap);
+        if (int rc = check_launch("csr_fill_kernel")) return rc;
     }
     return IPSR_OK;
 }

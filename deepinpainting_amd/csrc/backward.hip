@@ -7,47 +7,63 @@
 // scatter-add; written as a GATHER over the CSR built by bwd_index_kernel it needs no atomics and is
 // deterministic:   acc = sum_{q in col(k), ascending} g[c][q]  (+ the few surviving masked rows).
 //
-// HBM-bound: reads g once, writes grad_in once (2*C*N*4 bytes per sample); the gathered g[c][q] are
-// re-reads of the 4 KB row the workgroup is streaming anyway (L1/L2 hits).
+// HBM-bound: reads g once, writes grad_in once (2*C*N*4 bytes per sample); the gathered g[c][q] come from the
+// LDS copy of the rows the workgroup owns.
 #include "ipsr_common.h"
 
 namespace ipsr {
 
-constexpr int BW_KT = 256;   // k columns per workgroup (one per thread)
-constexpr int BW_CT = 16;    // channel rows per workgroup (accumulators in registers)
+constexpr int BW_THREADS = 256;
+constexpr int BW_ROWS = 16;               // channel rows per workgroup (LDS-resident), fewer when N is large
+constexpr int BW_LDS_BYTES = 64 * 1024;
 
-__global__ void __launch_bounds__(BW_KT) ipsr_backward_kernel(const float* __restrict__ g, const int32_t* __restrict__ bwd_index,
-                                                              size_t ints_per_sample, size_t cap, float triple_w, int C, int N,
-                                                              float* __restrict__ gin)
+// One workgroup = R channel rows of one sample.  The rows (R x N fp32) are staged once into LDS with coalesced
+// 16-byte loads — that is the ONLY read of grad_out from HBM/L2 — and every gathered g[c][q] of the scatter-add
+// then comes from LDS.  Threads walk the patch index k; the CSR column of k is read once and applied to all R
+// rows, so the output is written with coalesced stores.  HBM traffic = the algorithmic 2*C*N*4 bytes (+ index).
+template <int R>
+__global__ void __launch_bounds__(BW_THREADS) ipsr_backward_kernel(const float* __restrict__ g, const int32_t* __restrict__ bwd_index,
+                                                                   size_t ints_per_sample, size_t cap, float triple_w, int C, int N,
+                                                                   float* __restrict__ gin)
 {
-    const int k = blockIdx.x * BW_KT + threadIdx.x;
-    const int c0 = blockIdx.y * BW_CT, b = blockIdx.z;
-    if (k >= N) return;
+    extern __shared__ __attribute__((aligned(16))) float rows[];      // [R][N]
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * R, b = blockIdx.y;
+    const int nrow = min(R, C - c0);
+    const float* gb = g + ((size_t)b * C + c0) * N;
+    float* ob = gin + ((size_t)b * C + c0) * N;
+    const size_t total = (size_t)nrow * N;
+    if ((N & 3) == 0) {
+        for (size_t i = (size_t)tid * 4; i < total; i += BW_THREADS * 4)
+            *reinterpret_cast<float4*>(&rows[i]) = *reinterpret_cast<const float4*>(gb + i);
+    } else {
+        for (size_t i = tid; i < total; i += BW_THREADS) rows[i] = gb[i];
+    }
+    __syncthreads();
+
     const int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
     const int32_t* ent_q = col_off + N + 1;
     const float* ent_w = reinterpret_cast<const float*>(ent_q + cap);
-    const int e0 = col_off[k], e1 = col_off[k + 1];
-    const int c_hi = min(C, c0 + BW_CT);
-    const float* gb = g + ((size_t)b * C + c0) * N;
-    float acc[BW_CT];
+    for (int k = tid; k < N; k += BW_THREADS) {
+        const int e0 = col_off[k], e1 = col_off[k + 1];
+        float acc[R];
 #pragma unroll
-    for (int i = 0; i < BW_CT; ++i) acc[i] = 0.0f;
-    // column k of trunc(kbar)^T: one-hot rows first (weight 1, ascending q), then the masked rows that survive
-    // the truncation (ascending l) — one fmaf chain per output, the same order as the oracle
-#pragma unroll 4
-    for (int e = e0; e < e1; ++e) {
-        const int q = ent_q[e];
-        const float wgt = ent_w[e];
+        for (int i = 0; i < R; ++i) acc[i] = 0.0f;
+        // column k of trunc(kbar)^T: one-hot rows first (weight 1, ascending q), then the masked rows that survive
+        // the truncation (ascending l) — one fmaf chain per output, the same order as the oracle
+        for (int e = e0; e < e1; ++e) {
+            const int q = ent_q[e];
+            const float wgt = ent_w[e];
 #pragma unroll
-        for (int i = 0; i < BW_CT; ++i)
-            if (c0 + i < c_hi) acc[i] = __builtin_fmaf(wgt, gb[(size_t)i * N + q], acc[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < BW_CT; ++i)
-        if (c0 + i < c_hi) {
-            const float t = acc[i] * triple_w;                 // (:173) mul then add, separately rounded
-            gin[((size_t)b * C + c0 + i) * N + k] = gb[(size_t)i * N + k] + t;
+            for (int i = 0; i < R; ++i) acc[i] = __builtin_fmaf(wgt, rows[(size_t)i * N + q], acc[i]);   // rows past nrow: stale LDS, never stored
         }
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            if (i < nrow) {
+                const float t = acc[i] * triple_w;             // (:173) mul then add, separately rounded
+                ob[(size_t)i * N + k] = rows[(size_t)i * N + k] + t;
+            }
+    }
 }
 
 int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn, const int32_t* bwd_index,
@@ -56,7 +72,25 @@ int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn
     (void)mpi; (void)attn;      // everything the backward needs is in bwd_index
     const size_t cap = (size_t)(N - M) + (size_t)M * (M + 1) / 2;
     const size_t ints = (size_t)N + 1 + 2 * cap;
-    ipsr_backward_kernel<<<dim3(cdiv(N, BW_KT), cdiv(C, BW_CT), B), BW_KT, 0, st>>>(g, bwd_index, ints, cap, triple_w, C, N, gin);
+    int R = BW_ROWS;
+    while (R > 1 && (size_t)R * N * sizeof(float) > BW_LDS_BYTES) R >>= 1;
+    const size_t lds = (size_t)R * N * sizeof(float);
+    if (lds > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_backward: N=%d too large for one LDS-resident row", N);
+#define LAUNCH_BW(RR)                                                                                              \
+    do {                                                                                                           \
+        if (lds > 48 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ipsr_backward_kernel<RR>),                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        ipsr_backward_kernel<RR><<<dim3(cdiv(C, RR), B), BW_THREADS, lds, st>>>(g, bwd_index, ints, cap, triple_w, C, N, gin); \
+    } while (0)
+    switch (R) {
+        case 16: LAUNCH_BW(16); break;
+        case 8: LAUNCH_BW(8); break;
+        case 4: LAUNCH_BW(4); break;
+        case 2: LAUNCH_BW(2); break;
+        default: LAUNCH_BW(1); break;
+    }
+#undef LAUNCH_BW
     return check_launch("ipsr_backward_kernel");
 }
 

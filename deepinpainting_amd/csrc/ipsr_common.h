@@ -67,14 +67,23 @@ struct AttnArgs {
     const int32_t* ind;    // [B,N]
     const float* vmax;     // [B,N]
     const int32_t* mpi;    // [M]
-    int B, C, Cp, N, M;
-    float* wn;             // [B,M] ws
-    float* wo;             // [B,M] ws
-    int32_t* kq;           // [B,M] ws: ind[mpi[l]]
-    int32_t* col_cnt;      // [B,N] ws: entries of trunc(kbar) per column k
-    float* attn;           // [B,M,N]
+    int B, C, Cp, N, M, Mc;   // Mc = roundup(M, 32): row stride of the compressed attention
+    // workspace
+    float* wn;             // [B,M]
+    float* wo;             // [B,M]
+    int32_t* kq;           // [B,M]   ind[mpi[l]]
+    int32_t* jq;           // [B,M]   rank of kq[l] among the active columns
+    int32_t* dlist;        // [B,Mc]  active columns, ascending k (padded with a valid patch index)
+    int32_t* mprime;       // [B]     number of active columns
+    int32_t* rankflag;     // [B,N]   rank of column k among the active ones, or -1
+    int32_t* onehot_cnt;   // [B,N]   non-masked q with ind[q] == k
+    int32_t* surv_cnt;     // [B,Mc]  truncation survivors per active column
+    int32_t* col_cnt;      // [B,N]   entries of trunc(kbar) per column k
+    float* ac;             // [B,M,Mc] compressed attention rows
+    // outputs
+    float* attn;           // [B,M,N] dense attention rows, optional (NULL = not materialised)
     float* out;            // [B,C,N]
-    int32_t* bwd_index;    // [B, ipsr_bwd_index_ints(N,M)]
+    int32_t* bwd_index;    // [B, ipsr_bwd_index_ints(N,M)], optional
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 

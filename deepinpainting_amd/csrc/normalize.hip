@@ -94,10 +94,77 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Register-resident variant for C <= 512 (segment length L <= 64): a thread keeps its (segment, column) slice
+// of x in registers between the norm and the scaling, so x is read from HBM exactly once and nothing goes
+// through LDS but the 8 partial sums.  The thread holds 64 CONSECUTIVE channels of ONE patch, which is also a
+// contiguous 256-byte piece of the patch-major row xT[k][seg*64 ...]: written with 16-byte stores straight from
+// registers (every 64-byte line is completed by the same lane's next stores while it sits in L2).
+constexpr int LMAX = 64;
+
+__global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_reg_kernel(const float* __restrict__ x, int C, int N, int Cp,
+                                                                          float* __restrict__ xn, float* __restrict__ xT,
+                                                                          float* __restrict__ inv)
+{
+    __shared__ float part[NSEG][NCOL];
+    __shared__ float inv_s[NCOL];
+    const int tid = threadIdx.x;
+    const int col = tid & (NCOL - 1), seg = tid / NCOL;
+    const int ntile = (N + NCOL - 1) / NCOL;
+    const int b = blockIdx.x / ntile, k0 = (blockIdx.x % ntile) * NCOL;
+    const int k = k0 + col;
+    const bool kin = k < N;
+    const float* xb = x + (size_t)b * C * N;
+    const int L = (C + NSEG - 1) / NSEG;           // <= LMAX
+    const int c_lo = seg * L;
+
+    float v[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) {
+        const int c = c_lo + i;
+        v[i] = (kin && i < L && c < C) ? xb[(size_t)c * N + k] : 0.0f;
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) acc = __builtin_fmaf(v[i], v[i], acc);     // trailing zeros leave the chain unchanged
+    part[seg][col] = acc;
+    __syncthreads();
+    if (seg == 0) {
+        float tot = part[0][col];
+#pragma unroll
+        for (int s = 1; s < NSEG; ++s) tot = tot + part[s][col];
+        const float iv = 1.0f / (sqrtf(tot) + 1e-8f);
+        inv_s[col] = iv;
+        if (kin) inv[(size_t)b * N + k] = iv;
+    }
+    __syncthreads();
+    if (!kin) return;
+    const float iv = inv_s[col];
+    float* xnb = xn + (size_t)b * C * N;
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) {
+        const int c = c_lo + i;
+        if (i < L && c < C) xnb[(size_t)c * N + k] = v[i] * iv;
+    }
+    if (xT) {
+        // requires L % 4 == 0 (checked by the launcher) so that every float4 is 16-byte aligned and inside [0,Cp)
+        float* row = xT + ((size_t)b * N + k) * Cp + c_lo;
+#pragma unroll
+        for (int i = 0; i < LMAX; i += 4)
+            if (i < L && c_lo + i < Cp) *reinterpret_cast<float4*>(row + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    }
+}
+
 int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float* xT, int Cp, float* inv,
                            hipStream_t st)
 {
     const int ntile = cdiv(N, NCOL);
+    const int L = cdiv(C, NSEG);
+    // register path: segment fits 64 registers; float4 rows of xT need L % 4 == 0 and 8*L >= Cp (all of the padded row written)
+    if (L <= LMAX && L % 4 == 0 && NSEG * L >= Cp) {
+        patch_normalize_reg_kernel<<<B * ntile, NCOL * NSEG, 0, st>>>(x, C, N, Cp, xn, xT, inv);
+        return check_launch("patch_normalize_reg_kernel");
+    }
     patch_normalize_kernel<<<B * ntile, NCOL * NSEG, 0, st>>>(x, C, N, Cp, xn, xT, inv);
     return check_launch("patch_normalize_kernel");
 }

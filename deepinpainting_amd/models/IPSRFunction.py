@@ -30,15 +30,15 @@ class IPSRFunction(torch.autograd.Function):
         if mpi32 is None or mpi32.device != input.device:
             mpi32 = mask_point_idx.to(device=input.device, dtype=torch.int32)
         # `ref` is the VGG namedtuple; only relu4_3 is read (reference :49)
-        f = ops.forward(input.detach(), ref.relu4_3.detach(), mpi32, int(shift_sz), int(stride))
-        ctx.mpi32 = mpi32
-        ctx.attn_rows = f.attn_rows        # the reference's `in_attention` rows [B,M,N]
-        ctx.bwd_index = f.bwd_index        # sparse trunc(kbar)  (reference ctx.ind_lst, :139)
+        need_grad = torch.is_grad_enabled() and input.requires_grad
+        f = ops.forward(input.detach(), ref.relu4_3.detach(), mpi32, int(shift_sz), int(stride), want_index=need_grad)
+        ctx.M = int(mpi32.numel())
+        ctx.bwd_index = f.bwd_index        # sparse trunc(kbar)  (the reference keeps the dense ctx.ind_lst, :139)
         ctx.ind = f.ind
         ctx.vmax = f.vmax
         return f.out
 
     @staticmethod
     def backward(ctx, grad_output):
-        grad_input = ops.backward(grad_output, ctx.mpi32, ctx.attn_rows, ctx.bwd_index, ctx.triple_w)
+        grad_input = ops.backward(grad_output, ctx.bwd_index, ctx.triple_w, ctx.M)
         return grad_input, None, None, None, None, None, None, None, None, None, None, None

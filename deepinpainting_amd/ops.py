@@ -99,8 +99,11 @@ def corr_argmax(xn_bcn, ref_bcn, want_S=False):
 Forward = namedtuple("Forward", ["out", "ind", "vmax", "attn_rows", "bwd_index"])
 
 
-def forward(x, ref, mask_point_idx_i32, patch=1, stride=1):
-    """Whole layer forward.  x, ref [B,C,h,w] fp32; mask_point_idx_i32 [M] i32 -> Forward."""
+def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want_index=True):
+    """Whole layer forward.  x, ref [B,C,h,w] fp32; mask_point_idx_i32 [M] i32 -> Forward.
+    want_attn:  also materialise the dense attention rows [B,M,N] (the reference's `in_attention`; tests and
+                inspection only — the layer itself works on the compressed form);
+    want_index: build the sparse trunc(kbar) the backward needs (skip under no_grad)."""
     x = _req(x, torch.float32, "input")
     ref = _req(ref, torch.float32, "ref.relu4_3")
     B, C, h, w = x.shape
@@ -114,25 +117,26 @@ def forward(x, ref, mask_point_idx_i32, patch=1, stride=1):
     out = torch.empty_like(x)
     ind = torch.empty((B, N), dtype=torch.int32, device=dev)
     vmax = torch.empty((B, N), dtype=torch.float32, device=dev)
-    attn = torch.empty((B, max(M, 1), N), dtype=torch.float32, device=dev)
-    bidx = torch.empty((B, L.ipsr_bwd_index_ints(N, M)), dtype=torch.int32, device=dev)
+    attn = torch.empty((B, M, N), dtype=torch.float32, device=dev) if (want_attn and M > 0) else None
+    bidx = torch.empty((B, L.ipsr_bwd_index_ints(N, M)), dtype=torch.int32, device=dev) if want_index else None
     nbytes = L.ipsr_forward_workspace_bytes(B, C, h, w, M, patch, stride)
     ws = _workspace(nbytes, dev)
     _lib.check(L.ipsr_forward(x.data_ptr(), ref.data_ptr(), mpi.data_ptr() if M else None, M, B, C, h, w,
-                              patch, stride, out.data_ptr(), ind.data_ptr(), vmax.data_ptr(), attn.data_ptr(),
-                              bidx.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ipsr_forward")
-    return Forward(out, ind, vmax, attn[:, :M], bidx)
+                              patch, stride, out.data_ptr(), ind.data_ptr(), vmax.data_ptr(),
+                              attn.data_ptr() if attn is not None else None,
+                              bidx.data_ptr() if bidx is not None else None, ws.data_ptr(), ws.numel(), _stream()),
+               "ipsr_forward")
+    if want_attn and attn is None:
+        attn = torch.empty((B, 0, N), dtype=torch.float32, device=dev)
+    return Forward(out, ind, vmax, attn, bidx)
 
 
-def backward(grad_out, mask_point_idx_i32, attn_rows, bwd_index, triple_w):
+def backward(grad_out, bwd_index, triple_w, M):
+    """grad_in = g + triple_w * trunc(kbar)^T-weighted g; needs only the sparse index built by forward."""
     g = _req(grad_out, torch.float32, "grad_output")
     B, C, h, w = g.shape
-    mpi = _req(mask_point_idx_i32, torch.int32, "mask_point_idx")
-    M = int(mpi.numel())
     gin = torch.empty_like(g)
-    attn = attn_rows if attn_rows.is_contiguous() else attn_rows.contiguous()
-    _lib.check(_lib.lib().ipsr_backward(g.data_ptr(), mpi.data_ptr() if M else None, M,
-                                        attn.data_ptr() if M else None, bwd_index.data_ptr(), float(triple_w),
+    _lib.check(_lib.lib().ipsr_backward(g.data_ptr(), None, int(M), None, bwd_index.data_ptr(), float(triple_w),
                                         B, C, h, w, gin.data_ptr(), _stream()), "ipsr_backward")
     return gin
 

@@ -158,8 +158,8 @@ def assert_index_equal(a, b, N, M):
 
 
 def run_hip_layer(ops, x, ref, mpi, triple_w, g):
-    f = ops.forward(dev(x), dev(ref), dev(mpi, torch.int32))
-    gin = ops.backward(dev(g), dev(mpi, torch.int32), f.attn_rows, f.bwd_index, triple_w)
+    f = ops.forward(dev(x), dev(ref), dev(mpi, torch.int32), want_attn=True)
+    gin = ops.backward(dev(g), f.bwd_index, triple_w, len(mpi))
     torch.cuda.synchronize()
     return f, gin
 
@@ -236,7 +236,7 @@ def test_layer_full_size_properties(ops):
     M = int(cnt.item())
     assert M == 256
     mpi = mpi_d[:M].contiguous()
-    f = ops.forward(dev(x), dev(ref), mpi)
+    f = ops.forward(dev(x), dev(ref), mpi, want_attn=True)
     out, ind, attn = f.out.cpu().numpy(), f.ind.cpu().numpy(), f.attn_rows.cpu().numpy()
     N = h * h
     xf = x.reshape(B, C, N)
@@ -257,8 +257,8 @@ def test_layer_full_size_properties(ops):
     np.testing.assert_array_equal(f1.out.cpu().numpy()[0], out[3])
     # 5. backward is linear in the upstream gradient, and sample 0 matches the oracle bit for bit
     g1 = rs.standard_normal(x.shape).astype(np.float32)
-    gi1 = ops.backward(dev(g1), mpi, f.attn_rows, f.bwd_index, 1.0).cpu().numpy()
-    gi2 = ops.backward(dev(2 * g1), mpi, f.attn_rows, f.bwd_index, 1.0).cpu().numpy()
+    gi1 = ops.backward(dev(g1), f.bwd_index, 1.0, M).cpu().numpy()
+    gi2 = ops.backward(dev(2 * g1), f.bwd_index, 1.0, M).cpu().numpy()
     np.testing.assert_array_equal(gi2, 2 * gi1)
     fo = orc.forward(x[:1], ref[:1], mp)
     np.testing.assert_array_equal(out[0], fo.out[0])
@@ -274,7 +274,7 @@ def test_layer_stress_size_cfg4_properties(ops):
     feat = np.zeros((h, h), np.uint8)
     feat[16:48, 16:48] = 1
     mp = orc.index_prep(feat).mask_point_idx
-    f = ops.forward(dev(x), dev(ref), dev(mp, torch.int32))
+    f = ops.forward(dev(x), dev(ref), dev(mp, torch.int32), want_attn=True)
     N = h * h
     out, ind, attn = f.out.cpu().numpy().reshape(C, N), f.ind.cpu().numpy()[0], f.attn_rows.cpu().numpy()[0]
     nonmask = np.setdiff1d(np.arange(N), mp)
