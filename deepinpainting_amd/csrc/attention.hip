@@ -22,6 +22,8 @@
 //     truncated toward zero.  What survives is stored as a CSR over the patch index k: the non-masked q
 //     with ind[q] == k (weight 1, ascending q) followed by the masked rows whose |a_l[k]| >= 1 (weight
 //     trunc(a_l[k]), ascending l).  That is all the backward needs.
+#include <cstdlib>
+
 #include "ipsr_common.h"
 
 namespace ipsr {
@@ -233,13 +235,21 @@ __global__ void __launch_bounds__(256) recon_gather_kernel(const float* __restri
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int q0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
     const float* xTb = xT + (size_t)b * N * Cp;
+    // two batches of independent loads (the 4 row indices, then the 4 row elements) instead of 4 dependent pairs
+    int row[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ql = ty + 8 * i, q = q0 + ql;
-        float v = 0.0f;
-        if (q < N && c0 + tx < Cp) v = xTb[(size_t)ind[(size_t)b * N + q] * Cp + c0 + tx];
-        tile[ql][tx] = v;
+        const int q = q0 + ty + 8 * i;
+        row[i] = q < N ? ind[(size_t)b * N + q] : 0;
     }
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = q0 + ty + 8 * i;
+        v[i] = (q < N && c0 + tx < Cp) ? xTb[(size_t)row[i] * Cp + c0 + tx] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = v[i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -409,34 +419,48 @@ __global__ void __launch_bounds__(AC_COLS) csr_fill_kernel(const int32_t* __rest
 
     if (blockIdx.x == 0) {
         // ---- one-hot rows: non-masked q, grouped by k = ind[q], ascending q inside a group.  One wave walks the
-        // positions 64 at a time; lanes with equal keys find each other with one ballot per key bit.
-        int* cursor = lds;           // [N] entries already written per column
-        int* ismask = lds + N;       // [N]
-        for (int k = threadIdx.x; k < N; k += AC_COLS) { cursor[k] = 0; ismask[k] = 0; }
+        // positions 64 at a time; lanes with equal keys find each other with one ballot per key bit.  Keys and the
+        // per-column write cursors (initialised to col_off) live in LDS, so the serial loop touches no global memory
+        // except the entry stores.
+        int* cursor = lds;           // [N] next entry slot of column k
+        int* key = lds + N;          // [N] ind[q], or -1 for masked q
+        const int32_t* indb = ind + (size_t)b * N;
+        for (int k0 = 0; k0 < N; k0 += 4 * AC_COLS) {
+            int c[4], v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j * AC_COLS + threadIdx.x;
+                c[j] = k < N ? col_off[k] : 0;
+                v[j] = k < N ? indb[k] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j * AC_COLS + threadIdx.x;
+                if (k < N) { cursor[k] = c[j]; key[k] = v[j]; }
+            }
+        }
         __syncthreads();
-        for (int l = threadIdx.x; l < M; l += AC_COLS) ismask[mpi[l]] = 1;
+        for (int l = threadIdx.x; l < M; l += AC_COLS) key[mpi[l]] = -1;
         __syncthreads();
         if (threadIdx.x >= 64) return;
         const int lane = threadIdx.x;
         const unsigned long long lt = (1ull << lane) - 1ull;
-        const int32_t* indb = ind + (size_t)b * N;
         for (int q0 = 0; q0 < N; q0 += 64) {
             const int q = q0 + lane;
-            const bool valid = q < N && !ismask[q];
-            const int key = valid ? indb[q] : 0;
+            const int kv = q < N ? key[q] : -1;
+            const bool valid = kv >= 0;
             unsigned long long m = __ballot(valid);
             for (int bit = 0; bit < nbits; ++bit) {
-                const bool one = (key >> bit) & 1;
+                const bool one = (kv >> bit) & 1;
                 const unsigned long long bal = __ballot(valid && one);
                 m &= one ? bal : ~bal;
             }
             if (valid) {
-                const int base = cursor[key];
+                const int base = cursor[kv];
                 const int rank = __popcll(m & lt);
-                const int e = col_off[key] + base + rank;
-                ent_q[e] = q;
-                ent_w[e] = 1.0f;
-                if (rank == 0) cursor[key] = base + __popcll(m);     // one leader per key; reads above precede this write
+                ent_q[base + rank] = q;
+                ent_w[base + rank] = 1.0f;
+                if (rank == 0) cursor[kv] = base + __popcll(m);      // one leader per key; the reads above precede this write
             }
         }
         return;
@@ -448,6 +472,7 @@ __global__ void __launch_bounds__(AC_COLS) csr_fill_kernel(const int32_t* __rest
     const int k = dlist[(size_t)b * Mc + j];
     int e = col_off[k] + onehot_cnt[(size_t)b * N + k];
     float a = 0.0f;
+#pragma unroll 8
     for (int l = 0; l < M; ++l) {
         const float4 s = step[l];
         a = a * s.x;
@@ -625,7 +650,8 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill);
         int nbits = 1;
         while ((1 << nbits) < N) ++nbits;
-        csr_fill_kernel<<<dim3(1 + (M > 0 ? cdiv(Mc, AC_COLS) : 0), B), AC_COLS, lds_fill, st>>>(
+        static const int dbg = getenv("IPSR_DEBUG_CSR") ? atoi(getenv("IPSR_DEBUG_CSR")) : 0;
+        csr_fill_kernel<<<dim3(dbg == 1 ? 1 : 1 + (M > 0 ? cdiv(Mc, AC_COLS) : 0), B), AC_COLS, lds_fill, st>>>(
             a.ind, a.mpi, a.wn, a.wo, a.jq, a.dlist, a.mprime, a.onehot_cnt, a.surv_cnt, N, M, Mc, nbits, a.bwd_index, ints, cap);
         if (int rc = check_launch("csr_fill_kernel")) return rc;
     }

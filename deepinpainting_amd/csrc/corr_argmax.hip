@@ -35,8 +35,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128;   // k rows (patches) per workgroup tile
 constexpr int BN = 128;   // q columns (reference positions) per workgroup tile
 constexpr int BK = 16;    // channels per LDS stage (generic kernel)
-constexpr int FBK = 32;   // channels per LDS stage (fast kernel: direct-to-LDS loads)
+constexpr int FBK = 16;   // channels per LDS stage (fast kernel: direct-to-LDS loads)
+constexpr int FNBUF = 4;  // LDS ring slots; the DMA of stage s+3 is issued while stage s computes
 constexpr int NTHREADS = 256;
+
+#ifdef IPSR_CLOCK_PROBE
+// Diagnostic build only (never shipped): per-workgroup shader-clock / 100 MHz real-time stamps around the K loop,
+// to read the clock the chip actually holds (MI355X_MICROARCH.md "DVFS give-back" item 6).
+__device__ unsigned long long g_probe[2 * 8192];
+#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -190,11 +197,23 @@ corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fast path (N % 128 == 0, C % 32 == 0, 16-byte aligned operands): same tiling and the same arithmetic, but
-//   * operand tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4: 64 lanes x 16 B = two 512-byte tile rows
-//     per wave-instruction, no staging VGPRs, no ds_write pass); the tile of stage s+1 is in flight while the
-//     64 MFMAs per wave of stage s run; FBK = 32 channels per stage halves the barriers;
-//   * the MFMA operand fragments of k-step kk+1 are read from LDS while the 4 MFMAs of kk execute.
+// Fast path (N % 128 == 0, C % 16 == 0, 16-byte aligned operands): same tile, same arithmetic (every S[k][q] is
+// still ONE fmaf chain over ascending channels), shaped by what was measured on gfx950 with this kernel
+// (IPSR_CLOCK_PROBE build, s_memtime around the K loop, clock 2.39 GHz):
+//   * the MFMA groups alone run at 64.4 cycles per v_mfma_f32_32x32x2_f32 (the 64-cycle peak);
+//   * every other vector-memory/LDS instruction is ADDED to that at the SIMD level, co-resident waves do not hide it:
+//     +7 cycles per LDS fragment instruction, +56 per global_load_lds piece (two workgroups per CU took exactly twice
+//     the cycles of one; a dedicated loader wave only concentrated the DMA cost on one SIMD and lost 6 %).
+// So the instruction stream is kept minimal and evenly spread:
+//   * operand tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4: 1 KiB = two 512-byte tile rows per
+//     wave-instruction, no staging VGPRs, no ds_write pass), 4 pieces per wave per stage, issued one at a time
+//     between MFMA groups; 4-slot LDS ring, the DMA of stage s+3 is issued during stage s and the end-of-stage
+//     wait is a COUNTED vmcnt (only stage s+1 must have landed) before a raw s_barrier — a __syncthreads() would
+//     drain the ring (cdna_hip_programming.md §5 "Pipelining across barriers");
+//   * a wave owns the 32x32 sub-tiles {wm*32, wm*32+64} x {wn*32, wn*32+64}: its two A (and two B) fragments of a
+//     k-step are 256 bytes apart in LDS = ONE ds_read2st64_b32 with immediate offsets each, i.e. 2 LDS instructions
+//     and no address arithmetic per 4 MFMAs; three fragment register sets in rotation, the reads of k-step kk+1
+//     pinned in front of the MFMAs of kk.
 template <bool WRITE_S>
 __global__ void __launch_bounds__(NTHREADS, 2)
 corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ ref, int C, int N,
@@ -202,9 +221,9 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
                         float* __restrict__ S_out, float* __restrict__ pval, int32_t* __restrict__ pidx)
 {
     // one array (a second __shared__ object next to an LDS-DMA target can make hipcc drain vmcnt early)
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * FBK * BM + 2 * 2 * 32 * 2];
-    float* const tiles = lds;                                  // [buf][A|B][FBK][128]
-    float* const red_v = lds + 2 * 2 * FBK * BM;               // [wn][jn][32]
+    __shared__ __attribute__((aligned(16))) float lds[FNBUF * 2 * FBK * BM + 2 * 2 * 32 * 2];
+    float* const tiles = lds;                                  // [slot][A|B][FBK][128]
+    float* const red_v = lds + FNBUF * 2 * FBK * BM;           // [wn][jn][32]
     int* const red_i = reinterpret_cast<int*>(red_v + 2 * 2 * 32);
 
     const int tid = threadIdx.x;
@@ -227,10 +246,14 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
     const int nstage = C / FBK;
     const int kt_lo = ks * kt_per_wg, kt_hi = min(ktiles, kt_lo + kt_per_wg);
 
-    // LDS-DMA assignment: a stage = 2 operands x FBK rows x 512 B = 32 wave-instructions of 1 KiB (2 rows);
-    // wave w issues instructions w, w+4, ...: 4 for A then 4 for B.  Lane -> (row parity, 16-byte column).
+    // LDS-DMA: a stage = 2 operands x FBK rows x 512 B = 2*FBK/2 = 16 pieces of 1 KiB (2 rows); wave w owns row
+    // pairs w and w+4 of A and of B -> NP = 4 pieces per wave per stage.  Lane -> (row parity, 16-byte column).
+    constexpr int NP = FBK / 4;
     const int dma_row = lane >> 5, dma_col = (lane & 31) * 4;
 
+#ifdef IPSR_CLOCK_PROBE
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         const int k0 = kt * BM;
         f32x16 acc[2][2];
@@ -241,55 +264,77 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-        auto stage_dma = [&](int s, int buf) {
-            const int c0 = s * FBK;
-            float* ta = tiles + (size_t)buf * (2 * FBK * BM);
-            float* tb = ta + FBK * BM;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int pair = wave + 4 * j;                 // rows 2*pair, 2*pair+1
-                const int row = 2 * pair + dma_row;
-                __builtin_amdgcn_global_load_lds((gptr_t)(A + (size_t)(c0 + row) * N + k0 + dma_col),
-                                                 (lptr_t)(ta + pair * 2 * BM), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(R + (size_t)(c0 + row) * N + q0 + dma_col),
-                                                 (lptr_t)(tb + pair * 2 * BM), 16, 0, 0);
-            }
+        // piece p of stage s: p < NP/2 -> A rows, else B rows (index the __shared__ array directly: the builtin needs a
+        // pointer the compiler KNOWS is LDS)
+        auto dma_piece = [&](int s, int p) {
+            const bool isA = p < NP / 2;
+            const int pair = wave + 4 * (isA ? p : p - NP / 2);
+            const int slot = (s & (FNBUF - 1)) * (2 * FBK * BM) + (isA ? 0 : FBK * BM) + pair * 2 * BM;
+            const size_t row = (size_t)s * FBK + 2 * pair + dma_row;
+            const float* g = isA ? (A + row * N + k0 + dma_col) : (R + row * N + q0 + dma_col);
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)&lds[slot], 16, 0, 0);
+        };
+        auto wait_stage = [&](int younger) {      // `younger` = stages whose DMA was issued after the one needed now
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
 
-        stage_dma(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // prologue: stages 0,1,2 in flight; stage 0 must have landed before the first compute
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dma_piece(0, p);
+        if (nstage > 1) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dma_piece(1, p);
+        }
+        if (nstage > 2) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dma_piece(2, p);
+        }
+        wait_stage(min(2, nstage - 1));
+        __builtin_amdgcn_s_barrier();
+
         for (int s = 0; s < nstage; ++s) {
-            const int cur = s & 1;
-            if (s + 1 < nstage) stage_dma(s + 1, cur ^ 1);
-            const float* ta = tiles + (size_t)cur * (2 * FBK * BM) + wm * 64 + r;
-            const float* tb = tiles + (size_t)cur * (2 * FBK * BM) + FBK * BM + wn * 64 + r;
-            float a0 = ta[h * BM], a1 = ta[h * BM + 32], b0 = tb[h * BM], b1 = tb[h * BM + 32];
+            const int cur = s & (FNBUF - 1);
+            // slot (s+3)%4 was last read in stage s-1, which every wave has left (barrier); its pieces are spread
+            // over this stage's k-steps
+            const bool prefetch = s + 3 < nstage;
+            const float* ta = tiles + (size_t)cur * (2 * FBK * BM) + h * BM + wm * 32 + r;
+            const float* tb = tiles + (size_t)cur * (2 * FBK * BM) + FBK * BM + h * BM + wn * 32 + r;
+            float fa0[3], fa1[3], fb0[3], fb1[3];
+            fa0[0] = ta[0]; fa1[0] = ta[64]; fb0[0] = tb[0]; fb1[0] = tb[64];
 #pragma unroll
             for (int kk = 0; kk < FBK / 2; ++kk) {
-                float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                // THREE fragment sets in rotation: the set refilled now (for kk+1) was last read by the MFMAs of kk-2
+                const int cs = kk % 3, ns = (kk + 1) % 3;
                 if (kk + 1 < FBK / 2) {
-                    const int ro = ((kk + 1) * 2 + h) * BM;
-                    na0 = ta[ro]; na1 = ta[ro + 32]; nb0 = tb[ro]; nb1 = tb[ro + 32];
+                    const int ro = (kk + 1) * 2 * BM;
+                    fa0[ns] = ta[ro]; fa1[ns] = ta[ro + 64]; fb0[ns] = tb[ro]; fb1[ns] = tb[ro + 64];
                 }
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+                if (prefetch && (kk % ((FBK / 2) / NP)) == 0) dma_piece(s + 3, kk / ((FBK / 2) / NP));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb0[cs], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb1[cs], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cs], fb0[cs], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cs], fb1[cs], acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            // stage s+1 must have landed: its NP pieces are older than those of stages s+2 and s+3
+            wait_stage(min(s + 3, nstage - 1) - (s + 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
 
+        // epilogue of this k-tile: fold 2x16 rows into the running (max, argmax) of the lane's 2 columns.
+        // Rows are visited in ascending k and only a strictly larger value replaces -> lowest k on ties.
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
-            const int q = q0 + wn * 64 + jn * 32 + r;
+            const int q = q0 + wn * 32 + jn * 64 + r;
 #pragma unroll
             for (int im = 0; im < 2; ++im) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int k = k0 + wm * 64 + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int k = k0 + wm * 32 + im * 64 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     const float v = acc[im][jn][e];
                     if (v > best[jn]) { best[jn] = v; bidx[jn] = k; }
                     if (WRITE_S) S_out[((size_t)b * N + k) * N + q] = v;
@@ -297,7 +342,14 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
             }
         }
     }
+#ifdef IPSR_CLOCK_PROBE
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - pt0;
+        g_probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - pr0;
+    }
+#endif
 
+    // merge the two lane halves (rows 4h..), then the two waves stacked along k (lexicographic (value, idx))
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) {
         const float ov = __shfl_xor(best[jn], 32);
@@ -315,7 +367,7 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
             const float ov = red_v[(wn * 2 + jn) * 32 + r];
             const int oi = red_i[(wn * 2 + jn) * 32 + r];
             if (better(ov, oi, best[jn], bidx[jn])) { best[jn] = ov; bidx[jn] = oi; }
-            const int q = q0 + wn * 64 + jn * 32 + r;
+            const int q = q0 + wn * 32 + jn * 64 + r;
             pval[((size_t)b * ksplit + ks) * N + q] = best[jn];
             pidx[((size_t)b * ksplit + ks) * N + q] = bidx[jn];
         }
@@ -388,3 +440,10 @@ int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, i
 }
 
 }  // namespace ipsr
+
+#ifdef IPSR_CLOCK_PROBE
+extern "C" int ipsr_debug_read_probe(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ipsr::g_probe), sizeof(unsigned long long) * 2 * n);
+}
+#endif

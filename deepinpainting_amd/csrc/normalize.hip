@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const floa
 // registers (every 64-byte line is completed by the same lane's next stores while it sits in L2).
 constexpr int LMAX = 64;
 
+template <int L>
 __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_reg_kernel(const float* __restrict__ x, int C, int N, int Cp,
                                                                           float* __restrict__ xn, float* __restrict__ xT,
                                                                           float* __restrict__ inv)
@@ -115,18 +116,20 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_reg_kernel(const 
     const int k = k0 + col;
     const bool kin = k < N;
     const float* xb = x + (size_t)b * C * N;
-    const int L = (C + NSEG - 1) / NSEG;           // <= LMAX
-    const int c_lo = seg * L;
+    const int c_lo = seg * L;                      // L = ceil(C/8) is a template constant: no per-load guards when C == 8*L
+    const bool full = (C == NSEG * L);
 
-    float v[LMAX];
+    float v[L];
+    if (full && kin) {
 #pragma unroll
-    for (int i = 0; i < LMAX; ++i) {
-        const int c = c_lo + i;
-        v[i] = (kin && i < L && c < C) ? xb[(size_t)c * N + k] : 0.0f;
+        for (int i = 0; i < L; ++i) v[i] = xb[(size_t)(c_lo + i) * N + k];
+    } else {
+#pragma unroll
+        for (int i = 0; i < L; ++i) v[i] = (kin && c_lo + i < C) ? xb[(size_t)(c_lo + i) * N + k] : 0.0f;
     }
     float acc = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LMAX; ++i) acc = __builtin_fmaf(v[i], v[i], acc);     // trailing zeros leave the chain unchanged
+    for (int i = 0; i < L; ++i) acc = __builtin_fmaf(v[i], v[i], acc);        // trailing zeros leave the chain unchanged
     part[seg][col] = acc;
     __syncthreads();
     if (seg == 0) {
@@ -142,16 +145,14 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_reg_kernel(const 
     const float iv = inv_s[col];
     float* xnb = xn + (size_t)b * C * N;
 #pragma unroll
-    for (int i = 0; i < LMAX; ++i) {
-        const int c = c_lo + i;
-        if (i < L && c < C) xnb[(size_t)c * N + k] = v[i] * iv;
-    }
+    for (int i = 0; i < L; ++i)
+        if (full || c_lo + i < C) xnb[(size_t)(c_lo + i) * N + k] = v[i] * iv;
     if (xT) {
         // requires L % 4 == 0 (checked by the launcher) so that every float4 is 16-byte aligned and inside [0,Cp)
         float* row = xT + ((size_t)b * N + k) * Cp + c_lo;
 #pragma unroll
-        for (int i = 0; i < LMAX; i += 4)
-            if (i < L && c_lo + i < Cp) *reinterpret_cast<float4*>(row + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+        for (int i = 0; i < L; i += 4)
+            if (full || c_lo + i < Cp) *reinterpret_cast<float4*>(row + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
     }
 }
 
@@ -162,8 +163,13 @@ int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float
     const int L = cdiv(C, NSEG);
     // register path: segment fits 64 registers; float4 rows of xT need L % 4 == 0 and 8*L >= Cp (all of the padded row written)
     if (L <= LMAX && L % 4 == 0 && NSEG * L >= Cp) {
-        patch_normalize_reg_kernel<<<B * ntile, NCOL * NSEG, 0, st>>>(x, C, N, Cp, xn, xT, inv);
-        return check_launch("patch_normalize_reg_kernel");
+        const int grid = B * ntile;
+        switch (L) {
+#define NORM_CASE(LL) case LL: patch_normalize_reg_kernel<LL><<<grid, NCOL * NSEG, 0, st>>>(x, C, N, Cp, xn, xT, inv); return check_launch("patch_normalize_reg_kernel")
+            NORM_CASE(64); NORM_CASE(32); NORM_CASE(16); NORM_CASE(8); NORM_CASE(4);
+#undef NORM_CASE
+            default: break;      // other lengths: generic kernel below
+        }
     }
     patch_normalize_kernel<<<B * ntile, NCOL * NSEG, 0, st>>>(x, C, N, Cp, xn, xT, inv);
     return check_launch("patch_normalize_kernel");

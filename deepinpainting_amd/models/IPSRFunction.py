@@ -30,7 +30,7 @@ class IPSRFunction(torch.autograd.Function):
         if mpi32 is None or mpi32.device != input.device:
             mpi32 = mask_point_idx.to(device=input.device, dtype=torch.int32)
         # `ref` is the VGG namedtuple; only relu4_3 is read (reference :49)
-        need_grad = torch.is_grad_enabled() and input.requires_grad
+        need_grad = ctx.needs_input_grad[0]      # grad mode is off inside Function.forward, so ask the ctx
         f = ops.forward(input.detach(), ref.relu4_3.detach(), mpi32, int(shift_sz), int(stride), want_index=need_grad)
         ctx.M = int(mpi32.numel())
         ctx.bwd_index = f.bwd_index        # sparse trunc(kbar)  (the reference keeps the dense ctx.ind_lst, :139)
