@@ -36,6 +36,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def _private_miopen_db():
+    """Give every rank its own copy of the shipped MIOpen find-db (deepinpainting_amd/miopen_db): MIOpen takes file
+    locks on its user db, and 8 ranks sharing one directory would serialise on them.  Must run before the first conv."""
+    if "MIOPEN_USER_DB_PATH" in os.environ or os.environ.get("IPSR_NO_MIOPEN_DB", "0") == "1":
+        return
+    import shutil
+    src = os.path.join(ROOT, "deepinpainting_amd", "miopen_db")
+    dst = os.path.join("/tmp", "ipsr_miopen_db_%d_%s" % (os.getuid(), os.environ.get("LOCAL_RANK", "0")))
+    try:
+        os.makedirs(dst, exist_ok=True)
+        for f in os.listdir(src):
+            if f.endswith(".txt"):
+                shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+        os.environ["MIOPEN_USER_DB_PATH"] = dst
+    except OSError:
+        pass      # fall back to the in-tree directory (deepinpainting_amd/__init__.py)
+
+
+_private_miopen_db()
+
 METRIC = "train images/sec at 256x256, batch 8/GPU, 1/2/4/8 MI355X; IPSR layer ms"
 FINE, BATCH, C_FEAT, H_FEAT = 256, 8, 512, 32
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32-input MFMA = 64 FLOP/clk/SIMD
