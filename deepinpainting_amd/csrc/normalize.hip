@@ -97,9 +97,8 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const floa
 // ---------------------------------------------------------------------------------------------------
 // Register-resident variant for C <= 512 (segment length L <= 64): a thread keeps its (segment, column) slice
 // of x in registers between the norm and the scaling, so x is read from HBM exactly once and nothing goes
-// through LDS but the 8 partial sums.  The thread holds 64 CONSECUTIVE channels of ONE patch, which is also a
-// contiguous 256-byte piece of the patch-major row xT[k][seg*64 ...]: written with 16-byte stores straight from
-// registers (every 64-byte line is completed by the same lane's next stores while it sits in L2).
+// through LDS on the way to xn.  The patch-major copy xT is transposed through an LDS tile so that it leaves the
+// CU as full 1-KiB wave stores (see the comment at the store).
 constexpr int LMAX = 64;
 
 template <int L>
@@ -107,6 +106,7 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_reg_kernel(const 
                                                                           float* __restrict__ xn, float* __restrict__ xT,
                                                                           float* __restrict__ inv)
 {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // [NCOL][Cp + 4] staging of the patch-major rows
     __shared__ float part[NSEG][NCOL];
     __shared__ float inv_s[NCOL];
     const int tid = threadIdx.x;
@@ -141,18 +141,31 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_reg_kernel(const 
         if (kin) inv[(size_t)b * N + k] = iv;
     }
     __syncthreads();
-    if (!kin) return;
     const float iv = inv_s[col];
     float* xnb = xn + (size_t)b * C * N;
+    if (kin) {
 #pragma unroll
-    for (int i = 0; i < L; ++i)
-        if (full || c_lo + i < C) xnb[(size_t)(c_lo + i) * N + k] = v[i] * iv;
+        for (int i = 0; i < L; ++i)
+            if (full || c_lo + i < C) xnb[(size_t)(c_lo + i) * N + k] = v[i] * iv;
+    }
     if (xT) {
-        // requires L % 4 == 0 (checked by the launcher) so that every float4 is 16-byte aligned and inside [0,Cp)
-        float* row = xT + ((size_t)b * N + k) * Cp + c_lo;
+        // Patch-major copy through LDS.  Writing the 256-byte register slice straight to xT[k][seg*64..] made every
+        // lane store 16 B into a different cache line: PMC WRITE_SIZE showed 99 MB for 32 MB of payload.  Instead the
+        // workgroup builds its [32 patches][Cp] tile in LDS (row stride Cp+4 floats: ds_write_b128 lanes land in 16
+        // distinct 16-byte bank groups) and streams it out with full 1-KiB wave stores.
+        const int stride = Cp + 4;
+        float* trow = tile + (size_t)col * stride + c_lo;
 #pragma unroll
         for (int i = 0; i < L; i += 4)
-            if (full || c_lo + i < Cp) *reinterpret_cast<float4*>(row + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+            if (full || c_lo + i < Cp) *reinterpret_cast<float4*>(trow + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+        __syncthreads();
+        const int nvec = Cp >> 2;                                  // float4 per patch row
+        float* xTb = xT + ((size_t)b * N + k0) * Cp;
+        for (int idx = tid; idx < NCOL * nvec; idx += NCOL * NSEG) {
+            const int row = idx / nvec, c4 = (idx - row * nvec) * 4;
+            if (k0 + row < N)
+                *reinterpret_cast<float4*>(xTb + (size_t)row * Cp + c4) = *reinterpret_cast<const float4*>(tile + (size_t)row * stride + c4);
+        }
     }
 }
 
@@ -164,8 +177,15 @@ int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float
     // register path: segment fits 64 registers; float4 rows of xT need L % 4 == 0 and 8*L >= Cp (all of the padded row written)
     if (L <= LMAX && L % 4 == 0 && NSEG * L >= Cp) {
         const int grid = B * ntile;
+        const size_t lds = xT ? (size_t)NCOL * (Cp + 4) * sizeof(float) : 0;
         switch (L) {
-#define NORM_CASE(LL) case LL: patch_normalize_reg_kernel<LL><<<grid, NCOL * NSEG, 0, st>>>(x, C, N, Cp, xn, xT, inv); return check_launch("patch_normalize_reg_kernel")
+#define NORM_CASE(LL)                                                                                             \
+    case LL:                                                                                                      \
+        if (lds > 48 * 1024)                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_normalize_reg_kernel<LL>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+        patch_normalize_reg_kernel<LL><<<grid, NCOL * NSEG, lds, st>>>(x, C, N, Cp, xn, xT, inv);                 \
+        return check_launch("patch_normalize_reg_kernel")
             NORM_CASE(64); NORM_CASE(32); NORM_CASE(16); NORM_CASE(8); NORM_CASE(4);
 #undef NORM_CASE
             default: break;      // other lengths: generic kernel below
