@@ -62,8 +62,7 @@ struct FwdPlan {
 };
 
 // workspace slices in carve order (all 256-B aligned)
-enum { WS_XN, WS_XT, WS_INV, WS_CORR, WS_WN, WS_WO, WS_KQ, WS_JQ, WS_DLIST, WS_MPRIME, WS_RANKFLAG, WS_ONEHOT, WS_SURV,
-       WS_COLCNT, WS_AC, WS_COUNT };
+enum { WS_XN, WS_XT, WS_INV, WS_CORR, WS_WN, WS_WO, WS_KQ, WS_JQ, WS_DLIST, WS_MPRIME, WS_RANKFLAG, WS_AC, WS_COUNT };
 
 static FwdPlan plan_forward(int B, int C, int h, int w, int M, size_t* sizes)
 {
@@ -78,9 +77,9 @@ static FwdPlan plan_forward(int B, int C, int h, int w, int M, size_t* sizes)
     sz[WS_INV] = (size_t)B * p.N * 4;
     sz[WS_CORR] = corr_argmax_ws_bytes(B, C, p.N);
     sz[WS_WN] = sz[WS_WO] = sz[WS_KQ] = sz[WS_JQ] = (size_t)B * Mx * 4;
-    sz[WS_DLIST] = sz[WS_SURV] = (size_t)B * p.Mc * 4;
+    sz[WS_DLIST] = (size_t)B * p.Mc * 4;
     sz[WS_MPRIME] = (size_t)B * 4;
-    sz[WS_RANKFLAG] = sz[WS_ONEHOT] = sz[WS_COLCNT] = (size_t)B * p.N * 4;
+    sz[WS_RANKFLAG] = (size_t)B * p.N * 4;
     sz[WS_AC] = (size_t)B * Mx * p.Mc * 4;
     p.total = 256;
     for (int i = 0; i < WS_COUNT; ++i) {
@@ -180,8 +179,7 @@ int ipsr_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int
 size_t ipsr_bwd_index_ints(int N, int M)
 {
     if (N < 1 || M < 0 || M > N) return 0;
-    const size_t cap = (size_t)(N - M) + (size_t)M * (M + 1) / 2;
-    return (size_t)N + 1 + 2 * cap;
+    return 2 * ((size_t)N + 1) + (size_t)N + (size_t)M * (M + 1);
 }
 
 size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride)
@@ -215,9 +213,8 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     float* inv = reinterpret_cast<float*>(slice[WS_INV]);
 
     if (int rc = launch_patch_normalize(x, B, C, p.N, xn, xT, p.Cp, inv, st)) return rc;
-    if (int rc = launch_corr_argmax(xn, ref, B, C, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st)) return rc;
-
     AttnArgs a;
+    if (int rc = launch_corr_argmax(xn, ref, B, C, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part)) return rc;
     a.x = x; a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
     a.B = B; a.C = C; a.Cp = p.Cp; a.N = p.N; a.M = M; a.Mc = p.Mc;
     a.wn = reinterpret_cast<float*>(slice[WS_WN]);
@@ -227,9 +224,6 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     a.dlist = reinterpret_cast<int32_t*>(slice[WS_DLIST]);
     a.mprime = reinterpret_cast<int32_t*>(slice[WS_MPRIME]);
     a.rankflag = reinterpret_cast<int32_t*>(slice[WS_RANKFLAG]);
-    a.onehot_cnt = reinterpret_cast<int32_t*>(slice[WS_ONEHOT]);
-    a.surv_cnt = reinterpret_cast<int32_t*>(slice[WS_SURV]);
-    a.col_cnt = reinterpret_cast<int32_t*>(slice[WS_COLCNT]);
     a.ac = reinterpret_cast<float*>(slice[WS_AC]);
     a.attn = attn_rows; a.out = out; a.bwd_index = bwd_index;
     return launch_attention(a, st);

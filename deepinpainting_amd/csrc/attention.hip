@@ -13,17 +13,15 @@
 //     only the scalars (wn_l, wo_l).  Latency-bound by construction: M dependent steps.
 //   * attn_compress_kernel — a_l[k] is a scalar recurrence per k, independent across k, and non-zero only in
 //     the columns {kq_l}: one thread per ACTIVE column replays (wn_l, wo_l) from LDS (see "Compressed attention").
-//   * recon_gather_kernel — non-masked q: kbar column is one-hot, so out[:,q] = P[ind[q]] is a row
+//   * gather_body — non-masked q: kbar column is one-hot, so out[:,q] = P[ind[q]] is a row
 //     gather (LDS-transposed so that both the read of xT rows and the write of out rows are coalesced).
 //   * recon_masked_kernel — masked q: out[:,q_l] = sum_k a_l[k] * P[k,:], the dense part of the
 //     reference's second GEMM, on fp32 MFMA over the active columns in ascending k (one fmaf chain per
 //     output; the skipped terms are exact zeros, so the bits equal the oracle's dense chain).
-//   * attn_prepare / index_scan / csr_fill — kbar is kept by the reference in a LongTensor (:36,134), i.e.
+//   * prepare_body / attn_compress_kernel — kbar is kept by the reference in a LongTensor (:36,134), i.e.
 //     truncated toward zero.  What survives is stored as a CSR over the patch index k: the non-masked q
 //     with ind[q] == k (weight 1, ascending q) followed by the masked rows whose |a_l[k]| >= 1 (weight
 //     trunc(a_l[k]), ascending l).  That is all the backward needs.
-#include <cstdlib>
-
 #include "ipsr_common.h"
 
 namespace ipsr {
@@ -116,16 +114,14 @@ __device__ __forceinline__ void rec_step(RowRegs<NCH>& o, const RowRegs<NCH>& pu
     }
 }
 
+// Runs in a 256-thread block of the stage kernel: all four waves fill / drain the LDS arrays, wave 0 alone walks the chain.
 template <int NCH, bool FULL>
-__global__ void __launch_bounds__(64) recurrence_kernel(const float* __restrict__ xT, const float* __restrict__ inv,
-                                                        const int32_t* __restrict__ ind, const float* __restrict__ vmax,
-                                                        const int32_t* __restrict__ mpi, int Cp, int N, int M,
-                                                        float* __restrict__ wn_out, float* __restrict__ wo_out,
-                                                        int32_t* __restrict__ kq_out)
+__device__ __forceinline__ void recurrence_body(int* lds_raw, int b, const float* __restrict__ xT, const float* __restrict__ inv,
+                                                const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M,
+                                                float* __restrict__ wn_out, float* __restrict__ wo_out)
 {
     // step-indexed LDS arrays: entry s describes step l = s + 1 (so a ring turn l = 1+4j.. is 16-byte aligned);
     // padded by 3*RING entries that repeat a valid row index so that run-ahead prefetches stay in bounds
-    extern __shared__ __attribute__((aligned(16))) int lds_raw[];
     const int Mp = ((M + 3) & ~3) + 3 * RING;
     int* q_s = lds_raw;
     int* kq_s = q_s + Mp;
@@ -134,27 +130,32 @@ __global__ void __launch_bounds__(64) recurrence_kernel(const float* __restrict_
     float* wn_s = vm_s + Mp;      // (wn_l, wo_l) indexed by l, copied out in one coalesced pass at the end
     float* wo_s = wn_s + Mp;
 
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const float* xTb = xT + (size_t)b * N * Cp;
-    const int32_t* indb = ind + (size_t)b * N;
 
-    for (int l = lane; l < M; l += 64) {
+    // resolve the chain mask_point_idx -> arg-max (merged from the k-split partials) -> (inv, vmax) for all steps
+    for (int l = tid; l < M; l += 256) {
         const int q = mpi[l];
-        const int kq = indb[q];
-        kq_out[(size_t)b * M + l] = kq;
+        float vq; int kq;
+        merged_argmax(part, b, N, q, vq, kq);
         if (l >= 1) {
             q_s[l - 1] = q;
             kq_s[l - 1] = kq;
             iv_s[l - 1] = inv[(size_t)b * N + q];
-            vm_s[l - 1] = vmax[(size_t)b * N + q];
+            vm_s[l - 1] = vq;
+        } else {
+            q_s[Mp - 1] = q;        // step 0's (q, kq) parked in the last padding slot (rewritten below with the same values)
+            kq_s[Mp - 1] = kq;
         }
     }
-    const int q0 = mpi[0];
-    const int kq0 = indb[q0];
-    for (int s = M - 1 + lane; s < Mp; s += 64) { q_s[s] = q0; kq_s[s] = kq0; iv_s[s] = 0.0f; vm_s[s] = 1.0f; }
-    if (lane == 0) { wn_s[0] = 0.0f; wo_s[0] = 1.0f; }      // step 0: (wn, wo) = (0, 1) makes a_0 = onehot(kq_0)
+    __syncthreads();
+    const int q0 = q_s[Mp - 1], kq0 = kq_s[Mp - 1];
+    __syncthreads();
+    for (int s = M - 1 + tid; s < Mp; s += 256) { q_s[s] = q0; kq_s[s] = kq0; iv_s[s] = 0.0f; vm_s[s] = 1.0f; }
+    if (tid == 0) { wn_s[0] = 0.0f; wo_s[0] = 1.0f; }      // step 0: (wn, wo) = (0, 1) makes a_0 = onehot(kq_0)
     __syncthreads();
 
+  if (tid < 64) {
     // Two register sets of RING slots: set A serves even ring turns, set B odd ones.  A slot is refilled right
     // after it is consumed with the row of the step TWO turns ahead, so every load has a full turn (4 steps)
     // of compute to land in, wherever the scheduler places it inside the turn.
@@ -221,26 +222,30 @@ __global__ void __launch_bounds__(64) recurrence_kernel(const float* __restrict_
     }
 #undef IPSR_TURN
 #undef IPSR_TAIL
+  }
     __syncthreads();
-    for (int l = lane; l < M; l += 64) { wn_out[(size_t)b * M + l] = wn_s[l]; wo_out[(size_t)b * M + l] = wo_s[l]; }
+    for (int l = tid; l < M; l += 256) { wn_out[(size_t)b * M + l] = wn_s[l]; wo_out[(size_t)b * M + l] = wo_s[l]; }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // non-masked columns: out[c][q] = P[ind[q]][c]  (one-hot kbar column, IPSRFunction.py:129-133).
 // (masked columns are written too and overwritten by recon_masked_kernel afterwards.)
-__global__ void __launch_bounds__(256) recon_gather_kernel(const float* __restrict__ xT, const int32_t* __restrict__ ind,
-                                                           int C, int Cp, int N, float* __restrict__ out)
+__device__ __forceinline__ void gather_body(float (*tile)[33], int tileid, const float* __restrict__ xT, const CorrPartials& part,
+                                            int B, int C, int Cp, int N, float* __restrict__ out)
 {
-    __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int q0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+    const int nq = (N + 31) / 32, nc = (C + 31) / 32;
+    const int q0 = (tileid % nq) * 32, c0 = ((tileid / nq) % nc) * 32, b = tileid / (nq * nc);
+    (void)B;
     const float* xTb = xT + (size_t)b * N * Cp;
-    // two batches of independent loads (the 4 row indices, then the 4 row elements) instead of 4 dependent pairs
+    // two batches of independent loads (the 4 merged row indices, then the 4 row elements) instead of 4 dependent pairs
     int row[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = q0 + ty + 8 * i;
-        row[i] = q < N ? ind[(size_t)b * N + q] : 0;
+        float v; int k = 0;
+        if (q < N) merged_argmax(part, b, N, q, v, k);
+        row[i] = k;
     }
     float v[4];
 #pragma unroll
@@ -264,186 +269,84 @@ __global__ void __launch_bounds__(256) recon_gather_kernel(const float* __restri
 // Row l of the reference's `in_attention` [M,N] (IPSRFunction.py:76,123-125) is non-zero only in the columns
 // kq_0..kq_l it has touched, so all M rows live in the M' <= M "active" columns D = sorted{kq_l}.  Everything
 // downstream works on the compressed matrix Ac[l][j] = a_l[D_j] (zero terms of the dense sums are exact no-ops):
-//   attn_prepare_kernel     per sample: active-column list D (ascending k), rank of every column, jq_l = rank(kq_l),
+//   prepare_body            per sample: active-column list D (ascending k), rank of every column, jq_l = rank(kq_l),
 //                           and the one-hot column counts of trunc(kbar) (non-masked q with ind[q] == k)
+//                           and the one-hot CSR of trunc(kbar): one wave ranks the non-masked q by (ind[q], q) with
+//                           ballot-based matching and writes the entries in ascending q — all inside the stage kernel,
+//                           i.e. while the serial recurrence runs
 //   attn_compress_kernel    thread per active column j replays the scalar recurrence  a = a*wn_l (+ wo_l if jq_l == j)
-//                           from LDS, writes Ac coalesced over j and counts the entries with |a| >= 1 that survive the
-//                           reference's LongTensor truncation (:36,134)
-//   index_scan_kernel       exclusive scan of the per-column entry counts -> col_off
-//   csr_fill_kernel         block 0: one wave ranks the non-masked q by (ind[q], q) with ballot-based matching and
-//                           writes the one-hot entries in ascending q; other blocks: the survivors, ascending l
+//                           from LDS, writes Ac coalesced over j, and builds the CSR of the entries with |a| >= 1 that
+//                           survive the reference's LongTensor truncation (:36,134)
 //   attn_expand_kernel      only when the caller asks for the dense [M,N] rows (tests / inspection)
 //   recon_masked_kernel     out[:,q_l] = sum_j Ac[l][j] * P[D_j,:]  on fp32 MFMA, j ascending == k ascending
 
-__global__ void __launch_bounds__(1024) attn_prepare_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
-                                                            const int32_t* __restrict__ kq, int N, int M, int Mc,
-                                                            int32_t* __restrict__ dlist, int32_t* __restrict__ mprime,
-                                                            int32_t* __restrict__ jq, int32_t* __restrict__ rankflag,
-                                                            int32_t* __restrict__ onehot_cnt, int32_t* __restrict__ col_cnt)
+__device__ __forceinline__ void prepare_body(int* lds, int b, const CorrPartials& part, const int32_t* __restrict__ mpi,
+                                             int N, int M, int Mc, int nbits, int32_t* __restrict__ ind, float* __restrict__ vmax,
+                                             int32_t* __restrict__ dlist, int32_t* __restrict__ mprime,
+                                             int32_t* __restrict__ jq, int32_t* __restrict__ rankflag,
+                                             int32_t* __restrict__ bwd_index, size_t ints_per_sample)
 {
-    extern __shared__ __attribute__((aligned(16))) int lds[];
-    int* flag = lds;            // [N] 1 = active column
-    int* cnt = lds + N;         // [N] one-hot count
-    int* ismask = lds + 2 * N;  // [N]
-    __shared__ int wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
-    const int32_t* indb = ind + (size_t)b * N;
-    const int32_t* kqb = kq + (size_t)b * M;
-    for (int k = tid; k < N; k += 1024) { flag[k] = 0; cnt[k] = 0; ismask[k] = 0; }
+    int* flag = lds;            // [N] 1 = active column (later rank+1)
+    int* cnt = lds + N;         // [N] one-hot count, later the write cursor of column k
+    int* key = lds + 2 * N;     // [N] merged arg-max of q, or -1 for masked q
+    int* indm = lds + 3 * N;    // [N] merged arg-max of this sample
+    __shared__ int wave_tot[4], wave_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // this role is the one that materialises the merged (ind, vmax) outputs of the layer
+    for (int q = tid; q < N; q += 256) {
+        float v; int k;
+        merged_argmax(part, b, N, q, v, k);
+        indm[q] = k;
+        key[q] = k;
+        ind[(size_t)b * N + q] = k;
+        vmax[(size_t)b * N + q] = v;
+        flag[q] = 0; cnt[q] = 0;
+    }
     __syncthreads();
-    for (int l = tid; l < M; l += 1024) { flag[kqb[l]] = 1; ismask[mpi[l]] = 1; }
+    for (int l = tid; l < M; l += 256) { const int q = mpi[l]; flag[indm[q]] = 1; key[q] = -1; }
     __syncthreads();
-    for (int q = tid; q < N; q += 1024)
-        if (!ismask[q]) atomicAdd(&cnt[indb[q]], 1);
-    // ordered compaction of the active columns: thread t owns k in [t*KPT, (t+1)*KPT)
-    const int KPT = (N + 1023) / 1024;
+    for (int q = tid; q < N; q += 256)
+        if (key[q] >= 0) atomicAdd(&cnt[key[q]], 1);
+    __syncthreads();
+    // two exclusive scans over k at once (thread t owns k in [t*KPT, (t+1)*KPT)):
+    //   active-column ranks (ordered compaction -> dlist) and one-hot entry offsets (offA of the backward's CSR)
+    const int KPT = (N + 255) / 256;
     const int k_lo = tid * KPT, k_hi = min(N, k_lo + KPT);
-    int total = 0;
-    for (int k = k_lo; k < k_hi; ++k) total += flag[k];
-    int incl = total;
+    int total = 0, ctotal = 0;
+    for (int k = k_lo; k < k_hi; ++k) { total += flag[k]; ctotal += cnt[k]; }
+    int incl = total, cincl = ctotal;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
-        const int t = __shfl_up(incl, s);
-        if (lane >= s) incl += t;
+        const int t = __shfl_up(incl, s), ct = __shfl_up(cincl, s);
+        if (lane >= s) { incl += t; cincl += ct; }
     }
-    if (lane == 63) wave_tot[wv] = incl;
+    if (lane == 63) { wave_tot[wv] = incl; wave_cnt[wv] = cincl; }
     __syncthreads();
-    int rank = incl - total;
-    for (int j = 0; j < wv; ++j) rank += wave_tot[j];
+    int rank = incl - total, off = cincl - ctotal;
+    for (int j = 0; j < wv; ++j) { rank += wave_tot[j]; off += wave_cnt[j]; }
+    int32_t* offA = bwd_index ? bwd_index + (size_t)b * ints_per_sample : nullptr;
     for (int k = k_lo; k < k_hi; ++k) {
         const int f = flag[k];
-        rankflag[(size_t)b * N + k] = f ? rank : -1;
+        // active column: its rank; inactive: -(number of active columns below k) - 1
+        rankflag[(size_t)b * N + k] = f ? rank : -rank - 1;
         if (f) { dlist[(size_t)b * Mc + rank] = k; flag[k] = rank + 1; }     // flag now holds rank+1 for the jq lookup
         rank += f;
         const int c = cnt[k];
-        onehot_cnt[(size_t)b * N + k] = c;
-        col_cnt[(size_t)b * N + k] = c;
+        if (offA) offA[k] = off;
+        cnt[k] = off;                                                          // cursor of column k
+        off += c;
     }
-    if (tid == 1023) mprime[b] = rank;
+    if (tid == 255) { mprime[b] = rank; if (offA) offA[N] = off; }
     __syncthreads();
-    int mp = 0;
-    for (int j = 0; j < 16; ++j) mp += wave_tot[j];
-    for (int j = mp + tid; j < Mc; j += 1024) dlist[(size_t)b * Mc + j] = 0;     // padding rows of the GEMM: any valid patch
-    for (int l = tid; l < M; l += 1024) jq[(size_t)b * M + l] = flag[kqb[l]] - 1;
-}
+    const int mp = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    for (int j = mp + tid; j < Mc; j += 256) dlist[(size_t)b * Mc + j] = 0;     // padding rows of the GEMM: any valid patch
+    for (int l = tid; l < M; l += 256) jq[(size_t)b * M + l] = flag[indm[mpi[l]]] - 1;
 
-constexpr int AC_COLS = 128;
-
-// (wn, wo, jq) of all steps into LDS as float4, 2 independent loads per thread per batch
-__device__ __forceinline__ float4* load_steps_lds(int* lds, const float* __restrict__ wn, const float* __restrict__ wo,
-                                                  const int32_t* __restrict__ jq, int M)
-{
-    float4* step = reinterpret_cast<float4*>(lds);
-    for (int l0 = 0; l0 < M; l0 += 2 * AC_COLS) {
-        float4 v[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int l = l0 + j * AC_COLS + threadIdx.x;
-            v[j] = l < M ? make_float4(wn[l], wo[l], __int_as_float(jq[l]), 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const int l = l0 + j * AC_COLS + threadIdx.x; if (l < M) step[l] = v[j]; }
-    }
-    __syncthreads();
-    return step;
-}
-
-__global__ void __launch_bounds__(AC_COLS) attn_compress_kernel(const float* __restrict__ wn, const float* __restrict__ wo,
-                                                                const int32_t* __restrict__ jq, const int32_t* __restrict__ dlist,
-                                                                const int32_t* __restrict__ mprime, int N, int M, int Mc,
-                                                                float* __restrict__ ac, int32_t* __restrict__ surv_cnt,
-                                                                int32_t* __restrict__ col_cnt)
-{
-    extern __shared__ __attribute__((aligned(16))) int lds[];
-    const int b = blockIdx.y;
-    const float4* step = load_steps_lds(lds, wn + (size_t)b * M, wo + (size_t)b * M, jq + (size_t)b * M, M);
-    const int j = blockIdx.x * AC_COLS + threadIdx.x;
-    if (j >= Mc) return;
-    float* acb = ac + (size_t)b * M * Mc;
-    float a = 0.0f;
-    int cnt = 0;
-#pragma unroll 8
-    for (int l = 0; l < M; ++l) {
-        const float4 s = step[l];
-        a = a * s.x;                                            // (:123)
-        a = (__float_as_int(s.z) == j) ? a + s.y : a;           // (:124)
-        acb[(size_t)l * Mc + j] = a;                            // (:125) compressed row l
-        cnt += (truncf(a) != 0.0f) ? 1 : 0;
-    }
-    if (j < mprime[b]) {
-        surv_cnt[(size_t)b * Mc + j] = cnt;
-        if (cnt) col_cnt[(size_t)b * N + dlist[(size_t)b * Mc + j]] += cnt;     // single writer per column
-    }
-}
-
-// exclusive scan of col_cnt over k -> col_off[0..N]; one workgroup per sample
-__global__ void __launch_bounds__(1024) index_scan_kernel(const int32_t* __restrict__ col_cnt, int N,
-                                                          int32_t* __restrict__ bwd_index, size_t ints_per_sample)
-{
-    __shared__ int wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
-    int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
-    const int KPT = (N + 1023) / 1024;
-    const int k_lo = tid * KPT, k_hi = min(N, k_lo + KPT);
-    int total = 0;
-    for (int k = k_lo; k < k_hi; ++k) total += col_cnt[(size_t)b * N + k];
-    int incl = total;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const int t = __shfl_up(incl, s);
-        if (lane >= s) incl += t;
-    }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    int off = incl - total;
-    for (int j = 0; j < wv; ++j) off += wave_tot[j];
-    for (int k = k_lo; k < k_hi; ++k) {
-        col_off[k] = off;
-        off += col_cnt[(size_t)b * N + k];
-    }
-    if (tid == 1023) col_off[N] = off;
-}
-
-__global__ void __launch_bounds__(AC_COLS) csr_fill_kernel(const int32_t* __restrict__ ind, const int32_t* __restrict__ mpi,
-                                                           const float* __restrict__ wn, const float* __restrict__ wo,
-                                                           const int32_t* __restrict__ jq, const int32_t* __restrict__ dlist,
-                                                           const int32_t* __restrict__ mprime, const int32_t* __restrict__ onehot_cnt,
-                                                           const int32_t* __restrict__ surv_cnt, int N, int M, int Mc, int nbits,
-                                                           int32_t* __restrict__ bwd_index, size_t ints_per_sample, size_t cap)
-{
-    extern __shared__ __attribute__((aligned(16))) int lds[];
-    const int b = blockIdx.y;
-    int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
-    int32_t* ent_q = col_off + N + 1;
-    float* ent_w = reinterpret_cast<float*>(ent_q + cap);
-
-    if (blockIdx.x == 0) {
-        // ---- one-hot rows: non-masked q, grouped by k = ind[q], ascending q inside a group.  One wave walks the
-        // positions 64 at a time; lanes with equal keys find each other with one ballot per key bit.  Keys and the
-        // per-column write cursors (initialised to col_off) live in LDS, so the serial loop touches no global memory
-        // except the entry stores.
-        int* cursor = lds;           // [N] next entry slot of column k
-        int* key = lds + N;          // [N] ind[q], or -1 for masked q
-        const int32_t* indb = ind + (size_t)b * N;
-        for (int k0 = 0; k0 < N; k0 += 4 * AC_COLS) {
-            int c[4], v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + j * AC_COLS + threadIdx.x;
-                c[j] = k < N ? col_off[k] : 0;
-                v[j] = k < N ? indb[k] : -1;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + j * AC_COLS + threadIdx.x;
-                if (k < N) { cursor[k] = c[j]; key[k] = v[j]; }
-            }
-        }
-        __syncthreads();
-        for (int l = threadIdx.x; l < M; l += AC_COLS) key[mpi[l]] = -1;
-        __syncthreads();
-        if (threadIdx.x >= 64) return;
-        const int lane = threadIdx.x;
+    // ---- one-hot rows of trunc(kbar): non-masked q grouped by k = ind[q], ascending q inside a group.  One wave walks
+    // the positions 64 at a time; lanes with equal keys find each other with one ballot per key bit.  Keys and cursors
+    // are in LDS, so the serial loop touches no global memory except the entry stores.
+    if (offA && tid < 64) {
+        int32_t* entA = offA + N + 1;
         const unsigned long long lt = (1ull << lane) - 1ull;
         for (int q0 = 0; q0 < N; q0 += 64) {
             const int q = q0 + lane;
@@ -456,29 +359,143 @@ __global__ void __launch_bounds__(AC_COLS) csr_fill_kernel(const int32_t* __rest
                 m &= one ? bal : ~bal;
             }
             if (valid) {
-                const int base = cursor[kv];
-                const int rank = __popcll(m & lt);
-                ent_q[base + rank] = q;
-                ent_w[base + rank] = 1.0f;
-                if (rank == 0) cursor[kv] = base + __popcll(m);      // one leader per key; the reads above precede this write
+                const int base = cnt[kv];
+                const int rnk = __popcll(m & lt);
+                entA[base + rnk] = q;
+                if (rnk == 0) cnt[kv] = base + __popcll(m);      // one leader per key; the reads above precede this write
             }
         }
-        return;
     }
-    // ---- masked rows that survive the truncation: thread per active column replays the recurrence
-    const float4* step = load_steps_lds(lds, wn + (size_t)b * M, wo + (size_t)b * M, jq + (size_t)b * M, M);
-    const int j = (blockIdx.x - 1) * AC_COLS + threadIdx.x;
-    if (j >= mprime[b] || surv_cnt[(size_t)b * Mc + j] == 0) return;
-    const int k = dlist[(size_t)b * Mc + j];
-    int e = col_off[k] + onehot_cnt[(size_t)b * N + k];
-    float a = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stage kernel: ONE launch behind the correlation kernel runs three independent jobs side by side, because the
+// coherent-attention recurrence is a serial chain on one wave per sample and would otherwise leave 248 CUs idle:
+//   blocks [0, nrec)            recurrence_body  (nrec = B, or 0 when nothing is masked)
+//   blocks [nrec, nrec + B)     prepare_body     (merged ind/vmax outputs, active columns, one-hot counts)
+//   remaining blocks            gather_body      (non-masked reconstruction, one 32x32 tile each)
+// All of them fold the correlation kernel's k-split partials themselves, so no merge launch is needed either.
+template <int NCH, bool FULL>
+__global__ void __launch_bounds__(256) attention_stage_kernel(AttnArgs a, int nrec, int nbits, size_t ints_per_sample)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds_dyn[];
+    __shared__ float gtile[32][33];
+    const int bid = blockIdx.x;
+    if (bid < nrec) {
+        recurrence_body<NCH, FULL>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
+    } else if (bid < nrec + a.B) {
+        prepare_body(lds_dyn, bid - nrec, a.part, a.mpi, a.N, a.M, a.Mc, nbits, a.ind, a.vmax, a.dlist, a.mprime, a.jq, a.rankflag,
+                     a.bwd_index, ints_per_sample);
+    } else {
+        gather_body(gtile, bid - nrec - a.B, a.xT, a.part, a.B, a.C, a.Cp, a.N, a.out);
+    }
+}
+
+constexpr int AC_MAXT = 1024;   // threads per workgroup: one active column each (columns beyond 1024 loop)
+constexpr int AC_KEEP = 4;      // survivors per column remembered in registers during the single replay
+
+// Compressed attention rows + the survivor CSR, one workgroup per sample.
+//   replay: thread per active column j runs  a = a*wn_l (+ wo_l if jq_l == j)  from an LDS copy of the steps, writes
+//           Ac[l][j] (coalesced over j), counts the entries with |a| >= 1 that survive the LongTensor truncation and
+//           remembers the first AC_KEEP of them (in practice a column has 0 or 1);
+//   scan  : survivor counts over the active columns (ascending j == ascending k) -> offB for EVERY k;
+//   fill  : remembered survivors are written straight out; a column with more than AC_KEEP replays once more.
+template <bool WITH_INDEX>
+__global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __restrict__ wn, const float* __restrict__ wo,
+                                                                const int32_t* __restrict__ jq, const int32_t* __restrict__ mprime,
+                                                                const int32_t* __restrict__ rankflag, const int32_t* __restrict__ mpi,
+                                                                int N, int M, int Mc, float* __restrict__ ac,
+                                                                int32_t* __restrict__ bwd_index, size_t ints_per_sample)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds[];
+    float4* step = reinterpret_cast<float4*>(lds);          // [M] {wn, wo, jq bits, 0}
+    int* offj = lds + 4 * M;                                 // [Mc + 1] survivor count, then offset, of active column j
+    __shared__ int wave_tot[AC_MAXT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
+    const float* wnb = wn + (size_t)b * M;
+    const float* wob = wo + (size_t)b * M;
+    const int32_t* jqb = jq + (size_t)b * M;
+    for (int l = tid; l < M; l += nthr) step[l] = make_float4(wnb[l], wob[l], __int_as_float(jqb[l]), 0.0f);
+    __syncthreads();
+    float* acb = ac + (size_t)b * M * Mc;
+    const size_t capB = (size_t)M * (M + 1) / 2;
+    int32_t* offB = WITH_INDEX ? bwd_index + (size_t)b * ints_per_sample + (N + 1) + N : nullptr;
+    int32_t* entB_q = WITH_INDEX ? offB + N + 1 : nullptr;
+    float* entB_w = reinterpret_cast<float*>(entB_q + capB);
+
+    for (int j0 = 0; j0 < Mc; j0 += nthr) {                  // one pass for Mc <= 1024
+        const int j = j0 + tid;
+        float a = 0.0f;
+        int cnt = 0;
+        int keep_l[AC_KEEP];
+        float keep_w[AC_KEEP];
+#pragma unroll
+        for (int i = 0; i < AC_KEEP; ++i) { keep_l[i] = 0; keep_w[i] = 0.0f; }
+        if (j < Mc) {
 #pragma unroll 8
-    for (int l = 0; l < M; ++l) {
-        const float4 s = step[l];
-        a = a * s.x;
-        a = (__float_as_int(s.z) == j) ? a + s.y : a;
-        const float t = truncf(a);
-        if (t != 0.0f) { ent_q[e] = mpi[l]; ent_w[e] = t; ++e; }
+            for (int l = 0; l < M; ++l) {
+                const float4 s = step[l];
+                a = a * s.x;                                            // (:123)
+                a = (__float_as_int(s.z) == j) ? a + s.y : a;           // (:124)
+                acb[(size_t)l * Mc + j] = a;                            // (:125) compressed row l
+                if (WITH_INDEX) {
+                    const float t = truncf(a);
+                    if (t != 0.0f) {
+#pragma unroll
+                        for (int i = 0; i < AC_KEEP; ++i)
+                            if (cnt == i) { keep_l[i] = l; keep_w[i] = t; }
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        if (!WITH_INDEX) continue;
+        // exclusive scan of the survivor counts of this batch of columns (one column per thread), on top of the
+        // running total carried in offj[Mc] from the previous batch
+        __syncthreads();
+        int incl = cnt;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int t = __shfl_up(incl, s);
+            if (lane >= s) incl += t;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int off = (j0 == 0 ? 0 : offj[Mc]) + incl - cnt;
+        for (int w = 0; w < wv; ++w) off += wave_tot[w];
+        if (j < Mc) offj[j] = off;
+        __syncthreads();
+        if (tid == nthr - 1) {
+            int tot = j0 == 0 ? 0 : offj[Mc];
+            for (int w = 0; w < nwave; ++w) tot += wave_tot[w];
+            offj[Mc] = tot;
+        }
+        if (j < Mc && cnt > 0) {
+            if (cnt <= AC_KEEP) {
+#pragma unroll
+                for (int i = 0; i < AC_KEEP; ++i)
+                    if (i < cnt) { entB_q[off + i] = mpi[keep_l[i]]; entB_w[off + i] = keep_w[i]; }
+            } else {                                          // rare: many survivors in one column -> replay it
+                float a2 = 0.0f;
+                int e = off;
+                for (int l = 0; l < M; ++l) {
+                    const float4 s = step[l];
+                    a2 = a2 * s.x;
+                    a2 = (__float_as_int(s.z) == j) ? a2 + s.y : a2;
+                    const float t = truncf(a2);
+                    if (t != 0.0f) { entB_q[e] = mpi[l]; entB_w[e] = t; ++e; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!WITH_INDEX) return;
+    // offB[k] = survivors in columns < k: active column -> offj[rank], inactive -> offj[#active columns below]
+    for (int k = tid; k <= N; k += nthr) {
+        int r;
+        if (k < N) { const int rf = rankflag[(size_t)b * N + k]; r = rf >= 0 ? rf : -rf - 1; }
+        else r = mprime[b];
+        offB[k] = offj[r];
     }
 }
 
@@ -585,54 +602,51 @@ __global__ void __launch_bounds__(256) recon_masked_kernel(const float* __restri
 int launch_attention(const AttnArgs& a, hipStream_t st)
 {
     const int B = a.B, C = a.C, Cp = a.Cp, N = a.N, M = a.M, Mc = a.Mc;
-    const size_t cap = (size_t)(N - M) + (size_t)M * (M + 1) / 2;
-    const size_t ints = (size_t)N + 1 + 2 * cap;
-    if (M > 0) {
+    const size_t ints = 2 * ((size_t)N + 1) + (size_t)N + (size_t)M * (M + 1);     // ipsr_bwd_index_ints(N, M)
+    int nbits = 1;
+    while ((1 << nbits) < N) ++nbits;
+    {
         const int nch = cdiv(Cp, 512);
-        const size_t lds = (size_t)6 * (((M + 3) & ~3) + 3 * RING) * sizeof(int);
-        if (lds > 160 * 1024 - 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: M=%d too large for the recurrence's LDS index cache", M);
-#define LAUNCH_REC2(NCH, FULL)                                                                                       \
+        const size_t lds_rec = M > 0 ? (size_t)6 * (((M + 3) & ~3) + 3 * RING) * sizeof(int) : 0;
+        const size_t lds_prep = (size_t)4 * N * sizeof(int);
+        const size_t lds = lds_rec > lds_prep ? lds_rec : lds_prep;
+        if (lds > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: N=%d / M=%d too large for the stage kernel's LDS", N, M);
+        const int nrec = M > 0 ? B : 0;
+        const int grid = nrec + B + cdiv(N, 32) * cdiv(C, 32) * B;
+#define LAUNCH_STAGE2(NCH, FULL)                                                                                     \
     do {                                                                                                             \
         if (lds > 48 * 1024)                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&recurrence_kernel<NCH, FULL>),                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_stage_kernel<NCH, FULL>),             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
-        recurrence_kernel<NCH, FULL><<<B, 64, lds, st>>>(a.xT, a.inv, a.ind, a.vmax, a.mpi, Cp, N, M, a.wn, a.wo, a.kq); \
+        attention_stage_kernel<NCH, FULL><<<grid, 256, lds, st>>>(a, nrec, nbits, ints);                                          \
     } while (0)
-#define LAUNCH_REC(NCH)                                                                                              \
+#define LAUNCH_STAGE(NCH)                                                                                            \
     do {                                                                                                             \
-        if (Cp == 512 * (NCH)) LAUNCH_REC2(NCH, true);                                                               \
-        else LAUNCH_REC2(NCH, false);                                                                                \
+        if (Cp == 512 * (NCH)) LAUNCH_STAGE2(NCH, true);                                                             \
+        else LAUNCH_STAGE2(NCH, false);                                                                              \
     } while (0)
         switch (nch) {
-            case 1: LAUNCH_REC(1); break;
-            case 2: LAUNCH_REC(2); break;
-            case 3: LAUNCH_REC(3); break;
-            case 4: LAUNCH_REC(4); break;
+            case 1: LAUNCH_STAGE(1); break;
+            case 2: LAUNCH_STAGE(2); break;
+            case 3: LAUNCH_STAGE(3); break;
+            case 4: LAUNCH_STAGE(4); break;
             default: return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: C=%d > 2048 channels not supported", C);
         }
-#undef LAUNCH_REC
-#undef LAUNCH_REC2
-        if (int rc = check_launch("recurrence_kernel")) return rc;
+#undef LAUNCH_STAGE
+#undef LAUNCH_STAGE2
+        if (int rc = check_launch("attention_stage_kernel")) return rc;
     }
-    // non-masked columns first (masked ones are overwritten below)
-    recon_gather_kernel<<<dim3(cdiv(N, 32), cdiv(C, 32), B), 256, 0, st>>>(a.xT, a.ind, C, Cp, N, a.out);
-    if (int rc = check_launch("recon_gather_kernel")) return rc;
-
     const bool need_index = a.bwd_index != nullptr;
-    if (M > 0 || need_index) {
-        const size_t lds_prep = (size_t)3 * N * sizeof(int);
-        if (lds_prep > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: N=%d too large for attn_prepare_kernel", N);
-        if (lds_prep > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
-        attn_prepare_kernel<<<B, 1024, lds_prep, st>>>(a.ind, a.mpi, a.kq, N, M, Mc, a.dlist, a.mprime, a.jq, a.rankflag, a.onehot_cnt, a.col_cnt);
-        if (int rc = check_launch("attn_prepare_kernel")) return rc;
-    }
-    const size_t lds_steps = (size_t)4 * (M > 0 ? M : 1) * sizeof(int);
     if (M > 0) {
-        if (lds_steps > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: M=%d too large for attn_compress_kernel", M);
-        if (lds_steps > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_compress_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_steps);
-        attn_compress_kernel<<<dim3(cdiv(Mc, AC_COLS), B), AC_COLS, lds_steps, st>>>(a.wn, a.wo, a.jq, a.dlist, a.mprime, N, M, Mc, a.ac, a.surv_cnt, a.col_cnt);
+        const size_t lds_c = ((size_t)4 * M + Mc + 1) * sizeof(int);
+        if (lds_c > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: M=%d too large for attn_compress_kernel", M);
+        if (lds_c > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_compress_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_compress_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        }
+        const int nthr = Mc < AC_MAXT ? ((Mc + 63) & ~63) : AC_MAXT;
+        if (need_index) attn_compress_kernel<true><<<B, nthr, lds_c, st>>>(a.wn, a.wo, a.jq, a.mprime, a.rankflag, a.mpi, N, M, Mc, a.ac, a.bwd_index, ints);
+        else attn_compress_kernel<false><<<B, nthr, lds_c, st>>>(a.wn, a.wo, a.jq, a.mprime, a.rankflag, a.mpi, N, M, Mc, a.ac, nullptr, ints);
         if (int rc = check_launch("attn_compress_kernel")) return rc;
         recon_masked_kernel<<<dim3(cdiv(M, RM_BL), cdiv(C, RM_BC), B), 256, 0, st>>>(a.xT, a.ac, a.dlist, a.mprime, a.mpi, C, Cp, N, M, Mc, a.out);
         if (int rc = check_launch("recon_masked_kernel")) return rc;
@@ -640,20 +654,11 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
             attn_expand_kernel<<<dim3(cdiv(N, 256), M, B), 256, 0, st>>>(a.ac, a.rankflag, N, M, Mc, a.attn);
             if (int rc = check_launch("attn_expand_kernel")) return rc;
         }
-    }
-    if (need_index) {
-        index_scan_kernel<<<B, 1024, 0, st>>>(a.col_cnt, N, a.bwd_index, ints);
-        if (int rc = check_launch("index_scan_kernel")) return rc;
-        const size_t lds_fill = (size_t)(2 * N > 4 * M ? 2 * N : 4 * M) * sizeof(int);
-        if (lds_fill > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: N=%d too large for csr_fill_kernel", N);
-        if (lds_fill > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill);
-        int nbits = 1;
-        while ((1 << nbits) < N) ++nbits;
-        static const int dbg = getenv("IPSR_DEBUG_CSR") ? atoi(getenv("IPSR_DEBUG_CSR")) : 0;
-        csr_fill_kernel<<<dim3(dbg == 1 ? 1 : 1 + (M > 0 ? cdiv(Mc, AC_COLS) : 0), B), AC_COLS, lds_fill, st>>>(
-            a.ind, a.mpi, a.wn, a.wo, a.jq, a.dlist, a.mprime, a.onehot_cnt, a.surv_cnt, N, M, Mc, nbits, a.bwd_index, ints, cap);
-        if (int rc = check_launch("csr_fill_kernel")) return rc;
+    } else if (need_index) {
+        // nothing masked: the survivor CSR is empty (offB = 0)
+        for (int b = 0; b < B; ++b)
+            if (hipMemsetAsync(a.bwd_index + (size_t)b * ints + (N + 1) + N, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess)
+                return fail(IPSR_ERR_LAUNCH, "ipsr_forward: hipMemsetAsync failed");
     }
     return IPSR_OK;
 }

@@ -23,7 +23,7 @@ constexpr int BW_LDS_BYTES = 64 * 1024;
 // rows, so the output is written with coalesced stores.  HBM traffic = the algorithmic 2*C*N*4 bytes (+ index).
 template <int R>
 __global__ void __launch_bounds__(BW_THREADS) ipsr_backward_kernel(const float* __restrict__ g, const int32_t* __restrict__ bwd_index,
-                                                                   size_t ints_per_sample, size_t cap, float triple_w, int C, int N,
+                                                                   size_t ints_per_sample, size_t capB, float triple_w, int C, int N,
                                                                    float* __restrict__ gin)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];      // [R][N]
@@ -41,21 +41,27 @@ __global__ void __launch_bounds__(BW_THREADS) ipsr_backward_kernel(const float* 
     }
     __syncthreads();
 
-    const int32_t* col_off = bwd_index + (size_t)b * ints_per_sample;
-    const int32_t* ent_q = col_off + N + 1;
-    const float* ent_w = reinterpret_cast<const float*>(ent_q + cap);
+    const int32_t* offA = bwd_index + (size_t)b * ints_per_sample;
+    const int32_t* entA = offA + N + 1;
+    const int32_t* offB = entA + N;
+    const int32_t* entB_q = offB + N + 1;
+    const float* entB_w = reinterpret_cast<const float*>(entB_q + capB);
     for (int k = tid; k < N; k += BW_THREADS) {
-        const int e0 = col_off[k], e1 = col_off[k + 1];
         float acc[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) acc[i] = 0.0f;
         // column k of trunc(kbar)^T: one-hot rows first (weight 1, ascending q), then the masked rows that survive
-        // the truncation (ascending l) — one fmaf chain per output, the same order as the oracle
-        for (int e = e0; e < e1; ++e) {
-            const int q = ent_q[e];
-            const float wgt = ent_w[e];
+        // the truncation (ascending l) — one chain per output, the same order as the oracle
+        for (int e = offA[k], e1 = offA[k + 1]; e < e1; ++e) {
+            const int q = entA[e];
 #pragma unroll
-            for (int i = 0; i < R; ++i) acc[i] = __builtin_fmaf(wgt, rows[(size_t)i * N + q], acc[i]);   // rows past nrow: stale LDS, never stored
+            for (int i = 0; i < R; ++i) acc[i] = acc[i] + rows[(size_t)i * N + q];                       // rows past nrow: stale LDS, never stored
+        }
+        for (int e = offB[k], e1 = offB[k + 1]; e < e1; ++e) {
+            const int q = entB_q[e];
+            const float wgt = entB_w[e];
+#pragma unroll
+            for (int i = 0; i < R; ++i) acc[i] = __builtin_fmaf(wgt, rows[(size_t)i * N + q], acc[i]);
         }
 #pragma unroll
         for (int i = 0; i < R; ++i)
@@ -70,8 +76,8 @@ int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn
                     float triple_w, int B, int C, int N, float* gin, hipStream_t st)
 {
     (void)mpi; (void)attn;      // everything the backward needs is in bwd_index
-    const size_t cap = (size_t)(N - M) + (size_t)M * (M + 1) / 2;
-    const size_t ints = (size_t)N + 1 + 2 * cap;
+    const size_t capB = (size_t)M * (M + 1) / 2;
+    const size_t ints = 2 * ((size_t)N + 1) + (size_t)N + 2 * capB;
     int R = BW_ROWS;
     while (R > 1 && (size_t)R * N * sizeof(float) > BW_LDS_BYTES) R >>= 1;
     const size_t lds = (size_t)R * N * sizeof(float);
@@ -81,7 +87,7 @@ int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn
         if (lds > 48 * 1024)                                                                                       \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ipsr_backward_kernel<RR>),                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-        ipsr_backward_kernel<RR><<<dim3(cdiv(C, RR), B), BW_THREADS, lds, st>>>(g, bwd_index, ints, cap, triple_w, C, N, gin); \
+        ipsr_backward_kernel<RR><<<dim3(cdiv(C, RR), B), BW_THREADS, lds, st>>>(g, bwd_index, ints, capB, triple_w, C, N, gin); \
     } while (0)
     switch (R) {
         case 16: LAUNCH_BW(16); break;

@@ -48,11 +48,6 @@ __device__ unsigned long long g_probe[2 * 8192];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ bool better(float v1, int i1, float v0, int i0)
-{
-    return (v1 > v0) || (v1 == v0 && i1 < i0);
-}
-
 template <bool FAST, bool WRITE_S>
 __global__ void __launch_bounds__(NTHREADS, 2)
 corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, int C, int N,
@@ -414,7 +409,7 @@ size_t corr_argmax_ws_bytes(int B, int C, int N)
 }
 
 int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
-                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st)
+                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials)
 {
     int qt, kt, ks, kpw;
     plan(B, N, &qt, &kt, &ks, &kpw);
@@ -435,6 +430,12 @@ int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, i
     }
     profile_mark_stop(st);
     if (int rc = check_launch("corr_argmax_kernel")) return rc;
+    if (partials) {
+        partials->pval = pval;
+        partials->pidx = pidx;
+        partials->ksplit = ks;
+        return IPSR_OK;
+    }
     argmax_merge_kernel<<<cdiv(B * N, 256), 256, 0, st>>>(pval, pidx, B, N, ks, ind, vmax);
     return check_launch("argmax_merge_kernel");
 }

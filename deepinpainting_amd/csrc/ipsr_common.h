@@ -48,6 +48,31 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned wg, unsigned nwg)
     return start + slot;
 }
 
+// k-split partial (max, argmax) of the correlation kernel, merged on the fly by their consumers.
+struct CorrPartials {
+    const float* pval;     // [B, ksplit, N]
+    const int32_t* pidx;   // [B, ksplit, N]
+    int ksplit;
+};
+
+__device__ __forceinline__ bool better(float v1, int i1, float v0, int i0)
+{
+    return (v1 > v0) || (v1 == v0 && i1 < i0);
+}
+
+// arg-max over k of column q of sample b: fold the k-split partials in ascending k (lowest k on ties)
+__device__ __forceinline__ void merged_argmax(const CorrPartials& cp, int b, int N, int q, float& v, int& i)
+{
+    const size_t base = (size_t)b * cp.ksplit * N + q;
+    v = cp.pval[base];
+    i = cp.pidx[base];
+    for (int s = 1; s < cp.ksplit; ++s) {
+        const float vs = cp.pval[base + (size_t)s * N];
+        const int is = cp.pidx[base + (size_t)s * N];
+        if (better(vs, is, v, i)) { v = vs; i = is; }
+    }
+}
+
 // ---- device-side kernels' launchers (one per .hip file) ----
 int launch_feat_mask(const uint8_t* mask, int H, int W, int layers, float threshold, uint8_t* feat,
                      void* ws, size_t ws_bytes, hipStream_t st);
@@ -57,15 +82,18 @@ int launch_index_prep(const uint8_t* feat, int h, int w, int patch, int stride, 
 int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float* xT, int Cp, float* inv,
                            hipStream_t st);
 size_t corr_argmax_ws_bytes(int B, int C, int N);
+// partials != NULL: skip the merge kernel and hand the k-split partials to the caller (ind/vmax are then written by the
+// consumer that merges them: the attention stage kernel)
 int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
-                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st);
+                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials = nullptr);
 
 struct AttnArgs {
     const float* x;        // [B,C,N] raw features
     const float* xT;       // [B,N,Cp] patch-major raw copy, zero padded to Cp = roundup(C,8)
     const float* inv;      // [B,N]
-    const int32_t* ind;    // [B,N]
-    const float* vmax;     // [B,N]
+    int32_t* ind;          // [B,N]  written by the stage kernel (merged arg-max)
+    float* vmax;           // [B,N]
+    CorrPartials part;     // k-split partials of the correlation kernel
     const int32_t* mpi;    // [M]
     int B, C, Cp, N, M, Mc;   // Mc = roundup(M, 32): row stride of the compressed attention
     // workspace
@@ -75,10 +103,7 @@ struct AttnArgs {
     int32_t* jq;           // [B,M]   rank of kq[l] among the active columns
     int32_t* dlist;        // [B,Mc]  active columns, ascending k (padded with a valid patch index)
     int32_t* mprime;       // [B]     number of active columns
-    int32_t* rankflag;     // [B,N]   rank of column k among the active ones, or -1
-    int32_t* onehot_cnt;   // [B,N]   non-masked q with ind[q] == k
-    int32_t* surv_cnt;     // [B,Mc]  truncation survivors per active column
-    int32_t* col_cnt;      // [B,N]   entries of trunc(kbar) per column k
+    int32_t* rankflag;     // [B,N]   rank of column k among the active ones; inactive: -(#active columns below k) - 1
     float* ac;             // [B,M,Mc] compressed attention rows
     // outputs
     float* attn;           // [B,M,N] dense attention rows, optional (NULL = not materialised)

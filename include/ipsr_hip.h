@@ -82,12 +82,16 @@ int ipsr_corr_argmax(const float* xn, const float* ref, int B, int C, int N,
  *   out               [B,C,h,w] fp32
  *   ind, vmax         [B,N]     arg-max / max of the correlation (kept for inspection + backward)
  *   attn_rows         [B,M,N]   the reference's `in_attention` rows (IPSRFunction.py:76,123-125)
- *   bwd_index         [B, ipsr_bwd_index_ints(N,M)] i32: trunc(kbar) (the reference keeps kbar in a
- *                     LongTensor, IPSRFunction.py:36,134) in sparse form, per sample:
- *                       col_off[N+1] | ent_q[cap] | ent_w[cap] (fp32 bits),  cap = (N-M) + M(M+1)/2
- *                     column k lists every (q, W[q][k] != 0): first the non-masked q with ind[q]==k
- *                     (weight 1, ascending q), then the masked rows with |a_l[k]| >= 1 (weight
- *                     trunc(a_l[k]), ascending l).  Only the first col_off[N] entries are defined. */
+ *   bwd_index         [B, ipsr_bwd_index_ints(N,M)] i32, optional (NULL when no backward will follow):
+ *                     trunc(kbar) (the reference keeps kbar in a LongTensor, IPSRFunction.py:36,134) in
+ *                     sparse form, per sample two CSRs over the patch index k:
+ *                       offA[N+1] | entA_q[N]                    non-masked q with ind[q]==k (weight 1),
+ *                                                                ascending q; N-M entries
+ *                       offB[N+1] | entB_q[capB] | entB_w[capB]  masked rows with |a_l[k]| >= 1: q = mpi[l],
+ *                                                                weight trunc(a_l[k]) (fp32 bits), ascending l;
+ *                                                                capB = M(M+1)/2, offB[N] entries defined
+ *   attn_rows         optional as well (NULL = the dense rows are not materialised; the layer itself works
+ *                     on a compressed form). */
 size_t ipsr_bwd_index_ints(int N, int M);
 size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride);
 int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx, int M,

@@ -183,14 +183,13 @@ HOT static float lane_dot(const float* u, const float* o, int C)
     return p[0];
 }
 
-/* Sparse form of trunc(kbar) kept for the backward, per sample (int32 words):
- *   col_off[N+1]            CSR offsets over the patch index k
- *   ent_q[cap], ent_w[cap]  entries of column k = all (q, W[q][k]) with W[q][k] != 0:
- *                           first the non-masked q with ind[q] == k (weight 1), ascending q, then the masked rows
- *                           l (q = mask_point_idx[l], weight trunc(a_l[k])), ascending l.  ent_w holds fp32 bits.
- *   cap = (N - M) + M(M+1)/2  (row l of the attention has at most l+1 non-zeros). */
-static size_t bwd_cap(int N, int M) { return (size_t)(N - M) + (size_t)M * (M + 1) / 2; }
-size_t ipsr_bwd_index_ints_cpu(int N, int M) { return (size_t)N + 1 + 2 * bwd_cap(N, M); }
+/* Sparse form of trunc(kbar) kept for the backward, per sample (int32 words), two CSRs over the patch index k:
+ *   offA[N+1] | entA_q[N]                   the non-masked q with ind[q] == k (weight 1), ascending q (N-M entries)
+ *   offB[N+1] | entB_q[capB] | entB_w[capB] the masked rows l with trunc(a_l[k]) != 0: q = mask_point_idx[l],
+ *                                           weight trunc(a_l[k]) (fp32 bits), ascending l;  capB = M(M+1)/2
+ *                                           (row l of the attention has at most l+1 non-zeros). */
+static size_t bwd_capB(int M) { return (size_t)M * (M + 1) / 2; }
+size_t ipsr_bwd_index_ints_cpu(int N, int M) { return 2 * ((size_t)N + 1) + (size_t)N + 2 * bwd_capB(M); }
 
 /* ---- whole layer forward: IPSRFunction.forward (models/IPSRFunction.py:13-140) -------------- */
 HOT int ipsr_forward_cpu(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
@@ -258,30 +257,30 @@ HOT int ipsr_forward_cpu(const float* x, const float* ref, const int32_t* mask_p
         }
         /* sparse form of trunc(kbar) for the backward (:36,134 — kbar is stored in a LongTensor) */
         if (bwd_index) {
-            const size_t cap = bwd_cap(N, M);
-            int32_t* col_off = bwd_index + (size_t)b * ipsr_bwd_index_ints_cpu(N, M);
-            int32_t* ent_q = col_off + N + 1;
-            float* ent_w = (float*)(ent_q + cap);
-            for (int k = 0; k <= N; ++k) col_off[k] = 0;
-            for (int q = 0; q < N; ++q) if (!is_mask[q]) col_off[indb[q] + 1]++;
+            const size_t capB = bwd_capB(M);
+            int32_t* offA = bwd_index + (size_t)b * ipsr_bwd_index_ints_cpu(N, M);
+            int32_t* entA = offA + N + 1;
+            int32_t* offB = entA + N;
+            int32_t* entB_q = offB + N + 1;
+            float* entB_w = (float*)(entB_q + capB);
+            for (int k = 0; k <= N; ++k) { offA[k] = 0; offB[k] = 0; }
+            for (int q = 0; q < N; ++q) if (!is_mask[q]) offA[indb[q] + 1]++;
             for (int l = 0; l < M; ++l) {
                 const float* a = attn + (size_t)l * N;
-                for (int k = 0; k < N; ++k) if (truncf(a[k]) != 0.0f) col_off[k + 1]++;
+                for (int k = 0; k < N; ++k) if (truncf(a[k]) != 0.0f) offB[k + 1]++;
             }
-            for (int k = 0; k < N; ++k) col_off[k + 1] += col_off[k];
-            int32_t* fill = (int32_t*)calloc(N, sizeof(int32_t));
-            for (int q = 0; q < N; ++q) if (!is_mask[q]) {
-                const int k = indb[q], e = col_off[k] + fill[k]++;
-                ent_q[e] = q; ent_w[e] = 1.0f;
-            }
+            for (int k = 0; k < N; ++k) { offA[k + 1] += offA[k]; offB[k + 1] += offB[k]; }
+            int32_t* fillA = (int32_t*)calloc(N, sizeof(int32_t));
+            int32_t* fillB = (int32_t*)calloc(N, sizeof(int32_t));
+            for (int q = 0; q < N; ++q) if (!is_mask[q]) { const int k = indb[q]; entA[offA[k] + fillA[k]++] = q; }
             for (int l = 0; l < M; ++l) {
                 const float* a = attn + (size_t)l * N;
                 for (int k = 0; k < N; ++k) {
                     const float t = truncf(a[k]);
-                    if (t != 0.0f) { const int e = col_off[k] + fill[k]++; ent_q[e] = mask_point_idx[l]; ent_w[e] = t; }
+                    if (t != 0.0f) { const int e = offB[k] + fillB[k]++; entB_q[e] = mask_point_idx[l]; entB_w[e] = t; }
                 }
             }
-            free(fill);
+            free(fillA); free(fillB);
         }
     }
     free(is_mask); free(o); free(u); free(kk); free(xn); free(inv);
@@ -294,18 +293,21 @@ int ipsr_backward_cpu(const float* g, const int32_t* mask_point_idx, int M, cons
 {
     if (!g || !gin || !bwd_index || B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return IPSR_ERR_INVALID;
     const int N = h * w;
-    const size_t cap = bwd_cap(N, M);
+    const size_t capB = bwd_capB(M);
     (void)mask_point_idx; (void)attn_rows;   /* everything the backward needs is in bwd_index */
     for (int b = 0; b < B; ++b) {
-        const int32_t* col_off = bwd_index + (size_t)b * ipsr_bwd_index_ints_cpu(N, M);
-        const int32_t* ent_q = col_off + N + 1;
-        const float* ent_w = (const float*)(ent_q + cap);
+        const int32_t* offA = bwd_index + (size_t)b * ipsr_bwd_index_ints_cpu(N, M);
+        const int32_t* entA = offA + N + 1;
+        const int32_t* offB = entA + N;
+        const int32_t* entB_q = offB + N + 1;
+        const float* entB_w = (const float*)(entB_q + capB);
         for (int c = 0; c < C; ++c) {
             const float* gr = g + ((size_t)b * C + c) * N;
             float* go = gin + ((size_t)b * C + c) * N;
             for (int k = 0; k < N; ++k) {
                 float acc = 0.0f;
-                for (int e = col_off[k]; e < col_off[k + 1]; ++e) acc = fmaf(ent_w[e], gr[ent_q[e]], acc);
+                for (int e = offA[k]; e < offA[k + 1]; ++e) acc = acc + gr[entA[e]];                      /* one-hot rows :129 */
+                for (int e = offB[k]; e < offB[k + 1]; ++e) acc = fmaf(entB_w[e], gr[entB_q[e]], acc);   /* truncated masked rows */
                 const float t = acc * triple_w;                                                 /* :173 */
                 go[k] = gr[k] + t;
             }

@@ -46,7 +46,7 @@ def test_binding_table_matches_header(built):
 
 def test_host_side_queries_and_argument_errors(built):
     L = built.lib()
-    assert L.ipsr_bwd_index_ints(1024, 256) == 1024 + 1 + 2 * ((1024 - 256) + 256 * 257 // 2)
+    assert L.ipsr_bwd_index_ints(1024, 256) == 2 * 1025 + 1024 + 2 * (256 * 257 // 2)
     assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 1, 1) > 8 * 512 * 1024 * 4 * 2
     assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 3, 1) == 0          # unsupported patch size
     assert L.ipsr_feat_mask_workspace_bytes(256, 256, 3) >= 2 * 128 * 128 * 4

@@ -142,13 +142,17 @@ def test_argmax_ties_lowest_index(ops):
 
 # ------------------------------------------------------------------------------------------ whole layer
 def used_index(bwd_index, N, M):
-    """The defined part of the sparse trunc(kbar): col_off[N+1] + the first col_off[N] entries (q, weight bits)."""
+    """The defined part of the sparse trunc(kbar): offA, the N-M one-hot entries, offB, the offB[N] survivor (q, weight bits)."""
     bi = bwd_index if isinstance(bwd_index, np.ndarray) else bwd_index.cpu().numpy()
-    cap = (N - M) + M * (M + 1) // 2
+    capB = M * (M + 1) // 2
     out = []
     for row in bi:
-        tot = int(row[N])
-        out.append(np.concatenate([row[:N + 1], row[N + 1:N + 1 + tot], row[N + 1 + cap:N + 1 + cap + tot]]))
+        offA, entA = row[:N + 1], row[N + 1:2 * N + 1]
+        offB = row[2 * N + 1:3 * N + 2]
+        nb = int(offB[N])
+        entBq = row[3 * N + 2:3 * N + 2 + nb]
+        entBw = row[3 * N + 2 + capB:3 * N + 2 + capB + nb]
+        out.append(np.concatenate([offA, entA[:N - M], offB, entBq, entBw]))
     return out
 
 
@@ -216,7 +220,7 @@ def test_layer_truncation_survivors(ops):
     d = load("layer_c16_8x8_signed")
     fo = orc.forward(d["x"], d["ref"], d["mask_point_idx"])
     N, M = 64, len(d["mask_point_idx"])
-    assert (fo.bwd_index[:, N] > N - M + 1).any(), "fixture should have truncation survivors beyond row 0"
+    assert (fo.bwd_index[:, 3 * N + 1] > 1).any(), "fixture should have truncation survivors beyond row 0"
     gin_o = orc.backward(d["grad_out"], d["mask_point_idx"], fo.attn_rows, fo.bwd_index, 1.0)
     f, gin = run_hip_layer(ops, d["x"], d["ref"], d["mask_point_idx"], 1.0, d["grad_out"])
     assert_index_equal(f.bwd_index, fo.bwd_index, N, M)

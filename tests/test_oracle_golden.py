@@ -90,9 +90,10 @@ def test_forward_backward_vs_reference(name):
     # backward: the sparse trunc(kbar) has exactly as many entries as the reference's LongTensor has non-zeros
     M = d["mask_point_idx"].shape[0]
     for b in range(B):
-        col_off = f.bwd_index[b, :N + 1]
-        assert col_off[0] == 0 and (np.diff(col_off) >= 0).all()
-        assert col_off[N] == d["trunc_kbar_nnz"][b]
+        offA = f.bwd_index[b, :N + 1]
+        offB = f.bwd_index[b, 2 * N + 1:3 * N + 2]
+        assert offA[0] == 0 and offB[0] == 0 and (np.diff(offA) >= 0).all() and (np.diff(offB) >= 0).all()
+        assert offA[N] == N - M and offA[N] + offB[N] == d["trunc_kbar_nnz"][b]
     gin = orc.backward(d["grad_out"], d["mask_point_idx"], f.attn_rows, f.bwd_index, float(d["triple_w"]))
     gin = gin if "grad_in_channels" not in d else gin[:, d["grad_in_channels"]]
     err = np.abs(gin - d["grad_in"]).max()
