@@ -192,6 +192,11 @@ def main():
         if rank == 0:
             print("[bench] warm-up step %d/%d done (%.1f s since start)" % (i + 1, args.warmup, time.perf_counter() - T_START),
                   file=sys.stderr, flush=True)
+    # A CPython gen-2 collection walks every live object (the module trees, ~100 ms here) and would land inside one
+    # timed step (measured: one 123 ms step in every ~25).  Collect now and freeze the survivors out of future scans.
+    import gc
+    gc.collect()
+    gc.freeze()
     lib.ipsr_profile_enable(max(args.steps, 1))
     torch.cuda.synchronize()
     if world > 1:

@@ -16,6 +16,8 @@ namespace ipsr {
 constexpr int BW_THREADS = 256;
 constexpr int BW_ROWS = 16;               // channel rows per workgroup (LDS-resident), fewer when N is large
 constexpr int BW_LDS_BYTES = 64 * 1024;
+constexpr int BW_INLINE = 8;               // entry lists up to this length are finished by the column's own thread
+constexpr int BW_MAXLONG = 512;            // deferred (long) columns per workgroup
 
 // One workgroup = R channel rows of one sample.  The rows (R x N fp32) are staged once into LDS with coalesced
 // 16-byte loads — that is the ONLY read of grad_out from HBM/L2 — and every gathered g[c][q] of the scatter-add
@@ -46,18 +48,32 @@ __global__ void __launch_bounds__(BW_THREADS) ipsr_backward_kernel(const float* 
     const int32_t* offB = entA + N;
     const int32_t* entB_q = offB + N + 1;
     const float* entB_w = reinterpret_cast<const float*>(entB_q + capB);
+
+    // Columns whose entry list is long (real training features are signed: attention weights leave [0,1] and a few
+    // columns collect hundreds of truncation survivors — measured up to ~220 of 256 rows) are deferred to a second
+    // phase where every (column, channel row) chain gets its own lane; short columns are finished inline.
+    __shared__ int long_k[BW_MAXLONG];
+    __shared__ int n_long;
+    if (tid == 0) n_long = 0;
+    __syncthreads();
+
     for (int k = tid; k < N; k += BW_THREADS) {
+        const int a0 = offA[k], a1 = offA[k + 1], b0 = offB[k], b1 = offB[k + 1];
+        if ((a1 - a0) + (b1 - b0) > BW_INLINE) {
+            const int slot = atomicAdd(&n_long, 1);
+            if (slot < BW_MAXLONG) { long_k[slot] = k; continue; }       // else: list full, fall through and do it inline
+        }
         float acc[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) acc[i] = 0.0f;
         // column k of trunc(kbar)^T: one-hot rows first (weight 1, ascending q), then the masked rows that survive
         // the truncation (ascending l) — one chain per output, the same order as the oracle
-        for (int e = offA[k], e1 = offA[k + 1]; e < e1; ++e) {
+        for (int e = a0; e < a1; ++e) {
             const int q = entA[e];
 #pragma unroll
             for (int i = 0; i < R; ++i) acc[i] = acc[i] + rows[(size_t)i * N + q];                       // rows past nrow: stale LDS, never stored
         }
-        for (int e = offB[k], e1 = offB[k + 1]; e < e1; ++e) {
+        for (int e = b0; e < b1; ++e) {
             const int q = entB_q[e];
             const float wgt = entB_w[e];
 #pragma unroll
@@ -69,6 +85,20 @@ __global__ void __launch_bounds__(BW_THREADS) ipsr_backward_kernel(const float* 
                 const float t = acc[i] * triple_w;             // (:173) mul then add, separately rounded
                 ob[(size_t)i * N + k] = rows[(size_t)i * N + k] + t;
             }
+    }
+    __syncthreads();
+    // phase 2: one lane per (long column, channel row); the chain itself stays sequential (same bits as phase 1)
+    const int nl = min(n_long, BW_MAXLONG);
+    for (int idx = tid; idx < nl * R; idx += BW_THREADS) {
+        const int k = long_k[idx / R], i = idx % R;
+        if (i >= nrow) continue;
+        const float* row = rows + (size_t)i * N;
+        float acc = 0.0f;
+        for (int e = offA[k], e1 = offA[k + 1]; e < e1; ++e) acc = acc + row[entA[e]];
+#pragma unroll 4
+        for (int e = offB[k], e1 = offB[k + 1]; e < e1; ++e) acc = __builtin_fmaf(entB_w[e], row[entB_q[e]], acc);
+        const float t = acc * triple_w;
+        ob[(size_t)i * N + k] = row[k] + t;
     }
 }
 

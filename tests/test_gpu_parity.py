@@ -328,3 +328,36 @@ def test_error_behaviour(ops):
         ops.forward(x.cpu(), x.cpu(), mpi)
     with pytest.raises(RuntimeError):
         ops.forward(x, torch.zeros(1, 8, 4, 4, device="cuda"), mpi)
+
+
+def test_layer_signed_long_survivor_columns(ops):
+    """Signed features (what the conv stack feeds the layer in training): attention weights leave [0,1] and a few
+    columns collect many |a| >= 1 entries.  Exercises the compress kernel's replay path (> 4 survivors in a column)
+    and the backward's cooperative long-column phase (> 8 entries); everything still bit-exact vs the oracle."""
+    rs = np.random.RandomState(21)
+    B, C, h, w = 2, 64, 16, 16
+    N = h * w
+    best = None
+    for seed in range(8):
+        rs = np.random.RandomState(100 + seed)
+        x = rs.standard_normal((B, C, h, w)).astype(np.float32)
+        ref = rs.standard_normal((B, C, h, w)).astype(np.float32)
+        feat = np.zeros((h, w), np.uint8)
+        feat[3:13, 2:14] = 1
+        mpi = orc.index_prep(feat).mask_point_idx
+        fo = orc.forward(x, ref, mpi)
+        offB = fo.bwd_index[:, 2 * N + 1:3 * N + 2]
+        longest = int((offB[:, 1:] - offB[:, :-1]).max())
+        if best is None or longest > best[0]:
+            best = (longest, x, ref, mpi, fo)
+        if longest > 12:
+            break
+    longest, x, ref, mpi, fo = best
+    assert longest > 8, "need a column with a long survivor list to exercise the cooperative path (got %d)" % longest
+    g = rs.standard_normal(x.shape).astype(np.float32)
+    gin_o = orc.backward(g, mpi, fo.attn_rows, fo.bwd_index, 1.0)
+    f, gin = run_hip_layer(ops, x, ref, mpi, 1.0, g)
+    assert_index_equal(f.bwd_index, fo.bwd_index, N, len(mpi))
+    np.testing.assert_array_equal(f.attn_rows.cpu().numpy(), fo.attn_rows)
+    np.testing.assert_array_equal(f.out.cpu().numpy(), fo.out)
+    np.testing.assert_array_equal(gin.cpu().numpy(), gin_o)

@@ -35,7 +35,7 @@ def main():
         rd_b, wr_b = 2.0 * f * 1024.0, wr * 1024.0
         out[k] = rd_b + wr_b
         w.writerow([k, round(f, 1), round(wr, 1), int(rd_b), int(wr_b), int(rd_b + wr_b)])
-    key = [k for k in out if "corr_argmax_kernel" in k]
+    key = [k for k in out if "corr_argmax" in k]
     if key:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         with open(os.path.join(root, "profiles", "traffic_corr_argmax.json"), "w") as fh:
