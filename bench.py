@@ -177,6 +177,7 @@ def main():
     torch.backends.cudnn.benchmark = os.environ.get("IPSR_BENCH_MIOPEN_FIND", "0") == "1"
 
     opt = Option(gpu_ids=[local_rank], batchSize=args.batch, use_dropout=True, quiet=True,
+                 batch_vgg=os.environ.get("IPSR_BENCH_BATCH_VGG", "0") == "1",
                  checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
     torch.manual_seed(1234)                       # identical init on every rank (rank 0 is broadcast anyway)
     model = quiet(create_model, opt)

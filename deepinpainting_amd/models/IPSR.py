@@ -37,6 +37,7 @@ class IPSR(BaseModel):
         self.opt = opt
         self.isTrain = opt.isTrain
         self.strict_reference = bool(getattr(opt, 'strict_reference', False))
+        self.batch_vgg = bool(getattr(opt, 'batch_vgg', False))
 
         self.vgg = Vgg16(requires_grad=False, weights_path=getattr(opt, 'vgg16_weights', None)).to(self.device)
         self.vgg.eval()
@@ -140,14 +141,31 @@ class IPSR(BaseModel):
         self.Cosis_list[0].set_mask(mask_global, self.opt, feat_mask=shared)
         self.Cosis_list2[0].set_mask(mask_global, self.opt, feat_mask=shared)
 
-    def set_ref_latent(self):
+    def _vgg_ref_and_gt(self):
+        """VGG features of the reference image and of the ground truth in ONE [2B] pass (both are known after
+        set_input; the reference runs two [B] passes, models/IPSR.py:163,187).  Per-sample results are unchanged."""
+        from .vgg16 import VggOutputs
+        B = self.input_ref.size(0)
         with torch.no_grad():
-            self.ref_latent = self.vgg(self.input_ref)
+            both = self.vgg(torch.cat((self.input_ref, self.input_B), 0))
+        self._ref_latent_cache = VggOutputs(*[t[:B] for t in both])
+        self._gt_latent = VggOutputs(*[t[B:] for t in both])
+
+    def set_ref_latent(self):
+        if self.batch_vgg and not self.strict_reference:
+            self._vgg_ref_and_gt()
+            self.ref_latent = self._ref_latent_cache
+        else:
+            with torch.no_grad():
+                self.ref_latent = self.vgg(self.input_ref)
         self.CSA_model[0].set_ref(self.ref_latent)
 
     def set_gt_latent(self):
-        with torch.no_grad():
-            gt_latent = self.vgg(self.input_B)
+        if self._gt_latent is not None and self.batch_vgg and not self.strict_reference:
+            gt_latent = self._gt_latent                  # computed together with the reference features
+        else:
+            with torch.no_grad():
+                gt_latent = self.vgg(self.input_B)
         self._gt_latent = gt_latent
         self.Cosis_list[0].set_target(gt_latent.relu4_3)
         self.Cosis_list2[0].set_target(gt_latent.relu4_3)

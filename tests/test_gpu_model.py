@@ -269,3 +269,60 @@ def test_trainer_data_parallel_two_ranks(tmp_path):
         assert torch.equal(a[tag]["w"], b[tag]["w"]), "net%s weights diverged across ranks" % tag
     # the losses differ (different data) — proves the ranks really saw different batches
     assert a["errors"]["G_L1"] != b["errors"]["G_L1"]
+
+
+def test_notebook_flow_through_package_alias(tmp_path):
+    """with `models` / `util` aliased to this package, the reference's train.ipynb cell flow
+    (cell 0 Option bag, cell 1 `from models.models import create_model`, cell 2 loop body) runs unchanged."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, os
+sys.path.insert(0, %r)
+import deepinpainting_amd.models as _m, deepinpainting_amd.util as _u
+sys.modules["models"], sys.modules["util"] = _m, _u
+for _n in ("models", "IPSR", "IPSR_model", "IPSRFunction", "InnerCos", "InnerCos2", "networks", "base_model", "vgg16"):
+    __import__("deepinpainting_amd.models." + _n); sys.modules["models." + _n] = sys.modules["deepinpainting_amd.models." + _n]
+for _n in ("util", "NonparametricShift", "MaxCoord"):
+    __import__("deepinpainting_amd.util." + _n); sys.modules["util." + _n] = sys.modules["deepinpainting_amd.util." + _n]
+
+# ---- train.ipynb cell 0 (the fields the models read; paths replaced)
+class Option():
+    def __init__(self):
+        self.batchSize = 1; self.fineSize = 256; self.input_nc = 3; self.input_nc_g = 6; self.output_nc = 3
+        self.ngf = 64; self.ndf = 64; self.which_model_netD = 'basic'; self.which_model_netF = 'feature'
+        self.which_model_netG = 'unet_ipsr'; self.which_model_netP = 'unet_256'; self.triple_weight = 1
+        self.name = 'IPSR_inpainting'; self.n_layers_D = '3'; self.gpu_ids = [0]; self.model = 'ipsr_net'
+        self.checkpoints_dir = %r; self.norm = 'instance'; self.fixed_mask = 1; self.use_dropout = True
+        self.init_type = 'normal'; self.mask_type = 'random'; self.lambda_A = 100; self.threshold = 5 / 16.0
+        self.stride = 1; self.shift_sz = 1; self.mask_thred = 1; self.bottleneck = 512; self.gp_lambda = 10.0
+        self.ncritic = 5; self.constrain = 'MSE'; self.strength = 1; self.init_gain = 0.02; self.cosis = 1
+        self.gan_type = 'lsgan'; self.gan_weight = 0.2; self.overlap = 4; self.skip = 0; self.continue_train = False
+        self.epoch_count = 1; self.phase = 'train'; self.which_epoch = ''; self.niter = 20; self.niter_decay = 100
+        self.beta1 = 0.5; self.lr = 0.0002; self.lr_policy = 'lambda'; self.lr_decay_iters = 50; self.isTrain = True
+
+# ---- cell 1
+from models.models import create_model
+import torch
+opt = Option()
+model = create_model(opt)
+# ---- cell 2, loop body (one synthetic batch instead of the DataLoader)
+image = torch.rand(1, 3, 256, 256) * 2 - 1
+mask = torch.zeros(1, 1, 256, 256); mask[:, :, 40:200, 90:170] = 1
+ref = torch.rand(1, 3, 256, 256) * 2 - 1
+image = image.cuda(); mask = mask.cuda()
+mask = mask[0][0]; mask = torch.unsqueeze(mask, 0); mask = torch.unsqueeze(mask, 1); mask = mask.bool()
+model.set_input(image, mask, ref)
+model.set_ref_latent()
+model.set_gt_latent()
+model.optimize_parameters()
+tl = model.get_loss().get('GAN')
+model.save(1)
+model.update_learning_rate()
+assert tl == tl and len(model.get_current_visuals()) == 5
+print("NOTEBOOK_FLOW_OK", tl)
+""" % (root, str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert "NOTEBOOK_FLOW_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert sorted(os.listdir(os.path.join(str(tmp_path), "IPSR_inpainting"))) == ['1_net_D.pt', '1_net_F.pt', '1_net_G.pt', '1_net_P.pt']
