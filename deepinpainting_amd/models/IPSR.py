@@ -38,6 +38,9 @@ class IPSR(BaseModel):
         self.isTrain = opt.isTrain
         self.strict_reference = bool(getattr(opt, 'strict_reference', False))
         self.batch_vgg = bool(getattr(opt, 'batch_vgg', False))
+        # BASELINE config 5: convolutions under bf16 autocast (CDNA4 bf16 MFMA); the IPSR layer, the InnerCos taps and all
+        # losses stay fp32.  Off by default — the reference is fp32.
+        self.amp_bf16 = bool(getattr(opt, 'amp_bf16', False))
 
         self.vgg = Vgg16(requires_grad=False, weights_path=getattr(opt, 'vgg16_weights', None)).to(self.device)
         self.vgg.eval()
@@ -115,6 +118,9 @@ class IPSR(BaseModel):
                     networks.print_network(net)
                 print('-----------------------------------------------')
 
+    def _amp(self):
+        return torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=self.amp_bf16 and self.device.type == 'cuda')
+
     def set_isTrain(self):
         self.isTrain = True
 
@@ -158,7 +164,7 @@ class IPSR(BaseModel):
         set_input; the reference runs two [B] passes, models/IPSR.py:163,187).  Per-sample results are unchanged."""
         from .vgg16 import VggOutputs
         B = self.input_ref.size(0)
-        with torch.no_grad():
+        with torch.no_grad(), self._amp():
             both = self.vgg(torch.cat((self.input_ref, self.input_B), 0))
         self._ref_latent_cache = VggOutputs(*[t[:B] for t in both])
         self._gt_latent = VggOutputs(*[t[B:] for t in both])
@@ -168,7 +174,7 @@ class IPSR(BaseModel):
             self._vgg_ref_and_gt()
             self.ref_latent = self._ref_latent_cache
         else:
-            with torch.no_grad():
+            with torch.no_grad(), self._amp():
                 self.ref_latent = self.vgg(self.input_ref)
         self.CSA_model[0].set_ref(self.ref_latent)
 
@@ -176,7 +182,7 @@ class IPSR(BaseModel):
         if self._gt_latent is not None and self.batch_vgg and not self.strict_reference:
             gt_latent = self._gt_latent                  # computed together with the reference features
         else:
-            with torch.no_grad():
+            with torch.no_grad(), self._amp():
                 gt_latent = self.vgg(self.input_B)
         self._gt_latent = gt_latent
         self.Cosis_list[0].set_target(gt_latent.relu4_3)
@@ -185,13 +191,17 @@ class IPSR(BaseModel):
     # ------------------------------------------------------------------------------------------------
     def _two_stage(self):
         self.real_A = self.input_A.to(self.device)                                   # alias of input_A
-        self.fake_P = self.netP(self.real_A)
+        with self._amp():
+            self.fake_P = self.netP(self.real_A)
+        self.fake_P = self.fake_P.float()
         self.un = self.fake_P.clone()
         self.Unknowregion = self.un.data.masked_fill_(self.inv_ex_mask, 0)           # rough result inside the hole
         self.knownregion = self.real_A.data.masked_fill_(self.ex_mask, 0)            # NB zeroes input_A's hole in place
         self.Syn = self.Unknowregion + self.knownregion
         self.Middle = torch.cat((self.Syn, self.input_A), 1)
-        self.fake_B = self.netG(self.Middle)
+        with self._amp():
+            self.fake_B = self.netG(self.Middle)
+        self.fake_B = self.fake_B.float()
         self.real_B = self.input_B.to(self.device)
         self.real_Ref = self.input_ref.to(self.device)
 
@@ -208,7 +218,7 @@ class IPSR(BaseModel):
 
     def backward_D(self):
         fake_AB = self.fake_B
-        with torch.no_grad():
+        with torch.no_grad(), self._amp():
             self.gt_latent_fake = self.vgg(self.fake_B.data)
             if self._gt_latent is not None and not self.strict_reference:
                 self.gt_latent_real = self._gt_latent                               # same features as :213 recomputes
@@ -216,12 +226,12 @@ class IPSR(BaseModel):
                 self.gt_latent_real = self.vgg(self.input_B)
         real_AB = self.real_B
 
-        self.pred_fake = self.netD(fake_AB.detach())
-        self.pred_real = self.netD(real_AB)
+        with self._amp():
+            self.pred_fake = self.netD(fake_AB.detach()).float()
+            self.pred_real = self.netD(real_AB).float()
+            self.pred_fake_F = self.netF(self.gt_latent_fake.relu3_3.detach()).float()
+            self.pred_real_F = self.netF(self.gt_latent_real.relu3_3).float()
         self.loss_D_fake = self.criterionGAN(self.pred_fake, self.pred_real, True)
-
-        self.pred_fake_F = self.netF(self.gt_latent_fake.relu3_3.detach())
-        self.pred_real_F = self.netF(self.gt_latent_real.relu3_3)
         self.loss_F_fake = self.criterionGAN(self.pred_fake_F, self.pred_real_F, True)
 
         self.loss_D = self.loss_D_fake * 0.5 + self.loss_F_fake * 0.5
@@ -232,10 +242,11 @@ class IPSR(BaseModel):
             self._reducer_D.finish()
 
     def backward_G(self):
-        pred_fake = self.netD(self.fake_B)
-        pred_fake_f = self.netF(self.gt_latent_fake.relu3_3)
-        pred_real = self.netD(self.real_B)
-        pred_real_F = self.netF(self.gt_latent_real.relu3_3)
+        with self._amp():
+            pred_fake = self.netD(self.fake_B).float()
+            pred_fake_f = self.netF(self.gt_latent_fake.relu3_3).float()
+            pred_real = self.netD(self.real_B).float()
+            pred_real_F = self.netF(self.gt_latent_real.relu3_3).float()
 
         self.loss_G_GAN = self.criterionGAN(pred_fake, pred_real, False) + self.criterionGAN(pred_fake_f, pred_real_F, False)
         self.loss_G_L1 = (self.criterionL1(self.fake_B, self.real_B) + self.criterionL1(self.fake_P, self.real_B)) * self.opt.lambda_A

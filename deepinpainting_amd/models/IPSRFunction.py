@@ -31,7 +31,10 @@ class IPSRFunction(torch.autograd.Function):
             mpi32 = mask_point_idx.to(device=input.device, dtype=torch.int32)
         # `ref` is the VGG namedtuple; only relu4_3 is read (reference :49)
         need_grad = ctx.needs_input_grad[0]      # grad mode is off inside Function.forward, so ask the ctx
-        f = ops.forward(input.detach(), ref.relu4_3.detach(), mpi32, int(shift_sz), int(stride), want_index=need_grad)
+        # the layer itself is fp32 whatever the surrounding autocast regime (BASELINE config 5 runs the convs in bf16)
+        ctx.in_dtype = input.dtype
+        f = ops.forward(input.detach().float(), ref.relu4_3.detach().float(), mpi32, int(shift_sz), int(stride),
+                        want_index=need_grad)
         ctx.M = int(mpi32.numel())
         ctx.bwd_index = f.bwd_index        # sparse trunc(kbar)  (the reference keeps the dense ctx.ind_lst, :139)
         ctx.ind = f.ind
@@ -40,5 +43,5 @@ class IPSRFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        grad_input = ops.backward(grad_output, ctx.bwd_index, ctx.triple_w, ctx.M)
+        grad_input = ops.backward(grad_output.float(), ctx.bwd_index, ctx.triple_w, ctx.M).to(ctx.in_dtype)
         return grad_input, None, None, None, None, None, None, None, None, None, None, None

@@ -17,14 +17,16 @@ from ..util import util
 class _InnerCosLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cuse, mask, target, strength):
-        ctx.save_for_backward(x, mask, target)
-        ctx.cuse, ctx.strength = cuse, strength
-        return ops.innercos_loss(x.detach(), cuse, mask, target, strength)
+        xf, tf = x.detach().float(), target.detach().float()       # fp32 whatever the surrounding autocast regime
+        ctx.save_for_backward(xf, mask, tf)
+        ctx.cuse, ctx.strength, ctx.in_dtype = cuse, strength, x.dtype
+        return ops.innercos_loss(xf, cuse, mask, tf, strength)
 
     @staticmethod
     def backward(ctx, grad_loss):
         x, mask, target = ctx.saved_tensors
-        return ops.innercos_loss_backward(x, ctx.cuse, mask, target, ctx.strength, grad_loss), None, None, None, None
+        g = ops.innercos_loss_backward(x, ctx.cuse, mask, target, ctx.strength, grad_loss.float())
+        return g.to(ctx.in_dtype), None, None, None, None
 
 
 class InnerCos(nn.Module):

@@ -326,3 +326,26 @@ print("NOTEBOOK_FLOW_OK", tl)
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert "NOTEBOOK_FLOW_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert sorted(os.listdir(os.path.join(str(tmp_path), "IPSR_inpainting"))) == ['1_net_D.pt', '1_net_F.pt', '1_net_G.pt', '1_net_P.pt']
+
+
+def test_trainer_bf16_autocast_config5(tmp_path):
+    """BASELINE config 5: convs under bf16 autocast, the IPSR layer / InnerCos / losses in fp32.  Same weights and
+    inputs as an fp32 trainer: the first-step losses agree within bf16 noise and training proceeds (finite, weights move)."""
+    from deepinpainting_amd.options import Option
+    from deepinpainting_amd.models.models import create_model
+    losses = {}
+    for amp in (False, True):
+        opt = Option(gpu_ids=[0], batchSize=2, use_dropout=False, quiet=True, amp_bf16=amp, checkpoints_dir=str(tmp_path))
+        m = quiet(create_model, opt)
+        for i, net in enumerate((m.netG, m.netP, m.netD, m.netF, m.vgg)):
+            golden_cases.reinit_deterministic(net, 700 + i)
+        img, mask, ref = golden_cases.trainer_inputs(B=2)
+        m.set_input(img.cuda(), mask.cuda(), ref.cuda())
+        m.set_ref_latent()
+        m.set_gt_latent()
+        m.optimize_parameters()
+        e = m.get_current_errors()
+        losses[amp] = [e['G_GAN'], e['G_L1'], e['D'], e['F'], float(m.ng_loss_value)]
+        assert m.fake_B.dtype == torch.float32 and m.netG.model.model[0].weight.dtype == torch.float32
+        assert all(np.isfinite(v) for v in losses[amp])
+    np.testing.assert_allclose(losses[True], losses[False], rtol=0.08)
