@@ -58,24 +58,32 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 struct FwdPlan {
     int N, Cp, Mc;
+    int K, ld;         // patch length C*p*p and the row stride of the unfolded operands (p > 1: N rounded up to 128)
     size_t total;
 };
 
 // workspace slices in carve order (all 256-B aligned)
-enum { WS_XN, WS_XT, WS_INV, WS_CORR, WS_WN, WS_WO, WS_KQ, WS_JQ, WS_DLIST, WS_MPRIME, WS_RANKFLAG, WS_AC, WS_COUNT };
+enum { WS_XN, WS_XT, WS_INV, WS_CORR, WS_WN, WS_WO, WS_KQ, WS_JQ, WS_DLIST, WS_MPRIME, WS_RANKFLAG, WS_AC,
+       WS_XU, WS_RU, WS_OU, WS_COUNT };
 
-static FwdPlan plan_forward(int B, int C, int h, int w, int M, size_t* sizes)
+// patch == 1: the feature IS the patch matrix.  patch > 1: C/N below are the unfolded K = C*p*p and the window grid
+// N' = (h-p+1)(w-p+1); three more slices hold the unfolded x, the unfolded ref and the un-folded result.
+static FwdPlan plan_forward(int B, int C, int h, int w, int M, int patch, size_t* sizes)
 {
     FwdPlan p;
-    p.N = h * w;
-    p.Cp = (C + 7) & ~7;
+    p.K = C * patch * patch;
+    p.N = (h - patch + 1) * (w - patch + 1);
+    p.ld = patch > 1 ? (p.N + 127) & ~127 : p.N;
+    p.Cp = (p.K + 7) & ~7;
     p.Mc = M > 0 ? (M + 31) & ~31 : 32;
     const size_t Mx = M > 0 ? M : 1;
     size_t sz[WS_COUNT];
-    sz[WS_XN] = (size_t)B * C * p.N * 4;
+    sz[WS_XN] = (size_t)B * p.K * p.ld * 4;
     sz[WS_XT] = (size_t)B * p.N * p.Cp * 4;
     sz[WS_INV] = (size_t)B * p.N * 4;
-    sz[WS_CORR] = corr_argmax_ws_bytes(B, C, p.N);
+    sz[WS_CORR] = corr_argmax_ws_bytes(B, p.K, p.N);
+    sz[WS_XU] = sz[WS_RU] = patch > 1 ? (size_t)B * p.K * p.ld * 4 : 0;
+    sz[WS_OU] = patch > 1 ? (size_t)B * p.K * p.N * 4 : 0;
     sz[WS_WN] = sz[WS_WO] = sz[WS_KQ] = sz[WS_JQ] = (size_t)B * Mx * 4;
     sz[WS_DLIST] = (size_t)B * p.Mc * 4;
     sz[WS_MPRIME] = (size_t)B * 4;
@@ -96,7 +104,7 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 1; }
+int ipsr_abi_version(void) { return 2; }
 
 const char* ipsr_last_error(void) { return g_err; }
 
@@ -184,8 +192,8 @@ size_t ipsr_bwd_index_ints(int N, int M)
 
 size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride)
 {
-    if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0 || patch != 1 || stride != 1) return 0;
-    return plan_forward(B, C, h, w, M, nullptr).total;
+    if (B < 1 || C < 1 || patch < 1 || h < patch || w < patch || M < 0 || stride != 1) return 0;
+    return plan_forward(B, C, h, w, M, patch, nullptr).total;
 }
 
 int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
@@ -194,14 +202,16 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
                  void* ws, size_t ws_bytes, void* stream)
 {
     if (!x || !ref || !out || !ind || !vmax || !ws) return fail(IPSR_ERR_INVALID, "ipsr_forward: null pointer");
-    if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0 || M > h * w) return fail(IPSR_ERR_INVALID, "ipsr_forward: bad size B=%d C=%d h=%d w=%d M=%d", B, C, h, w, M);
-    if (patch != 1 || stride != 1)
-        return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: only shift_sz=1, stride=1 is implemented (got %d, %d); the reference raises for these too (models/IPSRFunction.py:134)", patch, stride);
+    if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return fail(IPSR_ERR_INVALID, "ipsr_forward: bad size B=%d C=%d h=%d w=%d M=%d", B, C, h, w, M);
+    if (stride != 1 || patch < 1)
+        return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: only stride=1 is implemented (got shift_sz=%d, stride=%d)", patch, stride);
+    if (h < patch || w < patch || M > (h - patch + 1) * (w - patch + 1))
+        return fail(IPSR_ERR_INVALID, "ipsr_forward: bad geometry h=%d w=%d shift_sz=%d M=%d", h, w, patch, M);
     if (M > 0 && !mask_point_idx) return fail(IPSR_ERR_INVALID, "ipsr_forward: M > 0 needs mask_point_idx");
     if (!aligned16(x) || !aligned16(ref) || !aligned16(out) || !aligned16(ws) || (attn_rows && !aligned16(attn_rows)))
         return fail(IPSR_ERR_INVALID, "ipsr_forward: x/ref/out/attn_rows/ws must be 16-byte aligned");
     size_t sz[WS_COUNT];
-    const FwdPlan p = plan_forward(B, C, h, w, M, sz);
+    const FwdPlan p = plan_forward(B, C, h, w, M, patch, sz);
     if (ws_bytes < p.total) return fail(IPSR_ERR_WORKSPACE, "ipsr_forward: workspace %zu < %zu", ws_bytes, p.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
 
@@ -212,11 +222,24 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     float* xT = reinterpret_cast<float*>(slice[WS_XT]);
     float* inv = reinterpret_cast<float*>(slice[WS_INV]);
 
-    if (int rc = launch_patch_normalize(x, B, C, p.N, xn, xT, p.Cp, inv, st)) return rc;
+    // shift_sz > 1: unfold both operands (unfold.hip); from here on a "channel" is one of the K numbers of a patch and a
+    // "position" one of the N' windows.  The result comes back as patches and is overlap-added at the end.
+    const float* xs = x;
+    const float* rs = ref;
+    float* outs = out;
+    if (patch > 1) {
+        float* xu = reinterpret_cast<float*>(slice[WS_XU]);
+        float* ru = reinterpret_cast<float*>(slice[WS_RU]);
+        if (int rc = launch_unfold(x, B, C, h, w, patch, p.ld, xu, st)) return rc;
+        if (int rc = launch_unfold(ref, B, C, h, w, patch, p.ld, ru, st)) return rc;
+        xs = xu; rs = ru;
+        outs = reinterpret_cast<float*>(slice[WS_OU]);
+    }
+    if (int rc = launch_patch_normalize(xs, B, p.K, p.N, xn, xT, p.Cp, inv, st, p.ld, p.ld)) return rc;
     AttnArgs a;
-    if (int rc = launch_corr_argmax(xn, ref, B, C, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part)) return rc;
-    a.x = x; a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
-    a.B = B; a.C = C; a.Cp = p.Cp; a.N = p.N; a.M = M; a.Mc = p.Mc;
+    if (int rc = launch_corr_argmax(xn, rs, B, p.K, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
+    a.x = xs; a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
+    a.B = B; a.C = p.K; a.Cp = p.Cp; a.N = p.N; a.M = M; a.Mc = p.Mc;
     a.wn = reinterpret_cast<float*>(slice[WS_WN]);
     a.wo = reinterpret_cast<float*>(slice[WS_WO]);
     a.kq = reinterpret_cast<int32_t*>(slice[WS_KQ]);
@@ -225,8 +248,10 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     a.mprime = reinterpret_cast<int32_t*>(slice[WS_MPRIME]);
     a.rankflag = reinterpret_cast<int32_t*>(slice[WS_RANKFLAG]);
     a.ac = reinterpret_cast<float*>(slice[WS_AC]);
-    a.attn = attn_rows; a.out = out; a.bwd_index = bwd_index;
-    return launch_attention(a, st);
+    a.attn = attn_rows; a.out = outs; a.bwd_index = bwd_index;
+    if (int rc = launch_attention(a, st)) return rc;
+    if (patch > 1) return launch_fold(outs, B, C, h, w, patch, out, st);
+    return IPSR_OK;
 }
 
 int ipsr_backward(const float* grad_out, const int32_t* mask_point_idx, int M, const float* attn_rows,
@@ -235,6 +260,32 @@ int ipsr_backward(const float* grad_out, const int32_t* mask_point_idx, int M, c
     if (!grad_out || !grad_in || !bwd_index) return fail(IPSR_ERR_INVALID, "ipsr_backward: null pointer");
     if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return fail(IPSR_ERR_INVALID, "ipsr_backward: bad size");
     return launch_backward(grad_out, mask_point_idx, M, attn_rows, bwd_index, triple_w, B, C, h * w, grad_in, static_cast<hipStream_t>(stream));
+}
+
+size_t ipsr_backward_workspace_bytes(int B, int C, int h, int w, int patch)
+{
+    if (B < 1 || C < 1 || patch < 1 || h < patch || w < patch) return 0;
+    if (patch == 1) return 0;
+    const size_t un = (size_t)B * C * patch * patch * (size_t)(h - patch + 1) * (w - patch + 1) * sizeof(float);
+    return 2 * align_up(un, 256) + 256;
+}
+
+int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, float triple_w,
+                        int B, int C, int h, int w, int patch, float* grad_in, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!grad_out || !grad_in || !bwd_index) return fail(IPSR_ERR_INVALID, "ipsr_backward_patch: null pointer");
+    if (B < 1 || C < 1 || patch < 1 || h < patch || w < patch || M < 0) return fail(IPSR_ERR_INVALID, "ipsr_backward_patch: bad size");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (patch == 1) return launch_backward(grad_out, nullptr, M, nullptr, bwd_index, triple_w, B, C, h * w, grad_in, st);
+    const size_t need = ipsr_backward_workspace_bytes(B, C, h, w, patch);
+    if (!ws || ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "ipsr_backward_patch: workspace %zu < %zu", ws_bytes, need);
+    const int K = C * patch * patch, Np = (h - patch + 1) * (w - patch + 1);
+    Carver cv(ws, ws_bytes);
+    float* gu = cv.take<float>((size_t)B * K * Np);
+    float* tu = cv.take<float>((size_t)B * K * Np);
+    if (int rc = launch_unfold(grad_out, B, C, h, w, patch, Np, gu, st)) return rc;
+    if (int rc = launch_backward(gu, nullptr, M, nullptr, bwd_index, triple_w, B, K, Np, tu, st, 0)) return rc;
+    return launch_fold(tu, B, C, h, w, patch, grad_in, st, grad_out);
 }
 
 size_t innercos_workspace_bytes(int B, int Cuse, int N) { return innercos_ws_bytes(B, Cuse, N); }

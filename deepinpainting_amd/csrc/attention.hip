@@ -114,46 +114,70 @@ __device__ __forceinline__ void rec_step(RowRegs<NCH>& o, const RowRegs<NCH>& pu
     }
 }
 
+// Step-indexed LDS arrays shared by both recurrence bodies: entry s describes step l = s + 1 (so a ring turn
+// l = 1+4j.. is 16-byte aligned); padded by 3*RING entries that repeat a valid row index so that run-ahead prefetches
+// stay in bounds.
+struct RecLds {
+    int Mp;
+    int* q_s;
+    int* kq_s;
+    float* iv_s;
+    float* vm_s;
+    float* wn_s;      // (wn_l, wo_l) indexed by l, copied out in one coalesced pass at the end
+    float* wo_s;
+    int q0, kq0;      // step 0
+};
+
+// All four waves resolve the chain mask_point_idx -> arg-max (merged from the k-split partials) -> (inv, vmax) for all steps.
+__device__ __forceinline__ RecLds recurrence_prologue(int* lds_raw, int b, const float* __restrict__ inv, const CorrPartials& part,
+                                                      const int32_t* __restrict__ mpi, int N, int M)
+{
+    RecLds r;
+    const int Mp = ((M + 3) & ~3) + 3 * RING;
+    r.Mp = Mp;
+    r.q_s = lds_raw;
+    r.kq_s = r.q_s + Mp;
+    r.iv_s = reinterpret_cast<float*>(r.kq_s + Mp);
+    r.vm_s = r.iv_s + Mp;
+    r.wn_s = r.vm_s + Mp;
+    r.wo_s = r.wn_s + Mp;
+    const int tid = threadIdx.x;
+    for (int l = tid; l < M; l += 256) {
+        const int q = mpi[l];
+        float vq; int kq;
+        merged_argmax(part, b, N, q, vq, kq);
+        if (l >= 1) {
+            r.q_s[l - 1] = q;
+            r.kq_s[l - 1] = kq;
+            r.iv_s[l - 1] = inv[(size_t)b * N + q];
+            r.vm_s[l - 1] = vq;
+        } else {
+            r.q_s[Mp - 1] = q;        // step 0's (q, kq) parked in the last padding slot (rewritten below with the same values)
+            r.kq_s[Mp - 1] = kq;
+        }
+    }
+    __syncthreads();
+    r.q0 = r.q_s[Mp - 1];
+    r.kq0 = r.kq_s[Mp - 1];
+    __syncthreads();
+    for (int s = M - 1 + tid; s < Mp; s += 256) { r.q_s[s] = r.q0; r.kq_s[s] = r.kq0; r.iv_s[s] = 0.0f; r.vm_s[s] = 1.0f; }
+    if (tid == 0) { r.wn_s[0] = 0.0f; r.wo_s[0] = 1.0f; }      // step 0: (wn, wo) = (0, 1) makes a_0 = onehot(kq_0)
+    __syncthreads();
+    return r;
+}
+
 // Runs in a 256-thread block of the stage kernel: all four waves fill / drain the LDS arrays, wave 0 alone walks the chain.
 template <int NCH, bool FULL>
 __device__ __forceinline__ void recurrence_body(int* lds_raw, int b, const float* __restrict__ xT, const float* __restrict__ inv,
                                                 const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M,
                                                 float* __restrict__ wn_out, float* __restrict__ wo_out)
 {
-    // step-indexed LDS arrays: entry s describes step l = s + 1 (so a ring turn l = 1+4j.. is 16-byte aligned);
-    // padded by 3*RING entries that repeat a valid row index so that run-ahead prefetches stay in bounds
-    const int Mp = ((M + 3) & ~3) + 3 * RING;
-    int* q_s = lds_raw;
-    int* kq_s = q_s + Mp;
-    float* iv_s = reinterpret_cast<float*>(kq_s + Mp);
-    float* vm_s = iv_s + Mp;
-    float* wn_s = vm_s + Mp;      // (wn_l, wo_l) indexed by l, copied out in one coalesced pass at the end
-    float* wo_s = wn_s + Mp;
-
+    const RecLds rl = recurrence_prologue(lds_raw, b, inv, part, mpi, N, M);
+    int* const q_s = rl.q_s; int* const kq_s = rl.kq_s;
+    float* const iv_s = rl.iv_s; float* const vm_s = rl.vm_s; float* const wn_s = rl.wn_s; float* const wo_s = rl.wo_s;
+    const int kq0 = rl.kq0;
     const int tid = threadIdx.x, lane = tid & 63;
     const float* xTb = xT + (size_t)b * N * Cp;
-
-    // resolve the chain mask_point_idx -> arg-max (merged from the k-split partials) -> (inv, vmax) for all steps
-    for (int l = tid; l < M; l += 256) {
-        const int q = mpi[l];
-        float vq; int kq;
-        merged_argmax(part, b, N, q, vq, kq);
-        if (l >= 1) {
-            q_s[l - 1] = q;
-            kq_s[l - 1] = kq;
-            iv_s[l - 1] = inv[(size_t)b * N + q];
-            vm_s[l - 1] = vq;
-        } else {
-            q_s[Mp - 1] = q;        // step 0's (q, kq) parked in the last padding slot (rewritten below with the same values)
-            kq_s[Mp - 1] = kq;
-        }
-    }
-    __syncthreads();
-    const int q0 = q_s[Mp - 1], kq0 = kq_s[Mp - 1];
-    __syncthreads();
-    for (int s = M - 1 + tid; s < Mp; s += 256) { q_s[s] = q0; kq_s[s] = kq0; iv_s[s] = 0.0f; vm_s[s] = 1.0f; }
-    if (tid == 0) { wn_s[0] = 0.0f; wo_s[0] = 1.0f; }      // step 0: (wn, wo) = (0, 1) makes a_0 = onehot(kq_0)
-    __syncthreads();
 
   if (tid < 64) {
     // Two register sets of RING slots: set A serves even ring turns, set B odd ones.  A slot is refilled right
@@ -225,6 +249,49 @@ __device__ __forceinline__ void recurrence_body(int* lds_raw, int b, const float
   }
     __syncthreads();
     for (int l = tid; l < M; l += 256) { wn_out[(size_t)b * M + l] = wn_s[l]; wo_out[(size_t)b * M + l] = wo_s[l]; }
+}
+
+// Wide patches (Cp > 1536; shift_sz > 1 makes a patch C*p*p numbers): the RING-deep double register ring above
+// would need 17 rows of NCH*8 registers.  Same arithmetic, same lane ownership, but ONE row pair in flight per set
+// (A serves even steps, B odd ones): 5 rows of NCH*8 registers, each load has one full step of compute to land in.
+template <int NCH>
+__device__ __forceinline__ void recurrence_wide_body(int* lds_raw, int b, const float* __restrict__ xT, const float* __restrict__ inv,
+                                                     const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M,
+                                                     float* __restrict__ wn_out, float* __restrict__ wo_out)
+{
+    const RecLds rl = recurrence_prologue(lds_raw, b, inv, part, mpi, N, M);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float* xTb = xT + (size_t)b * N * Cp;
+    if (tid < 64) {
+        RowRegs<NCH> o, puA, pkA, puB, pkB;
+        load_row<NCH>(o, xTb, rl.kq0, Cp, lane);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if ((lane + 64 * i) * 8 >= Cp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[i][e] = 0.0f;
+            }
+        load_row<NCH>(puA, xTb, rl.q_s[0], Cp, lane); load_row<NCH>(pkA, xTb, rl.kq_s[0], Cp, lane);
+        load_row<NCH>(puB, xTb, rl.q_s[1], Cp, lane); load_row<NCH>(pkB, xTb, rl.kq_s[1], Cp, lane);
+        const int nsteps = M - 1;
+        int s = 0;
+        for (; s + 2 <= nsteps; s += 2) {                 // entries up to s+3 <= Mp-1 exist (padding repeats a valid row)
+            float wn, wo;
+            rec_step<NCH, false>(o, puA, pkA, rl.iv_s[s], rl.vm_s[s], Cp, lane, wn, wo);
+            rl.wn_s[s + 1] = wn; rl.wo_s[s + 1] = wo;
+            load_row<NCH>(puA, xTb, rl.q_s[s + 2], Cp, lane); load_row<NCH>(pkA, xTb, rl.kq_s[s + 2], Cp, lane);
+            rec_step<NCH, false>(o, puB, pkB, rl.iv_s[s + 1], rl.vm_s[s + 1], Cp, lane, wn, wo);
+            rl.wn_s[s + 2] = wn; rl.wo_s[s + 2] = wo;
+            load_row<NCH>(puB, xTb, rl.q_s[s + 3], Cp, lane); load_row<NCH>(pkB, xTb, rl.kq_s[s + 3], Cp, lane);
+        }
+        if (s < nsteps) {
+            float wn, wo;
+            rec_step<NCH, false>(o, puA, pkA, rl.iv_s[s], rl.vm_s[s], Cp, lane, wn, wo);
+            rl.wn_s[s + 1] = wn; rl.wo_s[s + 1] = wo;
+        }
+    }
+    __syncthreads();
+    for (int l = tid; l < M; l += 256) { wn_out[(size_t)b * M + l] = rl.wn_s[l]; wo_out[(size_t)b * M + l] = rl.wo_s[l]; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -382,7 +449,8 @@ __global__ void __launch_bounds__(256) attention_stage_kernel(AttnArgs a, int nr
     __shared__ float gtile[32][33];
     const int bid = blockIdx.x;
     if (bid < nrec) {
-        recurrence_body<NCH, FULL>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
+        if constexpr (NCH > 3) recurrence_wide_body<NCH>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
+        else recurrence_body<NCH, FULL>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
     } else if (bid < nrec + a.B) {
         prepare_body(lds_dyn, bid - nrec, a.part, a.mpi, a.N, a.M, a.Mc, nbits, a.ind, a.vmax, a.dlist, a.mprime, a.jq, a.rankflag,
                      a.bwd_index, ints_per_sample);
@@ -630,7 +698,11 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
             case 2: LAUNCH_STAGE(2); break;
             case 3: LAUNCH_STAGE(3); break;
             case 4: LAUNCH_STAGE(4); break;
-            default: return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: C=%d > 2048 channels not supported", C);
+            // wide patches (shift_sz > 1: C*p*p numbers per patch): one instantiation per 1024 up to 5120 (C=512, p=3 is 4608)
+            case 5: case 6: LAUNCH_STAGE2(6, false); break;
+            case 7: case 8: LAUNCH_STAGE2(8, false); break;
+            case 9: case 10: LAUNCH_STAGE2(10, false); break;
+            default: return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: patch length C*p*p=%d > 5120 not supported", C);
         }
 #undef LAUNCH_STAGE
 #undef LAUNCH_STAGE2

@@ -9,6 +9,9 @@
 //
 // HBM-bound: reads g once, writes grad_in once (2*C*N*4 bytes per sample); the gathered g[c][q] come from the
 // LDS copy of the rows the workgroup owns.
+//
+// identity = 0 (shift_sz > 1, see ipsr_backward_patch): the kernel runs on the UNFOLDED gradient and returns only
+// triple_w * sum(...); the caller folds that back and adds g.
 #include "ipsr_common.h"
 
 namespace ipsr {
@@ -26,7 +29,7 @@ constexpr int BW_MAXLONG = 512;            // deferred (long) columns per workgr
 template <int R>
 __global__ void __launch_bounds__(BW_THREADS) ipsr_backward_kernel(const float* __restrict__ g, const int32_t* __restrict__ bwd_index,
                                                                    size_t ints_per_sample, size_t capB, float triple_w, int C, int N,
-                                                                   float* __restrict__ gin)
+                                                                   int identity, float* __restrict__ gin)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];      // [R][N]
     const int tid = threadIdx.x;
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(BW_THREADS) ipsr_backward_kernel(const float* 
         for (int i = 0; i < R; ++i)
             if (i < nrow) {
                 const float t = acc[i] * triple_w;             // (:173) mul then add, separately rounded
-                ob[(size_t)i * N + k] = rows[(size_t)i * N + k] + t;
+                ob[(size_t)i * N + k] = identity ? rows[(size_t)i * N + k] + t : t;
             }
     }
     __syncthreads();
@@ -98,12 +101,12 @@ __global__ void __launch_bounds__(BW_THREADS) ipsr_backward_kernel(const float* 
 #pragma unroll 4
         for (int e = offB[k], e1 = offB[k + 1]; e < e1; ++e) acc = __builtin_fmaf(entB_w[e], row[entB_q[e]], acc);
         const float t = acc * triple_w;
-        ob[(size_t)i * N + k] = row[k] + t;
+        ob[(size_t)i * N + k] = identity ? row[k] + t : t;
     }
 }
 
 int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn, const int32_t* bwd_index,
-                    float triple_w, int B, int C, int N, float* gin, hipStream_t st)
+                    float triple_w, int B, int C, int N, float* gin, hipStream_t st, int identity)
 {
     (void)mpi; (void)attn;      // everything the backward needs is in bwd_index
     const size_t capB = (size_t)M * (M + 1) / 2;
@@ -117,7 +120,7 @@ int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn
         if (lds > 48 * 1024)                                                                                       \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ipsr_backward_kernel<RR>),                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-        ipsr_backward_kernel<RR><<<dim3(cdiv(C, RR), B), BW_THREADS, lds, st>>>(g, bwd_index, ints, capB, triple_w, C, N, gin); \
+        ipsr_backward_kernel<RR><<<dim3(cdiv(C, RR), B), BW_THREADS, lds, st>>>(g, bwd_index, ints, capB, triple_w, C, N, identity, gin); \
     } while (0)
     switch (R) {
         case 16: LAUNCH_BW(16); break;

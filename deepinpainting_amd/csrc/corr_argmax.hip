@@ -50,7 +50,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <bool FAST, bool WRITE_S>
 __global__ void __launch_bounds__(NTHREADS, 2)
-corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, int C, int N,
+corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, int C, int N, int ld,
                    int qtiles, int ksplit, int ktiles, int kt_per_wg,
                    float* __restrict__ S_out, float* __restrict__ pval, int32_t* __restrict__ pidx)
 {
@@ -70,8 +70,8 @@ corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, 
     const int b = L / (ksplit * qtiles);
     const int q0 = qt * BN;
 
-    const float* A = xn + (size_t)b * C * N;
-    const float* R = ref + (size_t)b * C * N;
+    const float* A = xn + (size_t)b * C * ld;
+    const float* R = ref + (size_t)b * C * ld;
 
     // staging assignment: 16 rows x 32 float4 per operand tile = 512 float4, 2 per thread
     const int ld_row = tid >> 5;          // 0..7  (+8 for the second)
@@ -100,15 +100,15 @@ corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, 
             for (int i = 0; i < 2; ++i) {
                 const int c = c0 + ld_row + 8 * i;
                 if (FAST) {
-                    ra[i] = *reinterpret_cast<const float4*>(A + (size_t)c * N + k0 + ld_c4);
-                    rb[i] = *reinterpret_cast<const float4*>(R + (size_t)c * N + q0 + ld_c4);
+                    ra[i] = *reinterpret_cast<const float4*>(A + (size_t)c * ld + k0 + ld_c4);
+                    rb[i] = *reinterpret_cast<const float4*>(R + (size_t)c * ld + q0 + ld_c4);
                 } else {
                     float va[4], vb[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int kc = k0 + ld_c4 + e, qc = q0 + ld_c4 + e;
-                        va[e] = (c < C && kc < N) ? A[(size_t)c * N + kc] : 0.0f;
-                        vb[e] = (c < C && qc < N) ? R[(size_t)c * N + qc] : 0.0f;
+                        va[e] = (c < C && kc < N) ? A[(size_t)c * ld + kc] : 0.0f;
+                        vb[e] = (c < C && qc < N) ? R[(size_t)c * ld + qc] : 0.0f;
                     }
                     ra[i] = make_float4(va[0], va[1], va[2], va[3]);
                     rb[i] = make_float4(vb[0], vb[1], vb[2], vb[3]);
@@ -209,9 +209,12 @@ corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, 
 //     k-step are 256 bytes apart in LDS = ONE ds_read2st64_b32 with immediate offsets each, i.e. 2 LDS instructions
 //     and no address arithmetic per 4 MFMAs; three fragment register sets in rotation, the reads of k-step kk+1
 //     pinned in front of the MFMAs of kk.
-template <bool WRITE_S>
+//
+// RAGGED: the operands are [C][ld] with ld a multiple of 128 and the columns [N, ld) zero (shift_sz > 1 window grids);
+// patches k >= N are kept out of the arg-max and columns q >= N are not stored.
+template <bool WRITE_S, bool RAGGED>
 __global__ void __launch_bounds__(NTHREADS, 2)
-corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ ref, int C, int N,
+corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ ref, int C, int N, int ld,
                         int qtiles, int ksplit, int ktiles, int kt_per_wg,
                         float* __restrict__ S_out, float* __restrict__ pval, int32_t* __restrict__ pidx)
 {
@@ -232,8 +235,8 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
     const int b = L / (ksplit * qtiles);
     const int q0 = qt * BN;
 
-    const float* A = xn + (size_t)b * C * N;
-    const float* R = ref + (size_t)b * C * N;
+    const float* A = xn + (size_t)b * C * ld;
+    const float* R = ref + (size_t)b * C * ld;
 
     float best[2] = {-INFINITY, -INFINITY};
     int bidx[2] = {0x7fffffff, 0x7fffffff};
@@ -266,7 +269,7 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
             const int pair = wave + 4 * (isA ? p : p - NP / 2);
             const int slot = (s & (FNBUF - 1)) * (2 * FBK * BM) + (isA ? 0 : FBK * BM) + pair * 2 * BM;
             const size_t row = (size_t)s * FBK + 2 * pair + dma_row;
-            const float* g = isA ? (A + row * N + k0 + dma_col) : (R + row * N + q0 + dma_col);
+            const float* g = isA ? (A + row * ld + k0 + dma_col) : (R + row * ld + q0 + dma_col);
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)&lds[slot], 16, 0, 0);
         };
         auto wait_stage = [&](int younger) {      // `younger` = stages whose DMA was issued after the one needed now
@@ -331,8 +334,10 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
                 for (int e = 0; e < 16; ++e) {
                     const int k = k0 + wm * 32 + im * 64 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     const float v = acc[im][jn][e];
-                    if (v > best[jn]) { best[jn] = v; bidx[jn] = k; }
-                    if (WRITE_S) S_out[((size_t)b * N + k) * N + q] = v;
+                    if (!RAGGED || k < N) {
+                        if (v > best[jn]) { best[jn] = v; bidx[jn] = k; }
+                        if (WRITE_S) { if (!RAGGED || q < N) S_out[((size_t)b * N + k) * N + q] = v; }
+                    }
                 }
             }
         }
@@ -363,8 +368,10 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
             const int oi = red_i[(wn * 2 + jn) * 32 + r];
             if (better(ov, oi, best[jn], bidx[jn])) { best[jn] = ov; bidx[jn] = oi; }
             const int q = q0 + wn * 32 + jn * 64 + r;
-            pval[((size_t)b * ksplit + ks) * N + q] = best[jn];
-            pidx[((size_t)b * ksplit + ks) * N + q] = bidx[jn];
+            if (!RAGGED || q < N) {
+                pval[((size_t)b * ksplit + ks) * N + q] = best[jn];
+                pidx[((size_t)b * ksplit + ks) * N + q] = bidx[jn];
+            }
         }
     }
 }
@@ -409,8 +416,9 @@ size_t corr_argmax_ws_bytes(int B, int C, int N)
 }
 
 int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
-                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials)
+                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials, int ld)
 {
+    if (ld <= 0) ld = N;
     int qt, kt, ks, kpw;
     plan(B, N, &qt, &kt, &ks, &kpw);
     if (ws_bytes < corr_argmax_ws_bytes(B, C, N))
@@ -418,15 +426,20 @@ int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, i
     Carver cv(ws, ws_bytes);
     float* pval = cv.take<float>((size_t)B * ks * N);
     int32_t* pidx = cv.take<int32_t>((size_t)B * ks * N);
-    const bool fast = (N % BM == 0) && (C % FBK == 0) && ((reinterpret_cast<uintptr_t>(xn) | reinterpret_cast<uintptr_t>(ref)) & 15u) == 0;
+    // fast path: whole 128-column tiles in memory (ld), whole 16-channel stages, 16-byte aligned rows
+    const bool fast = (ld % BM == 0) && (ld >= qt * BN) && (C % FBK == 0) &&
+                      ((reinterpret_cast<uintptr_t>(xn) | reinterpret_cast<uintptr_t>(ref)) & 15u) == 0;
     const int grid = B * qt * ks;
     profile_mark_start(st);
-    if (fast) {
-        if (S_out) corr_argmax_fast_kernel<true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
-        else corr_argmax_fast_kernel<false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
+    if (fast && ld == N) {
+        if (S_out) corr_argmax_fast_kernel<true, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, ld, qt, ks, kt, kpw, S_out, pval, pidx);
+        else corr_argmax_fast_kernel<false, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, ld, qt, ks, kt, kpw, S_out, pval, pidx);
+    } else if (fast) {
+        if (S_out) corr_argmax_fast_kernel<true, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, ld, qt, ks, kt, kpw, S_out, pval, pidx);
+        else corr_argmax_fast_kernel<false, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, ld, qt, ks, kt, kpw, S_out, pval, pidx);
     } else {
-        if (S_out) corr_argmax_kernel<false, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
-        else corr_argmax_kernel<false, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, qt, ks, kt, kpw, S_out, pval, pidx);
+        if (S_out) corr_argmax_kernel<false, true><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, ld, qt, ks, kt, kpw, S_out, pval, pidx);
+        else corr_argmax_kernel<false, false><<<grid, NTHREADS, 0, st>>>(xn, ref, C, N, ld, qt, ks, kt, kpw, S_out, pval, pidx);
     }
     profile_mark_stop(st);
     if (int rc = check_launch("corr_argmax_kernel")) return rc;

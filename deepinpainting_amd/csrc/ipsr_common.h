@@ -79,13 +79,20 @@ int launch_feat_mask(const uint8_t* mask, int H, int W, int layers, float thresh
 int launch_index_prep(const uint8_t* feat, int h, int w, int patch, int stride, int mask_thred,
                       int32_t* flag, int32_t* mask_point_idx, int32_t* count, hipStream_t st);
 // xT may be NULL (then the patch-major copy is not produced).
+// ldx / ldn: row strides of x / xn (0 = N); with ldn > N the pad columns of xn are zero-filled.
 int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float* xT, int Cp, float* inv,
-                           hipStream_t st);
+                           hipStream_t st, int ldx = 0, int ldn = 0);
+// shift_sz > 1 (unfold.hip): p x p windows, stride 1, rows k = (c*p+dy)*p+dx; xu row stride ld >= N' (pad columns zeroed)
+int launch_unfold(const float* x, int B, int C, int h, int w, int patch, int ld, float* xu, hipStream_t st);
+// addend != NULL: out = addend + fold(yu)
+int launch_fold(const float* yu, int B, int C, int h, int w, int patch, float* out, hipStream_t st, const float* addend = nullptr);
 size_t corr_argmax_ws_bytes(int B, int C, int N);
+// ld: row stride of xn and ref (0 = N).  ld > N: operands zero-padded to whole 128-column tiles, patches k >= N are
+// excluded from the arg-max.
 // partials != NULL: skip the merge kernel and hand the k-split partials to the caller (ind/vmax are then written by the
 // consumer that merges them: the attention stage kernel)
 int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
-                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials = nullptr);
+                       float* S_out, void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials = nullptr, int ld = 0);
 
 struct AttnArgs {
     const float* x;        // [B,C,N] raw features
@@ -113,7 +120,7 @@ struct AttnArgs {
 int launch_attention(const AttnArgs& a, hipStream_t st);
 
 int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn, const int32_t* bwd_index,
-                    float triple_w, int B, int C, int N, float* gin, hipStream_t st);
+                    float triple_w, int B, int C, int N, float* gin, hipStream_t st, int identity = 1);
 
 size_t innercos_ws_bytes(int B, int Cuse, int N);
 int launch_innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,

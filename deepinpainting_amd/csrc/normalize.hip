@@ -22,7 +22,10 @@ namespace ipsr {
 constexpr int NCOL = 32;   // patches (columns) per workgroup
 constexpr int NSEG = 8;    // channel segments
 
+// ldx / ldn: row strides of x and xn (>= N).  With ldn > N the columns [N, ldn) of xn are written as zeros: the
+// correlation kernel's fast path wants whole 128-column tiles (shift_sz > 1 window grids are ragged).
 __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const float* __restrict__ x, int C, int N, int Cp,
+                                                                      int ldx, int ldn,
                                                                       float* __restrict__ xn, float* __restrict__ xT,
                                                                       float* __restrict__ inv)
 {
@@ -32,10 +35,10 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const floa
 
     const int tid = threadIdx.x;
     const int col = tid & (NCOL - 1), seg = tid / NCOL;
-    const int ntile = (N + NCOL - 1) / NCOL;
+    const int ntile = (ldn + NCOL - 1) / NCOL;
     const int b = blockIdx.x / ntile, k0 = (blockIdx.x % ntile) * NCOL;
     const int k = k0 + col;
-    const float* xb = x + (size_t)b * C * N;
+    const float* xb = x + (size_t)b * C * ldx;
 
     // phase 1: segment partial of sum(x^2), one fmaf chain per (segment, column)
     const int L = (C + NSEG - 1) / NSEG;
@@ -44,14 +47,14 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const floa
     if (k < N) {
         int c = c_lo;
         for (; c + 4 <= c_hi; c += 4) {
-            const float v0 = xb[(size_t)(c + 0) * N + k], v1 = xb[(size_t)(c + 1) * N + k];
-            const float v2 = xb[(size_t)(c + 2) * N + k], v3 = xb[(size_t)(c + 3) * N + k];
+            const float v0 = xb[(size_t)(c + 0) * ldx + k], v1 = xb[(size_t)(c + 1) * ldx + k];
+            const float v2 = xb[(size_t)(c + 2) * ldx + k], v3 = xb[(size_t)(c + 3) * ldx + k];
             acc = __builtin_fmaf(v0, v0, acc);
             acc = __builtin_fmaf(v1, v1, acc);
             acc = __builtin_fmaf(v2, v2, acc);
             acc = __builtin_fmaf(v3, v3, acc);
         }
-        for (; c < c_hi; ++c) { const float v = xb[(size_t)c * N + k]; acc = __builtin_fmaf(v, v, acc); }
+        for (; c < c_hi; ++c) { const float v = xb[(size_t)c * ldx + k]; acc = __builtin_fmaf(v, v, acc); }
     }
     part[seg][col] = acc;
     __syncthreads();
@@ -67,7 +70,7 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const floa
 
     // phase 2: scale (channel-major) and transpose (patch-major), 32 channels at a time
     const float iv = inv_s[col];
-    float* xnb = xn + (size_t)b * C * N;
+    float* xnb = xn + (size_t)b * C * ldn;
     float* xTb = xT ? xT + (size_t)b * N * Cp : nullptr;
     const int r = seg;   // 8 channel rows per pass
     for (int c0 = 0; c0 < Cp; c0 += 32) {
@@ -76,8 +79,10 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const floa
             const int cl = r + 8 * i, c = c0 + cl;
             float v = 0.0f;
             if (c < C && k < N) {
-                v = xb[(size_t)c * N + k];
-                xnb[(size_t)c * N + k] = v * iv;
+                v = xb[(size_t)c * ldx + k];
+                xnb[(size_t)c * ldn + k] = v * iv;
+            } else if (c < C && k < ldn) {
+                xnb[(size_t)c * ldn + k] = 0.0f;
             }
             tile[cl][col] = v;
         }
@@ -170,12 +175,14 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_reg_kernel(const 
 }
 
 int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float* xT, int Cp, float* inv,
-                           hipStream_t st)
+                           hipStream_t st, int ldx, int ldn)
 {
+    if (ldx <= 0) ldx = N;
+    if (ldn <= 0) ldn = N;
     const int ntile = cdiv(N, NCOL);
     const int L = cdiv(C, NSEG);
     // register path: segment fits 64 registers; float4 rows of xT need L % 4 == 0 and 8*L >= Cp (all of the padded row written)
-    if (L <= LMAX && L % 4 == 0 && NSEG * L >= Cp) {
+    if (ldx == N && ldn == N && L <= LMAX && L % 4 == 0 && NSEG * L >= Cp) {
         const int grid = B * ntile;
         const size_t lds = xT ? (size_t)NCOL * (Cp + 4) * sizeof(float) : 0;
         switch (L) {
@@ -191,7 +198,7 @@ int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float
             default: break;      // other lengths: generic kernel below
         }
     }
-    patch_normalize_kernel<<<B * ntile, NCOL * NSEG, 0, st>>>(x, C, N, Cp, xn, xT, inv);
+    patch_normalize_kernel<<<B * cdiv(ldn, NCOL), NCOL * NSEG, 0, st>>>(x, C, N, Cp, ldx, ldn, xn, xT, inv);
     return check_launch("patch_normalize_kernel");
 }
 

@@ -8,6 +8,10 @@ reference (:178).  What differs is only HOW: the reference loops over positions 
 materialises the N x N attention matrix `kbar` per sample (:36,78,134); here one C-ABI call launches the
 fused kernels (normalise -> MFMA correlation + arg-max -> recurrence -> reconstruction) and keeps `kbar`
 in sparse form (the masked rows + a CSR of the one-hot rows).
+
+shift_sz > 1 (BASELINE config 4's 3x3 patches): the reference's forward computes the result and then raises while
+saving `kbar` into a mis-sized buffer (:134); here it works — forward as the reference computes it up to :133,
+backward as the same rule carried through the unfold/fold pair (include/ipsr_hip.h, ipsr_backward_patch).
 """
 import torch
 
@@ -36,6 +40,7 @@ class IPSRFunction(torch.autograd.Function):
         f = ops.forward(input.detach().float(), ref.relu4_3.detach().float(), mpi32, int(shift_sz), int(stride),
                         want_index=need_grad)
         ctx.M = int(mpi32.numel())
+        ctx.shift_sz = int(shift_sz)
         ctx.bwd_index = f.bwd_index        # sparse trunc(kbar)  (the reference keeps the dense ctx.ind_lst, :139)
         ctx.ind = f.ind
         ctx.vmax = f.vmax
@@ -43,5 +48,5 @@ class IPSRFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        grad_input = ops.backward(grad_output.float(), ctx.bwd_index, ctx.triple_w, ctx.M).to(ctx.in_dtype)
+        grad_input = ops.backward(grad_output.float(), ctx.bwd_index, ctx.triple_w, ctx.M, ctx.shift_sz).to(ctx.in_dtype)
         return grad_input, None, None, None, None, None, None, None, None, None, None, None

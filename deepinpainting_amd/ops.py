@@ -109,7 +109,11 @@ def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want
     B, C, h, w = x.shape
     if tuple(ref.shape) != (B, C, h, w):
         raise RuntimeError("ref.relu4_3 %s does not match input %s" % (tuple(ref.shape), tuple(x.shape)))
-    N = h * w
+    if stride != 1:
+        raise NotImplementedError("IPSR layer: stride=%d is not implemented (only stride 1)" % stride)
+    if patch < 1 or h < patch or w < patch:
+        raise RuntimeError("IPSR layer: shift_sz=%d does not fit a %dx%d feature" % (patch, h, w))
+    N = (h - patch + 1) * (w - patch + 1)       # window grid; = h*w for the reference's shift_sz = 1
     mpi = _req(mask_point_idx_i32, torch.int32, "mask_point_idx")
     M = int(mpi.numel())
     L = _lib.lib()
@@ -131,13 +135,20 @@ def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want
     return Forward(out, ind, vmax, attn, bidx)
 
 
-def backward(grad_out, bwd_index, triple_w, M):
-    """grad_in = g + triple_w * trunc(kbar)^T-weighted g; needs only the sparse index built by forward."""
+def backward(grad_out, bwd_index, triple_w, M, patch=1):
+    """grad_in = g + triple_w * trunc(kbar)^T-weighted g; needs only the sparse index built by forward.
+    patch > 1: the extension described at ipsr_backward_patch (include/ipsr_hip.h)."""
     g = _req(grad_out, torch.float32, "grad_output")
     B, C, h, w = g.shape
     gin = torch.empty_like(g)
-    _lib.check(_lib.lib().ipsr_backward(g.data_ptr(), None, int(M), None, bwd_index.data_ptr(), float(triple_w),
-                                        B, C, h, w, gin.data_ptr(), _stream()), "ipsr_backward")
+    L = _lib.lib()
+    if patch == 1:
+        _lib.check(L.ipsr_backward(g.data_ptr(), None, int(M), None, bwd_index.data_ptr(), float(triple_w),
+                                   B, C, h, w, gin.data_ptr(), _stream()), "ipsr_backward")
+    else:
+        ws = _workspace(L.ipsr_backward_workspace_bytes(B, C, h, w, patch), g.device)
+        _lib.check(L.ipsr_backward_patch(g.data_ptr(), int(M), bwd_index.data_ptr(), float(triple_w), B, C, h, w, int(patch),
+                                         gin.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ipsr_backward_patch")
     return gin
 
 

@@ -91,7 +91,13 @@ int ipsr_corr_argmax(const float* xn, const float* ref, int B, int C, int N,
  *                                                                weight trunc(a_l[k]) (fp32 bits), ascending l;
  *                                                                capB = M(M+1)/2, offB[N] entries defined
  *   attn_rows         optional as well (NULL = the dense rows are not materialised; the layer itself works
- *                     on a compressed form). */
+ *                     on a compressed form).
+ * patch (the reference's shift_sz) > 1, stride 1: p x p windows as in NonparametricShift._extract_patches
+ * (util/NonparametricShift.py:59-73).  N above becomes the window grid N' = (h-p+1)(w-p+1): mask_point_idx indexes
+ * windows (ipsr_index_prep with the same patch), ind/vmax are [B,N'], attn_rows [B,M,N'], bwd_index
+ * [B, ipsr_bwd_index_ints(N',M)]; out stays [B,C,h,w] (the overlap-add of models/IPSRFunction.py:130).  The
+ * reference's own forward computes exactly this up to :133 and then raises at :134 on a mis-sized buffer.
+ * stride != 1 -> IPSR_ERR_UNSUPPORTED. */
 size_t ipsr_bwd_index_ints(int N, int M);
 size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride);
 int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
@@ -107,6 +113,16 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
 int ipsr_backward(const float* grad_out, const int32_t* mask_point_idx, int M,
                   const float* attn_rows, const int32_t* bwd_index, float triple_w,
                   int B, int C, int h, int w, float* grad_in, void* stream);
+
+/* Backward for any patch size.  patch == 1 is ipsr_backward (no workspace).  patch > 1 is an EXTENSION: the
+ * reference has no working backward there (models/IPSRFunction.py:158-170 index an N x N matrix by h*w); this
+ * carries the same rule (kbar constant and truncated, grad_in = grad_out + triple_w * d out / d patches) through
+ * the unfold/fold pair:  grad_in = g + fold(triple_w * trunc(kbar) applied to unfold(g)).
+ * bwd_index is the one ipsr_forward wrote for the same (h, w, patch, M). */
+size_t ipsr_backward_workspace_bytes(int B, int C, int h, int w, int patch);
+int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, float triple_w,
+                        int B, int C, int h, int w, int patch, float* grad_in,
+                        void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward

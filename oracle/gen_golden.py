@@ -185,6 +185,82 @@ def run_layer_case(R, name, x, ref, mask_img, threshold=5 / 16.0, triple_w=1.0, 
                                                           os.path.getsize(path) / 1024.0))
 
 
+class _Sink(object):
+    """Stands in for the `ind_lst` LongTensor of models/IPSRFunction.py:36 when shift_sz > 1: the reference sizes it
+    [bz, h*w, h, w] while kbar is [N', h-p+1, w-p+1], so the assignment at :134 raises.  Everything BEFORE that line
+    (the whole forward arithmetic, :46-133) is well defined for any patch size; swallowing that one store lets the
+    reference's own forward produce the p>1 output.  Harness-only; no reference file is touched."""
+    def __init__(self, *a):
+        pass
+
+    def cuda(self, *a, **k):
+        return self
+
+    def __setitem__(self, k, v):
+        pass
+
+
+def run_layer_case_patch(R, name, x, ref, mask_img, patch, threshold=5 / 16.0, note=""):
+    """Forward-only fixture for shift_sz = patch > 1 (BASELINE config 4's 3x3 patches).  The reference defines no
+    usable backward for it (its backward indexes an N x N matrix by h*w, :158-170), so none is recorded."""
+    rutil, NonparametricShift, MaxCoord, IPSRFunction, IPSR_model, InnerCos, InnerCos2 = R
+    B, C, h, w = x.shape
+    xt = torch.from_numpy(x.copy())
+    reft = Vgg(None, None, None, torch.from_numpy(ref.copy()))
+    mask_global = torch.from_numpy(mask_img.astype(bool))[None, None]
+    layer = IPSR_model(threshold, 1, patch, 1, 1, 1.0)
+    feat = layer.set_mask(mask_global, 3, threshold)
+    assert tuple(feat.shape) == (h, w), (feat.shape, h, w)
+    flag, nonmask_idx, flatten_offsets, mask_idx = rutil.cal_mask_given_mask_thred(xt[0], feat, patch, 1, 1)
+    sp_x, sp_y = rutil.cal_sps_for_Advanced_Indexing(h, w)
+    rec = {"ind": [], "vmax": [], "kbar": []}
+    orig_update = MaxCoord.update_output
+    orig_build = NonparametricShift.buildAutoencoder
+    orig_long = torch.LongTensor
+
+    def update_output(self, inp, sx, sy):
+        o = orig_update(self, inp, sx, sy)
+        rec["ind"].append(o[1].clone().numpy())
+        rec["vmax"].append(o[2].clone().numpy())
+        return o
+
+    def build(self, *a, **k):
+        r = list(orig_build(self, *a, **k))
+        dec = r[2]
+
+        class Rec(torch.nn.Module):
+            def forward(self_inner, kbar):
+                rec["kbar"].append(kbar.detach().clone().numpy()[0].reshape(kbar.size(1), -1))
+                return dec(kbar)
+        r[2] = Rec()
+        return tuple(r)
+
+    MaxCoord.update_output = update_output
+    NonparametricShift.buildAutoencoder = build
+    torch.LongTensor = _Sink
+    try:
+        ctx = types.SimpleNamespace()
+        with torch.no_grad():
+            out = IPSRFunction.forward(ctx, xt, feat, reft, patch, 1, 1.0, flag, nonmask_idx, mask_idx,
+                                       flatten_offsets, sp_x, sp_y)
+    finally:
+        torch.LongTensor = orig_long
+        MaxCoord.update_output = orig_update
+        NonparametricShift.buildAutoencoder = orig_build
+    M = int(mask_idx.numel())
+    kbar = np.stack(rec["kbar"])                                  # [B, N'(k), N'(q)]
+    attn_rows = np.stack([kbar[b][:, mask_idx.numpy()].T for b in range(B)]) if M else np.zeros((B, 0, kbar.shape[1]), np.float32)
+    d = dict(x=x, ref=ref, mask_img=mask_img, threshold=np.float32(threshold), patch=np.int64(patch),
+             feat_mask=feat.numpy().astype(np.uint8), flag=flag.numpy(), mask_point_idx=mask_idx.numpy(),
+             ind=np.stack(rec["ind"]).astype(np.int64), vmax=np.stack(rec["vmax"]),
+             attn_rows=attn_rows.astype(np.float32), out=out.numpy(), note=np.array(note))
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("%-28s B=%d C=%d %dx%d p=%d N'=%d M=%d  -> %s (%.1f KB)" % (name, B, C, h, w, patch, kbar.shape[1], M,
+                                                                  os.path.relpath(path), os.path.getsize(path) / 1024.0))
+
+
 def run_innercos2_case(R, name):
     rutil, _, _, _, _, InnerCos, InnerCos2 = R
     rs = np.random.RandomState(11)
@@ -386,7 +462,24 @@ def run_trainer_case(name):
     print("%-28s -> %s (%.1f KB)  errors=%s" % (name, os.path.relpath(path), os.path.getsize(path) / 1024.0, dict(errs)))
 
 
+def patch_cases(R):
+    def feats(seed, B, C, h):
+        rs = np.random.RandomState(seed)
+        return np.abs(rs.standard_normal((B, C, h, h))).astype(np.float32), rs.rand(B, C, h, h).astype(np.float32)
+    x, ref = feats(201, 2, 16, 12)
+    run_layer_case_patch(R, "patch_layer_p3_c16_12x12_center", x, ref, center_mask(96, 32, 64), 3,
+                         note="shift_sz=3 forward (BASELINE config 4 patch size)")
+    x, ref = feats(202, 1, 64, 16)
+    run_layer_case_patch(R, "patch_layer_p3_c64_16x16_stroke", x, ref, stroke_mask(128, 3), 3)
+    x, ref = feats(203, 2, 24, 8)
+    run_layer_case_patch(R, "patch_layer_p2_c24_8x8_center", x, ref, center_mask(64, 16, 48), 2, note="even patch size")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "patch":          # only the shift_sz > 1 fixtures
+        _install_cpu_aliases()
+        patch_cases(_import_reference())
+        return
     _install_cpu_aliases()
     R = _import_reference()
     torch.manual_seed(0)
@@ -436,6 +529,7 @@ def main():
     run_layer_case(R, "layer_c512_32x32_cfg2", x, ref, center_mask(256, 64, 192),
                    keep_channels=np.arange(0, 512, 37), note="BASELINE config 2, one sample")
 
+    patch_cases(R)
     run_innercos2_case(R, "innercos2_c1024_8x8")
     run_network_cases("networks")
     run_trainer_case("trainer_step")

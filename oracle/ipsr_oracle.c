@@ -192,12 +192,70 @@ static size_t bwd_capB(int M) { return (size_t)M * (M + 1) / 2; }
 size_t ipsr_bwd_index_ints_cpu(int N, int M) { return 2 * ((size_t)N + 1) + (size_t)N + 2 * bwd_capB(M); }
 
 /* ---- whole layer forward: IPSRFunction.forward (models/IPSRFunction.py:13-140) -------------- */
+/* ---- shift_sz > 1: patch unfold / overlap-add fold around the same algorithm ------------------
+ * NonparametricShift._extract_patches (util/NonparametricShift.py:59-73) unfolds p x p windows (stride 1, no padding)
+ * into patches [N', C, p, p], N' = (h-p+1)(w-p+1); every later step of IPSRFunction.forward (:46-133) treats a patch as
+ * one flat vector of K = C*p*p numbers (norm over the whole patch :40, correlation conv with p x p kernels :59, the
+ * recurrence's full-patch dot :109-116), and the final ConvTranspose2d (:130) overlap-adds the p x p patches back.
+ * So shift_sz = p is: unfold -> the p = 1 algorithm on a [K, N'] "feature" -> fold.
+ * Row order of the unfolded matrix: k = (c*p + dy)*p + dx (the flattening of a [C,p,p] patch); the fold adds the up
+ * to p*p contributions of a pixel in ascending (dy, dx), each add rounded (canonical order). */
+int ipsr_unfold_cpu(const float* x, int B, int C, int h, int w, int patch, float* xu)
+{
+    if (!x || !xu || B < 1 || C < 1 || patch < 1 || h < patch || w < patch) return IPSR_ERR_INVALID;
+    const int nH = h - patch + 1, nW = w - patch + 1, Np = nH * nW, K = C * patch * patch;
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int dy = 0; dy < patch; ++dy)
+                for (int dx = 0; dx < patch; ++dx) {
+                    float* row = xu + ((size_t)b * K + ((size_t)c * patch + dy) * patch + dx) * Np;
+                    const float* src = x + ((size_t)b * C + c) * h * w;
+                    for (int i = 0; i < nH; ++i)
+                        for (int j = 0; j < nW; ++j) row[i * nW + j] = src[(size_t)(i + dy) * w + j + dx];
+                }
+    return IPSR_OK;
+}
+
+int ipsr_fold_cpu(const float* yu, int B, int C, int h, int w, int patch, float* out)
+{
+    if (!yu || !out || B < 1 || C < 1 || patch < 1 || h < patch || w < patch) return IPSR_ERR_INVALID;
+    const int nH = h - patch + 1, nW = w - patch + 1, Np = nH * nW, K = C * patch * patch;
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int y = 0; y < h; ++y)
+                for (int xx = 0; xx < w; ++xx) {
+                    float acc = 0.0f;
+                    for (int dy = 0; dy < patch; ++dy)
+                        for (int dx = 0; dx < patch; ++dx) {
+                            const int i = y - dy, j = xx - dx;
+                            if (i < 0 || i >= nH || j < 0 || j >= nW) continue;
+                            acc = acc + yu[((size_t)b * K + ((size_t)c * patch + dy) * patch + dx) * Np + (size_t)i * nW + j];
+                        }
+                    out[(((size_t)b * C + c) * h + y) * w + xx] = acc;
+                }
+    return IPSR_OK;
+}
+
 HOT int ipsr_forward_cpu(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
                          int B, int C, int h, int w, int patch, int stride,
                          float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index)
 {
     if (!x || !ref || !out || !ind || !vmax || B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return IPSR_ERR_INVALID;
-    if (patch != 1 || stride != 1) return IPSR_ERR_UNSUPPORTED;   /* reference raises too: IPSRFunction.py:134 */
+    if (stride != 1 || patch < 1) return IPSR_ERR_UNSUPPORTED;
+    if (patch > 1) {                                  /* outputs ind/vmax/attn_rows/bwd_index live on the N' window grid */
+        if (h < patch || w < patch) return IPSR_ERR_INVALID;
+        const int nH = h - patch + 1, nW = w - patch + 1, K = C * patch * patch;
+        const size_t un = (size_t)B * K * nH * nW;
+        float* xu = (float*)malloc(sizeof(float) * un);
+        float* ru = (float*)malloc(sizeof(float) * un);
+        float* ou = (float*)malloc(sizeof(float) * un);
+        int rc = ipsr_unfold_cpu(x, B, C, h, w, patch, xu);
+        if (rc == IPSR_OK) rc = ipsr_unfold_cpu(ref, B, C, h, w, patch, ru);
+        if (rc == IPSR_OK) rc = ipsr_forward_cpu(xu, ru, mask_point_idx, M, B, K, nH, nW, 1, 1, ou, ind, vmax, attn_rows, bwd_index);
+        if (rc == IPSR_OK) rc = ipsr_fold_cpu(ou, B, C, h, w, patch, out);
+        free(xu); free(ru); free(ou);
+        return rc;
+    }
     if (M > 0 && (!mask_point_idx || !attn_rows)) return IPSR_ERR_INVALID;
     const int N = h * w;
     float* xn = (float*)malloc(sizeof(float) * (size_t)B * C * N);
@@ -288,13 +346,45 @@ HOT int ipsr_forward_cpu(const float* x, const float* ref, const int32_t* mask_p
 }
 
 /* ---- K8: IPSRFunction.backward (models/IPSRFunction.py:144-178) ------------------------------ */
+static int backward_core(const float* g, int M, const int32_t* bwd_index, float triple_w, int B, int C, int N,
+                         int identity, float* gin);
+
 int ipsr_backward_cpu(const float* g, const int32_t* mask_point_idx, int M, const float* attn_rows,
                       const int32_t* bwd_index, float triple_w, int B, int C, int h, int w, float* gin)
 {
     if (!g || !gin || !bwd_index || B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return IPSR_ERR_INVALID;
-    const int N = h * w;
-    const size_t capB = bwd_capB(M);
     (void)mask_point_idx; (void)attn_rows;   /* everything the backward needs is in bwd_index */
+    return backward_core(g, M, bwd_index, triple_w, B, C, h * w, 1, gin);
+}
+
+/* shift_sz > 1 — EXTENSION: the reference has no working backward for p > 1 (its forward already raises at :134 and
+ * :158-170 index an N x N matrix by h*w).  This is the same rule (:144-178: kbar is a constant, truncated to integers;
+ * grad_in = grad_out + triple_w * d out / d patches) carried through the unfold/fold pair, whose adjoints are each other:
+ *     GU = unfold(g);   TU[:,k] = triple_w * sum_q trunc(kbar)[k][q] GU[:,q];   grad_in = g + fold(TU).           */
+int ipsr_backward_patch_cpu(const float* g, int M, const int32_t* bwd_index, float triple_w,
+                            int B, int C, int h, int w, int patch, float* gin)
+{
+    if (!g || !gin || !bwd_index || B < 1 || C < 1 || patch < 1 || h < patch || w < patch || M < 0) return IPSR_ERR_INVALID;
+    if (patch == 1) return backward_core(g, M, bwd_index, triple_w, B, C, h * w, 1, gin);
+    const int nH = h - patch + 1, nW = w - patch + 1, K = C * patch * patch;
+    const size_t un = (size_t)B * K * nH * nW;
+    float* gu = (float*)malloc(sizeof(float) * un);
+    float* tu = (float*)malloc(sizeof(float) * un);
+    int rc = ipsr_unfold_cpu(g, B, C, h, w, patch, gu);
+    if (rc == IPSR_OK) rc = backward_core(gu, M, bwd_index, triple_w, B, K, nH * nW, 0, tu);
+    if (rc == IPSR_OK) rc = ipsr_fold_cpu(tu, B, C, h, w, patch, gin);
+    if (rc == IPSR_OK) {
+        const size_t n = (size_t)B * C * h * w;
+        for (size_t i = 0; i < n; ++i) gin[i] = g[i] + gin[i];
+    }
+    free(gu); free(tu);
+    return rc;
+}
+
+static int backward_core(const float* g, int M, const int32_t* bwd_index, float triple_w, int B, int C, int N,
+                         int identity, float* gin)
+{
+    const size_t capB = bwd_capB(M);
     for (int b = 0; b < B; ++b) {
         const int32_t* offA = bwd_index + (size_t)b * ipsr_bwd_index_ints_cpu(N, M);
         const int32_t* entA = offA + N + 1;
@@ -309,7 +399,7 @@ int ipsr_backward_cpu(const float* g, const int32_t* mask_point_idx, int M, cons
                 for (int e = offA[k]; e < offA[k + 1]; ++e) acc = acc + gr[entA[e]];                      /* one-hot rows :129 */
                 for (int e = offB[k]; e < offB[k + 1]; ++e) acc = fmaf(entB_w[e], gr[entB_q[e]], acc);   /* truncated masked rows */
                 const float t = acc * triple_w;                                                 /* :173 */
-                go[k] = gr[k] + t;
+                go[k] = identity ? gr[k] + t : t;
             }
         }
     }

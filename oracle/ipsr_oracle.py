@@ -130,7 +130,7 @@ def forward(x, ref, mask_point_idx, patch=1, stride=1):
     """IPSRFunction.forward.  x, ref [B,C,h,w]; mask_point_idx [M] -> Forward(...)."""
     x, ref = _f32(x), _f32(ref)
     B, C, h, w = x.shape
-    N = h * w
+    N = (h - patch + 1) * (w - patch + 1)          # the window grid: ind / vmax / attn_rows / bwd_index live on it
     mpi = np.ascontiguousarray(mask_point_idx, dtype=np.int32)
     M = int(mpi.shape[0])
     out = np.empty_like(x)
@@ -145,6 +145,24 @@ def forward(x, ref, mask_point_idx, patch=1, stride=1):
     return Forward(out, ind, vmax, attn[:, :M], bidx)
 
 
+def unfold(x, patch):
+    """x [B,C,h,w] -> [B, C*p*p, N'] (rows k = (c*p+dy)*p+dx)."""
+    x = _f32(x)
+    B, C, h, w = x.shape
+    xu = np.empty((B, C * patch * patch, (h - patch + 1) * (w - patch + 1)), np.float32)
+    _chk(lib().ipsr_unfold_cpu(_p(x, ctypes.c_float), B, C, h, w, patch, _p(xu, ctypes.c_float)), "unfold")
+    return xu
+
+
+def fold(yu, C, h, w, patch):
+    """overlap-add of [B, C*p*p, N'] back to [B,C,h,w]."""
+    yu = _f32(yu)
+    B = yu.shape[0]
+    out = np.empty((B, C, h, w), np.float32)
+    _chk(lib().ipsr_fold_cpu(_p(yu, ctypes.c_float), B, C, h, w, patch, _p(out, ctypes.c_float)), "fold")
+    return out
+
+
 def backward(grad_out, mask_point_idx, attn_rows, bwd_index, triple_w=1.0):
     """IPSRFunction.backward.  grad_out [B,C,h,w] -> grad_in [B,C,h,w]."""
     g = _f32(grad_out)
@@ -157,6 +175,17 @@ def backward(grad_out, mask_point_idx, attn_rows, bwd_index, triple_w=1.0):
     _chk(lib().ipsr_backward_cpu(_p(g, ctypes.c_float), _p(mpi, ctypes.c_int32), M, _p(attn, ctypes.c_float),
                                  _p(bidx, ctypes.c_int32), ctypes.c_float(triple_w), B, C, h, w,
                                  _p(gin, ctypes.c_float)), "backward")
+    return gin
+
+
+def backward_patch(grad_out, M, bwd_index, triple_w=1.0, patch=1):
+    """shift_sz > 1 extension of the backward (see ipsr_backward_patch_cpu)."""
+    g = _f32(grad_out)
+    B, C, h, w = g.shape
+    bidx = np.ascontiguousarray(bwd_index, dtype=np.int32)
+    gin = np.empty_like(g)
+    _chk(lib().ipsr_backward_patch_cpu(_p(g, ctypes.c_float), int(M), _p(bidx, ctypes.c_int32), ctypes.c_float(triple_w),
+                                       B, C, h, w, patch, _p(gin, ctypes.c_float)), "backward_patch")
     return gin
 
 

@@ -48,15 +48,19 @@ def test_host_side_queries_and_argument_errors(built):
     L = built.lib()
     assert L.ipsr_bwd_index_ints(1024, 256) == 2 * 1025 + 1024 + 2 * (256 * 257 // 2)
     assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 1, 1) > 8 * 512 * 1024 * 4 * 2
-    assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 3, 1) == 0          # unsupported patch size
+    # shift_sz = 3: three unfolded [K=4608, ld=1024] operands and a [K, N'=900] result on top of the p = 1 slices
+    assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 3, 1) > 8 * 4608 * (3 * 1024 + 900) * 4
+    assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 3, 2) == 0          # stride != 1: unsupported
+    assert L.ipsr_backward_workspace_bytes(8, 512, 32, 32, 1) == 0
+    assert L.ipsr_backward_workspace_bytes(8, 512, 32, 32, 3) >= 2 * 8 * 4608 * 900 * 4
     assert L.ipsr_feat_mask_workspace_bytes(256, 256, 3) >= 2 * 128 * 128 * 4
     # argument validation happens before any HIP call, so it is testable without a GPU
     assert L.ipsr_forward(None, None, None, 0, 1, 1, 1, 1, 1, 1, None, None, None, None, None, None, 0, None) == -1
     assert b"null pointer" in L.ipsr_last_error()
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    rc = L.ipsr_forward(p, p, None, 0, 1, 1, 8, 8, 3, 1, p, p, p, None, None, p, 1 << 20, None)
-    assert rc == -2 and b"shift_sz=1" in L.ipsr_last_error()
+    rc = L.ipsr_forward(p, p, None, 0, 1, 1, 8, 8, 3, 2, p, p, p, None, None, p, 1 << 20, None)
+    assert rc == -2 and b"stride=1" in L.ipsr_last_error()
     with pytest.raises(NotImplementedError):
         built.check(rc, "ipsr_forward")
 
@@ -65,5 +69,5 @@ def test_oracle_library_exports_cpu_twins():
     from oracle import ipsr_oracle as orc
     o = orc.lib()
     for name in ("ipsr_feat_mask", "ipsr_index_prep", "ipsr_patch_normalize", "ipsr_corr_argmax", "ipsr_forward",
-                 "ipsr_backward", "innercos_loss", "innercos_loss_backward"):
+                 "ipsr_backward", "ipsr_backward_patch", "ipsr_unfold", "ipsr_fold", "innercos_loss", "innercos_loss_backward"):
         assert hasattr(o, name + "_cpu")

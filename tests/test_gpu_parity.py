@@ -322,8 +322,10 @@ def test_innercos_full_size(ops):
 def test_error_behaviour(ops):
     x = torch.zeros(1, 8, 8, 8, device="cuda")
     mpi = torch.zeros(4, dtype=torch.int32, device="cuda")
-    with pytest.raises(NotImplementedError):      # reference raises for shift_sz=3 too (IPSRFunction.py:134)
-        ops.forward(x, x, mpi, patch=3, stride=1)
+    with pytest.raises(NotImplementedError):      # stride != 1 is not implemented
+        ops.forward(x, x, mpi, patch=3, stride=2)
+    with pytest.raises(RuntimeError):             # a 9x9 patch does not fit an 8x8 feature
+        ops.forward(x, x, mpi, patch=9, stride=1)
     with pytest.raises(RuntimeError):
         ops.forward(x.cpu(), x.cpu(), mpi)
     with pytest.raises(RuntimeError):
@@ -361,3 +363,137 @@ def test_layer_signed_long_survivor_columns(ops):
     np.testing.assert_array_equal(f.attn_rows.cpu().numpy(), fo.attn_rows)
     np.testing.assert_array_equal(f.out.cpu().numpy(), fo.out)
     np.testing.assert_array_equal(gin.cpu().numpy(), gin_o)
+
+
+# ------------------------------------------------------------------------------------------ shift_sz > 1
+PATCH_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "patch_layer_*.npz")))
+
+
+def run_hip_patch_layer(ops, x, ref, mpi, p, tw, g):
+    f = ops.forward(dev(x), dev(ref), dev(mpi, torch.int32), patch=p, want_attn=True)
+    gin = ops.backward(dev(g), f.bwd_index, tw, len(mpi), patch=p)
+    torch.cuda.synchronize()
+    return f, gin
+
+
+def assert_patch_layer_equal(f, gin, fo, gin_o, Np, M):
+    np.testing.assert_array_equal(f.ind.cpu().numpy(), fo.ind)
+    np.testing.assert_array_equal(f.vmax.cpu().numpy(), fo.vmax)
+    np.testing.assert_array_equal(f.attn_rows.cpu().numpy(), fo.attn_rows)
+    assert_index_equal(f.bwd_index, fo.bwd_index, Np, M)
+    np.testing.assert_array_equal(f.out.cpu().numpy(), fo.out)
+    np.testing.assert_array_equal(gin.cpu().numpy(), gin_o)
+
+
+@pytest.mark.parametrize("name", PATCH_CASES)
+def test_patch_layer_vs_oracle_bit_exact_and_vs_reference(ops, name):
+    """shift_sz = 2 / 3 (BASELINE config 4's 3x3 patches): HIP == oracle bit for bit, and == the reference's own forward
+    (fixture captured by gen_golden.py) within the north-star tolerance."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    p = int(d["patch"])
+    x, ref, mpi = d["x"], d["ref"], d["mask_point_idx"]
+    B, C, h, w = x.shape
+    Np = (h - p + 1) * (w - p + 1)
+    flag, mpi_d, cnt = ops.index_prep(dev(d["feat_mask"]), p, 1, 1)
+    assert int(cnt.item()) == len(mpi)
+    np.testing.assert_array_equal(mpi_d.cpu().numpy()[:len(mpi)], mpi)
+    np.testing.assert_array_equal(flag.cpu().numpy(), d["flag"])
+    g = np.random.RandomState(9).standard_normal(x.shape).astype(np.float32)
+    fo = orc.forward(x, ref, mpi, patch=p)
+    gin_o = orc.backward_patch(g, len(mpi), fo.bwd_index, 0.5, p)
+    f, gin = run_hip_patch_layer(ops, x, ref, mpi, p, 0.5, g)
+    assert_patch_layer_equal(f, gin, fo, gin_o, Np, len(mpi))
+    np.testing.assert_array_equal(f.ind.cpu().numpy().astype(np.int64), d["ind"])
+    assert np.abs(f.out.cpu().numpy() - d["out"]).max() <= ATOL
+    assert np.abs(f.attn_rows.cpu().numpy() - d["attn_rows"]).max() <= ATOL
+
+
+@pytest.mark.parametrize("B,C,h,w,p,seed", [(2, 16, 10, 14, 3, 1),      # K = 144: fast correlation path on a ragged grid
+                                            (1, 512, 10, 10, 3, 2),     # K = 4608: the config-4 patch length (wide recurrence)
+                                            (2, 20, 9, 9, 2, 3),        # K = 80, C not a multiple of 8: generic kernels
+                                            (1, 128, 14, 14, 3, 4),     # K = 1152 (3 lane chunks), N' = 144 > 128: two k-tiles
+                                            (1, 200, 8, 8, 3, 5),       # K = 1800: 4 lane chunks -> wide recurrence, not FULL
+                                            (1, 8, 3, 3, 3, 6)])        # a single window
+def test_patch_layer_random_shapes_vs_oracle(ops, B, C, h, w, p, seed):
+    rs = np.random.RandomState(seed)
+    x = np.abs(rs.standard_normal((B, C, h, w))).astype(np.float32)
+    ref = rs.rand(B, C, h, w).astype(np.float32)
+    feat = (rs.rand(h, w) < 0.12).astype(np.uint8)
+    mpi = orc.index_prep(feat, patch=p).mask_point_idx
+    g = rs.standard_normal((B, C, h, w)).astype(np.float32)
+    fo = orc.forward(x, ref, mpi, patch=p)
+    gin_o = orc.backward_patch(g, len(mpi), fo.bwd_index, 0.75, p)
+    f, gin = run_hip_patch_layer(ops, x, ref, mpi, p, 0.75, g)
+    assert_patch_layer_equal(f, gin, fo, gin_o, (h - p + 1) * (w - p + 1), len(mpi))
+
+
+def test_patch_layer_signed_features_all_negative_scores(ops):
+    """Signed features can make every real correlation negative: the zero pad columns of the ragged window grid must
+    never win the arg-max."""
+    rs = np.random.RandomState(11)
+    B, C, h, w, p = 1, 16, 9, 9, 3
+    x = np.abs(rs.standard_normal((B, C, h, w))).astype(np.float32)
+    ref = -rs.rand(B, C, h, w).astype(np.float32)               # every score < 0
+    mpi = orc.index_prep((rs.rand(h, w) < 0.1).astype(np.uint8), patch=p).mask_point_idx
+    fo = orc.forward(x, ref, mpi, patch=p)
+    f = ops.forward(dev(x), dev(ref), dev(mpi, torch.int32), patch=p, want_attn=True)
+    assert (fo.vmax < 0).all() and int(f.ind.max()) < (h - p + 1) * (w - p + 1)
+    np.testing.assert_array_equal(f.ind.cpu().numpy(), fo.ind)
+    np.testing.assert_array_equal(f.vmax.cpu().numpy(), fo.vmax)
+    np.testing.assert_array_equal(f.out.cpu().numpy(), fo.out)
+
+
+def test_patch_layer_nomask(ops):
+    rs = np.random.RandomState(12)
+    x = np.abs(rs.standard_normal((2, 16, 8, 8))).astype(np.float32)
+    ref = rs.rand(2, 16, 8, 8).astype(np.float32)
+    mpi = np.zeros(0, np.int64)
+    g = rs.standard_normal(x.shape).astype(np.float32)
+    fo = orc.forward(x, ref, mpi, patch=3)
+    gin_o = orc.backward_patch(g, 0, fo.bwd_index, 1.0, 3)
+    f, gin = run_hip_patch_layer(ops, x, ref, mpi, 3, 1.0, g)
+    np.testing.assert_array_equal(f.out.cpu().numpy(), fo.out)
+    np.testing.assert_array_equal(gin.cpu().numpy(), gin_o)
+
+
+def test_patch_layer_config4_size_properties(ops):
+    """BASELINE config 4: 512 channels, 64x64 feature, 3x3 patches (N' = 3844 windows of 4608 numbers, 136 GFLOP of
+    correlation per sample), one sample.  Too big for the oracle in test time: size-independent properties instead."""
+    rs = np.random.RandomState(21)
+    C, h, p = 512, 64, 3
+    nW = h - p + 1
+    Np = nW * nW
+    x = np.abs(rs.standard_normal((1, C, h, h))).astype(np.float32)
+    ref = rs.rand(1, C, h, h).astype(np.float32)
+    feat = np.zeros((h, h), np.uint8)
+    feat[16:48, 16:48] = 1
+    mpi = orc.index_prep(feat, patch=p).mask_point_idx
+    assert len(mpi) == 34 * 34
+    f = ops.forward(dev(x), dev(ref), dev(mpi, torch.int32), patch=p, want_attn=True)
+    torch.cuda.synchronize()
+    ind, attn = f.ind.cpu().numpy()[0], f.attn_rows.cpu().numpy()[0]
+    assert ind.min() >= 0 and ind.max() < Np
+    assert np.abs(attn.sum(-1) - 1).max() < 1e-4
+    # arg-max against an fp64 recomputation on a few columns
+    xu = torch.nn.functional.unfold(torch.from_numpy(x), p)[0].double()
+    ru = torch.nn.functional.unfold(torch.from_numpy(ref), p)[0].double()
+    xn = xu / (xu.norm(dim=0, keepdim=True) + 1e-8)
+    cols = torch.from_numpy(rs.choice(Np, 48, replace=False))
+    S = xn.t() @ ru[:, cols]
+    assert (S[torch.from_numpy(ind[cols.numpy()].astype(np.int64)), torch.arange(48)] - S.max(0).values).abs().max() < 1e-4
+    # reconstruction = fold of (one-hot gathers | attention rows @ patches), recomputed in fp64
+    kb = torch.zeros(Np, Np, dtype=torch.float64)
+    masked = np.zeros(Np, bool); masked[mpi] = True
+    q = np.nonzero(~masked)[0]
+    kb[torch.from_numpy(ind[q].astype(np.int64)), torch.from_numpy(q)] = 1.0
+    kb[:, torch.from_numpy(mpi)] = torch.from_numpy(attn.astype(np.float64)).t()
+    want = torch.nn.functional.fold((xu @ kb)[None], (h, h), p)[0].numpy()
+    got = f.out.cpu().numpy()[0]
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    # backward extension: the adjoint identity <fold(T unfold g), x'> on the one-hot part: with nothing masked-row-surviving
+    # the result must equal g + tw * fold(unfold(g) @ trunc(kb)^T)
+    g = rs.standard_normal(x.shape).astype(np.float32)
+    gin = ops.backward(dev(g), f.bwd_index, 0.5, len(mpi), patch=p).cpu().numpy()[0]
+    gu = torch.nn.functional.unfold(torch.from_numpy(g), p)[0].double()
+    wantg = g[0] + 0.5 * torch.nn.functional.fold((gu @ torch.trunc(kb).t())[None], (h, h), p)[0].numpy()
+    assert np.abs(gin - wantg).max() <= 1e-4 * max(1.0, np.abs(wantg).max())

@@ -140,3 +140,75 @@ def test_sps_helper():
     sp_y = np.tile(np.arange(7), 5)
     np.testing.assert_array_equal(sp_x, d["sps_5x7__sp_x"])
     np.testing.assert_array_equal(sp_y, d["sps_5x7__sp_y"])
+
+
+# ---- shift_sz > 1 (BASELINE config 4's 3x3 patches) ----------------------------------------------------------------
+PATCH_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "patch_layer_*.npz")))
+
+
+def dense_trunc_kbar(f, mpi, b):
+    """trunc(kbar) [N'(k), N'(q)] of sample b from the oracle's outputs (one-hot non-masked columns + truncated rows)."""
+    Np = f.ind.shape[1]
+    W = np.zeros((Np, Np), np.float32)
+    masked = np.zeros(Np, bool)
+    masked[mpi] = True
+    q = np.nonzero(~masked)[0]
+    W[f.ind[b, q], q] = 1.0
+    for l, ql in enumerate(mpi):
+        W[:, ql] = np.trunc(f.attn_rows[b, l])
+    return W
+
+
+def test_patch_fixture_inventory():
+    assert len(PATCH_CASES) >= 3
+
+
+@pytest.mark.parametrize("name", PATCH_CASES)
+def test_patch_forward_vs_reference(name):
+    """The reference's own forward for shift_sz > 1 (it computes the output and only then raises, IPSRFunction.py:134;
+    gen_golden.py swallows that one store) against the oracle = unfold -> p=1 algorithm -> fold."""
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    p = int(d["patch"])
+    ip = orc.index_prep(d["feat_mask"], patch=p)
+    np.testing.assert_array_equal(ip.flag, d["flag"])
+    np.testing.assert_array_equal(ip.mask_point_idx, d["mask_point_idx"])
+    f = orc.forward(d["x"], d["ref"], d["mask_point_idx"], patch=p)
+    np.testing.assert_array_equal(f.ind.astype(np.int64), d["ind"])
+    np.testing.assert_allclose(f.vmax, d["vmax"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(f.attn_rows, d["attn_rows"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(f.out, d["out"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", PATCH_CASES)
+def test_patch_unfold_fold_vs_torch(name):
+    import torch
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    p = int(d["patch"])
+    B, C, h, w = d["x"].shape
+    xu = orc.unfold(d["x"], p)
+    t = torch.nn.functional.unfold(torch.from_numpy(d["x"]), p)
+    np.testing.assert_array_equal(xu, t.numpy())
+    np.testing.assert_allclose(orc.fold(xu, C, h, w, p), torch.nn.functional.fold(t, (h, w), p).numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", PATCH_CASES)
+def test_patch_backward_extension_is_the_adjoint(name):
+    """shift_sz > 1 backward (extension, no reference counterpart): grad_in = g + triple_w * d<out, g>/dx with kbar held
+    constant and truncated — checked against torch autograd of fold(unfold(x) @ trunc(kbar))."""
+    import torch
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    p = int(d["patch"])
+    B, C, h, w = d["x"].shape
+    mpi = d["mask_point_idx"]
+    f = orc.forward(d["x"], d["ref"], mpi, patch=p)
+    g = np.random.RandomState(5).standard_normal(d["x"].shape).astype(np.float32)
+    tw = 0.75
+    gin = orc.backward_patch(g, len(mpi), f.bwd_index, tw, p)
+    for b in range(B):
+        W = torch.from_numpy(dense_trunc_kbar(f, mpi, b)).double()
+        x = torch.from_numpy(d["x"][b:b + 1]).double().requires_grad_(True)
+        ou = torch.nn.functional.unfold(x, p)[0] @ W
+        out = torch.nn.functional.fold(ou[None], (h, w), p)
+        (out * torch.from_numpy(g[b:b + 1]).double()).sum().backward()
+        want = g[b] + tw * x.grad[0].numpy()
+        np.testing.assert_allclose(gin[b], want, rtol=1e-5, atol=1e-5)
