@@ -143,7 +143,7 @@ __device__ __forceinline__ RecLds recurrence_prologue(int* lds_raw, int b, const
     r.wo_s = r.wn_s + Mp;
     const int tid = threadIdx.x;
     for (int l = tid; l < M; l += 256) {
-        const int q = mpi[l];
+        const int q = mpi_at(mpi, l, N);
         float vq; int kq;
         merged_argmax(part, b, N, q, vq, kq);
         if (l >= 1) {
@@ -294,6 +294,99 @@ __device__ __forceinline__ void recurrence_wide_body(int* lds_raw, int b, const 
     for (int l = tid; l < M; l += 256) { wn_out[(size_t)b * M + l] = rl.wn_s[l]; wo_out[(size_t)b * M + l] = rl.wo_s[l]; }
 }
 
+// Patches wider than 2048 numbers (shift_sz > 1: C*p*p, 4608 for the reference's 512 channels and 3x3 patches): one
+// wave would hold 72+ registers per row and issue 144 row loads per step (4.4 us per step measured).  All FOUR waves of
+// the block walk the chain together instead: lane J of 256 owns the 8-number chunks J, J+256, ..; every wave reduces its
+// 64 partials with the canonical butterfly, the four wave sums meet in LDS (one raw s_barrier per step, double-buffered
+// slot, no vmcnt drain) and are added as (s0+s1)+(s2+s3) — the oracle's lane_dot for C > 2048.  Every wave then
+// computes the same (wn, wo) bits and updates its own slice of o.  Row prefetch: QD single-row sets, distance QD steps.
+constexpr int QD = 4;
+
+template <int NW>
+__device__ __forceinline__ void load_row_quad(RowRegs<NW>& dst, const float* __restrict__ xTb, int row, int Cp, int J)
+{
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int base = (J + 256 * i) * 8;
+        const float* p = xTb + (size_t)row * Cp + (base < Cp ? base : 0);
+        const float4 v0 = *reinterpret_cast<const float4*>(p);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+        dst.v[i][0] = v0.x; dst.v[i][1] = v0.y; dst.v[i][2] = v0.z; dst.v[i][3] = v0.w;
+        dst.v[i][4] = v1.x; dst.v[i][5] = v1.y; dst.v[i][6] = v1.z; dst.v[i][7] = v1.w;
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void recurrence_quad_body(int* lds_raw, int b, const float* __restrict__ xT, const float* __restrict__ inv,
+                                                     const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M,
+                                                     float* __restrict__ wn_out, float* __restrict__ wo_out)
+{
+    const RecLds rl = recurrence_prologue(lds_raw, b, inv, part, mpi, N, M);
+    __shared__ float wsum[2][4];
+    const int J = threadIdx.x, lane = J & 63, wv = J >> 6;
+    const float* xTb = xT + (size_t)b * N * Cp;
+
+    RowRegs<NW> o, pu[QD], pk[QD];
+    load_row_quad<NW>(o, xTb, rl.kq0, Cp, J);
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+        if ((J + 256 * i) * 8 >= Cp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[i][e] = 0.0f;
+        }
+#pragma unroll
+    for (int d = 0; d < QD; ++d) { load_row_quad<NW>(pu[d], xTb, rl.q_s[d], Cp, J); load_row_quad<NW>(pk[d], xTb, rl.kq_s[d], Cp, J); }
+
+    const int nsteps = M - 1;
+    auto step = [&](const RowRegs<NW>& ru, const RowRegs<NW>& rk, int s) {
+        const float iq = rl.iv_s[s], v = rl.vm_s[s];
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const bool live = (J + 256 * i) * 8 < Cp;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = (live ? ru.v[i][e] : 0.0f) * iq;
+                acc = __builtin_fmaf(u, o.v[i][e], acc);
+            }
+        }
+        const float sw = wave_sum_canonical(acc);
+        float* slot = wsum[s & 1];
+        if (lane == 0) slot[wv] = sw;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const float at = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+        const float sden = at + v;
+        const float wn = at / sden, wo = v / sden;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const bool live = (J + 256 * i) * 8 < Cp;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t0 = wn * o.v[i][e];
+                const float t1 = wo * (live ? rk.v[i][e] : 0.0f);
+                o.v[i][e] = t0 + t1;
+            }
+        }
+        if (J == 0) { rl.wn_s[s + 1] = wn; rl.wo_s[s + 1] = wo; }
+    };
+
+    int t = 0;
+    for (; t + QD <= nsteps; t += QD) {
+#pragma unroll
+        for (int d = 0; d < QD; ++d) {
+            step(pu[d], pk[d], t + d);
+            load_row_quad<NW>(pu[d], xTb, rl.q_s[t + d + QD], Cp, J);        // padding entries repeat a valid row
+            load_row_quad<NW>(pk[d], xTb, rl.kq_s[t + d + QD], Cp, J);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < QD - 1; ++d)
+        if (t + d < nsteps) step(pu[d], pk[d], t + d);        // uniform across the block: every wave reaches the barrier
+    __syncthreads();
+    for (int l = J; l < M; l += 256) { wn_out[(size_t)b * M + l] = rl.wn_s[l]; wo_out[(size_t)b * M + l] = rl.wo_s[l]; }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // non-masked columns: out[c][q] = P[ind[q]][c]  (one-hot kbar column, IPSRFunction.py:129-133).
 // (masked columns are written too and overwritten by recon_masked_kernel afterwards.)
@@ -370,7 +463,7 @@ __device__ __forceinline__ void prepare_body(int* lds, int b, const CorrPartials
         flag[q] = 0; cnt[q] = 0;
     }
     __syncthreads();
-    for (int l = tid; l < M; l += 256) { const int q = mpi[l]; flag[indm[q]] = 1; key[q] = -1; }
+    for (int l = tid; l < M; l += 256) { const int q = mpi_at(mpi, l, N); flag[indm[q]] = 1; key[q] = -1; }
     __syncthreads();
     for (int q = tid; q < N; q += 256)
         if (key[q] >= 0) atomicAdd(&cnt[key[q]], 1);
@@ -407,7 +500,7 @@ __device__ __forceinline__ void prepare_body(int* lds, int b, const CorrPartials
     __syncthreads();
     const int mp = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     for (int j = mp + tid; j < Mc; j += 256) dlist[(size_t)b * Mc + j] = 0;     // padding rows of the GEMM: any valid patch
-    for (int l = tid; l < M; l += 256) jq[(size_t)b * M + l] = flag[indm[mpi[l]]] - 1;
+    for (int l = tid; l < M; l += 256) jq[(size_t)b * M + l] = flag[indm[mpi_at(mpi, l, N)]] - 1;
 
     // ---- one-hot rows of trunc(kbar): non-masked q grouped by k = ind[q], ascending q inside a group.  One wave walks
     // the positions 64 at a time; lanes with equal keys find each other with one ballot per key bit.  Keys and cursors
@@ -449,7 +542,8 @@ __global__ void __launch_bounds__(256) attention_stage_kernel(AttnArgs a, int nr
     __shared__ float gtile[32][33];
     const int bid = blockIdx.x;
     if (bid < nrec) {
-        if constexpr (NCH > 3) recurrence_wide_body<NCH>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
+        if constexpr (NCH > 4) recurrence_quad_body<(NCH + 3) / 4>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
+        else if constexpr (NCH > 3) recurrence_wide_body<NCH>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
         else recurrence_body<NCH, FULL>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
     } else if (bid < nrec + a.B) {
         prepare_body(lds_dyn, bid - nrec, a.part, a.mpi, a.N, a.M, a.Mc, nbits, a.ind, a.vmax, a.dlist, a.mprime, a.jq, a.rankflag,
@@ -542,7 +636,7 @@ __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __r
             if (cnt <= AC_KEEP) {
 #pragma unroll
                 for (int i = 0; i < AC_KEEP; ++i)
-                    if (i < cnt) { entB_q[off + i] = mpi[keep_l[i]]; entB_w[off + i] = keep_w[i]; }
+                    if (i < cnt) { entB_q[off + i] = mpi_at(mpi, keep_l[i], N); entB_w[off + i] = keep_w[i]; }
             } else {                                          // rare: many survivors in one column -> replay it
                 float a2 = 0.0f;
                 int e = off;
@@ -551,7 +645,7 @@ __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __r
                     a2 = a2 * s.x;
                     a2 = (__float_as_int(s.z) == j) ? a2 + s.y : a2;
                     const float t = truncf(a2);
-                    if (t != 0.0f) { entB_q[e] = mpi[l]; entB_w[e] = t; ++e; }
+                    if (t != 0.0f) { entB_q[e] = mpi_at(mpi, l, N); entB_w[e] = t; ++e; }
                 }
             }
         }
@@ -657,7 +751,7 @@ __global__ void __launch_bounds__(256) recon_masked_kernel(const float* __restri
 
     const int l = l0 + wn * 32 + r;
     if (l < M) {
-        const int q = mpi[l];
+        const int q = mpi_at(mpi, l, N);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int c = c0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -698,11 +792,11 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
             case 2: LAUNCH_STAGE(2); break;
             case 3: LAUNCH_STAGE(3); break;
             case 4: LAUNCH_STAGE(4); break;
-            // wide patches (shift_sz > 1: C*p*p numbers per patch): one instantiation per 1024 up to 5120 (C=512, p=3 is 4608)
-            case 5: case 6: LAUNCH_STAGE2(6, false); break;
-            case 7: case 8: LAUNCH_STAGE2(8, false); break;
-            case 9: case 10: LAUNCH_STAGE2(10, false); break;
-            default: return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: patch length C*p*p=%d > 5120 not supported", C);
+            // wide patches (shift_sz > 1: C*p*p numbers per patch): four-wave recurrence, one instantiation per 2048 numbers
+            case 5: case 6: case 7: case 8: LAUNCH_STAGE2(8, false); break;              // 2 chunks per lane of 256
+            case 9: case 10: case 11: case 12: LAUNCH_STAGE2(12, false); break;          // 3 (C=512, p=3: 4608 numbers)
+            case 13: case 14: case 15: case 16: LAUNCH_STAGE2(16, false); break;         // 4
+            default: return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: patch length C*p*p=%d > 8192 not supported", C);
         }
 #undef LAUNCH_STAGE
 #undef LAUNCH_STAGE2

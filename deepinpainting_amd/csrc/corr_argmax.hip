@@ -399,12 +399,22 @@ static void plan(int B, int N, int* qtiles, int* ktiles, int* ksplit, int* kt_pe
 {
     *qtiles = cdiv(N, BN);
     *ktiles = cdiv(N, BM);
-    // aim for >= 2 workgroups per CU (512) so the chip is full and the tail is short
-    int want = cdiv(512, B * *qtiles);
-    if (want < 1) want = 1;
-    if (want > *ktiles) want = *ktiles;
-    *kt_per_wg = cdiv(*ktiles, want);
-    *ksplit = cdiv(*ktiles, *kt_per_wg);
+    // The chip runs 512 workgroups at a time (256 CUs x 2).  Pick the k-tiles per workgroup that minimises
+    // (rounds of 512 workgroups) x (k-tiles per workgroup + a fixed per-workgroup cost of about a quarter tile); on
+    // ties the larger one (fewer partials).  N=1024, B=8: 8 splits of 1 tile (512 workgroups).  The 3x3-patch window
+    // grid N'=3844, B=4: 31 q-tiles x 4 splits of 8,8,8,7 tiles = 496 workgroups in ONE round (5 splits of 7 would be
+    // 620 workgroups = two rounds, the second one a fifth full).
+    const int base = B * *qtiles;
+    long best_cost = -1;
+    int best = *ktiles;
+    for (int kpw = *ktiles; kpw >= 1; --kpw) {
+        const int ks = cdiv(*ktiles, kpw);
+        const long rounds = cdiv(base * ks, 512);
+        const long cost = rounds * (4L * kpw + 1);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = kpw; }
+    }
+    *kt_per_wg = best;
+    *ksplit = cdiv(*ktiles, best);
 }
 
 size_t corr_argmax_ws_bytes(int B, int C, int N)

@@ -73,6 +73,14 @@ __device__ __forceinline__ void merged_argmax(const CorrPartials& cp, int b, int
     }
 }
 
+// mask_point_idx[l] as the kernels use it: the caller promises values in [0, N) (the host wrappers check what they can
+// without a device sync); a stray value must give a wrong answer, never an out-of-bounds access.
+__device__ __forceinline__ int mpi_at(const int32_t* __restrict__ mpi, int l, int N)
+{
+    const int q = mpi[l];
+    return q < 0 ? 0 : (q >= N ? N - 1 : q);
+}
+
 // ---- device-side kernels' launchers (one per .hip file) ----
 int launch_feat_mask(const uint8_t* mask, int H, int W, int layers, float threshold, uint8_t* feat,
                      void* ws, size_t ws_bytes, hipStream_t st);

@@ -30,9 +30,17 @@ class IPSRFunction(torch.autograd.Function):
         ctx.flatten_offsets = flatten_offsets
         ctx.bz, _, ctx.h, ctx.w = input.size()
 
+        # the index tensors must belong to THIS geometry: they live on the window grid (h-p+1)(w-p+1)
+        n_win = (ctx.h - int(shift_sz) + 1) * (ctx.w - int(shift_sz) + 1)
+        if torch.is_tensor(flag) and flag.numel() != n_win:
+            raise RuntimeError("IPSRFunction: flag has %d entries but a %dx%d feature with shift_sz=%d has %d patch positions"
+                               % (flag.numel(), ctx.h, ctx.w, int(shift_sz), n_win))
         mpi32 = getattr(mask_point_idx, "_ipsr_i32", None)
         if mpi32 is None or mpi32.device != input.device:
+            # a foreign index tensor (not produced by util.cal_mask_given_mask_thred here): check its range once
             mpi32 = mask_point_idx.to(device=input.device, dtype=torch.int32)
+            if mpi32.numel() and (int(mpi32.min()) < 0 or int(mpi32.max()) >= n_win):
+                raise RuntimeError("IPSRFunction: mask_point_idx out of range [0, %d)" % n_win)
         # `ref` is the VGG namedtuple; only relu4_3 is read (reference :49)
         need_grad = ctx.needs_input_grad[0]      # grad mode is off inside Function.forward, so ask the ctx
         # the layer itself is fp32 whatever the surrounding autocast regime (BASELINE config 5 runs the convs in bf16)

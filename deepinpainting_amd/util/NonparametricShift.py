@@ -3,7 +3,8 @@
 The reference wraps the patches into throw-away nn.Conv2d / nn.ConvTranspose2d modules per sample per
 step (:43-55).  Here the "encoder" is the fused correlation+arg-max kernel and the "decoder" is the
 reconstruction kernel; this class keeps the reference's entry points for callers that use it directly.
-Only patch_size == 1, stride == 1 (what the reference can actually run, models/IPSRFunction.py:134).
+This stand-alone helper covers patch_size == 1, stride == 1 (what the reference can actually run,
+models/IPSRFunction.py:134); the layer itself (IPSR_model / IPSRFunction -> ipsr_forward) also takes shift_sz > 1.
 """
 import torch
 
@@ -39,7 +40,7 @@ class NonparametricShift(object):
         if normalize or interpolate:
             raise NotImplementedError
         if patch_size != 1 or stride != 1:
-            raise NotImplementedError("only patch_size=1, stride=1 is implemented")
+            raise NotImplementedError("this helper implements patch_size=1, stride=1 only; use IPSR_model for shift_sz > 1")
         C, h, w = target_img.shape
         patches_all, patches_part, patches_mask = self._extract_patches(target_img, patch_size, stride,
                                                                        nonmask_point_idx, mask_point_idx)

@@ -77,7 +77,9 @@ int ipsr_corr_argmax(const float* xn, const float* ref, int B, int C, int N,
 /* ---- whole layer forward (K3..K7) -------------------------------------------------------------
  * replaces IPSRFunction.forward (models/IPSRFunction.py:13-140).
  *   x, ref            [B,C,h,w] fp32           (ref = ref.relu4_3)
- *   mask_point_idx    [M] i32  raster-ordered masked patch positions, shared by the whole batch
+ *   mask_point_idx    [M] i32  raster-ordered masked patch positions in [0,N), shared by the whole batch; device
+ *                     data, so NOT validated here — a stray value is clamped into range (wrong answer, never an
+ *                     out-of-bounds access); the Python wrapper checks foreign tensors
  *                     (reference semantics: one mask per batch, models/IPSR.py:36)
  *   out               [B,C,h,w] fp32
  *   ind, vmax         [B,N]     arg-max / max of the correlation (kept for inspection + backward)

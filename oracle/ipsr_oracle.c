@@ -22,7 +22,8 @@
  *     (what v_mfma_f32_32x32x2_f32 computes when K is walked in order);
  *   - patch norm: 8 contiguous channel segments, fmaf chain inside each, partials added in order;
  *   - recurrence dot <u, o>: 64 "lanes", lane j owns the 8-channel chunks ch with ch % 64 == j
- *     (fmaf chain, ascending), then an xor-butterfly over the 64 partials;
+ *     (fmaf chain, ascending), then an xor-butterfly over the 64 partials (patches wider than 2048
+ *     numbers: 256 lanes = four waves, see lane_dot);
  *   - everything else is element-wise with every product and sum rounded separately (no FMA
  *     contraction: build with -ffp-contract=off).
  */
@@ -162,25 +163,35 @@ HOT int ipsr_corr_argmax_cpu(const float* xn, const float* ref, int B, int C, in
     return IPSR_OK;
 }
 
-/* 64-lane dot used by the coherent-attention recurrence (IPSRFunction.py:109-118). */
+/* Dot used by the coherent-attention recurrence (IPSRFunction.py:109-118), in the order the HIP wave(s) reduce it:
+ * "lanes" own 8-element chunks round-robin (chunk ch -> lane ch % L), one fmaf chain per lane in ascending ch; the 64
+ * partials of a wave are summed by an xor-butterfly.  L = 64 (one wave) for patches up to 2048 numbers; wider patches
+ * (shift_sz > 1: C*p*p numbers) are spread over four waves, L = 256, and the four wave sums are added as (s0+s1)+(s2+s3). */
 HOT static float lane_dot(const float* u, const float* o, int C)
 {
-    float p[64];
-    for (int j = 0; j < 64; ++j) p[j] = 0.0f;
+    const int nwave = ((C + 7) & ~7) > 2048 ? 4 : 1;
+    const int L = 64 * nwave;
+    float p[256];
+    for (int j = 0; j < L; ++j) p[j] = 0.0f;
     const int nch = (C + 7) / 8;
     for (int ch = 0; ch < nch; ++ch) {
-        int j = ch & 63;
+        int j = ch % L;
         int c1 = ch * 8 + 8 < C ? ch * 8 + 8 : C;
         float a = p[j];
         for (int c = ch * 8; c < c1; ++c) a = fmaf(u[c], o[c], a);
         p[j] = a;
     }
-    for (int s = 1; s < 64; s <<= 1) {
-        float t[64];
-        for (int j = 0; j < 64; ++j) t[j] = p[j] + p[j ^ s];
-        memcpy(p, t, sizeof(p));
+    float sw[4];
+    for (int wv = 0; wv < nwave; ++wv) {
+        float* pw = p + 64 * wv;
+        for (int s = 1; s < 64; s <<= 1) {
+            float t[64];
+            for (int j = 0; j < 64; ++j) t[j] = pw[j] + pw[j ^ s];
+            memcpy(pw, t, sizeof(t));
+        }
+        sw[wv] = pw[0];
     }
-    return p[0];
+    return nwave == 1 ? sw[0] : (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 
 /* Sparse form of trunc(kbar) kept for the backward, per sample (int32 words), two CSRs over the patch index k:

@@ -109,8 +109,12 @@ def test_ipsr_function_12_arg_surface():
         IPSRFunction.apply(x[0], feat, Vgg(None, None, None, cu(d["ref"])), 1, 1, 1.0, flag, nonmask, midx, fo, sx, sy)
     with pytest.raises(AssertionError, match="Mask dimension must be 2"):
         IPSRFunction.apply(x, feat[None], Vgg(None, None, None, cu(d["ref"])), 1, 1, 1.0, flag, nonmask, midx, fo, sx, sy)
-    with pytest.raises(NotImplementedError):     # shift_sz = 3: the reference fails too (IPSRFunction.py:134)
+    with pytest.raises(RuntimeError, match="patch positions"):     # shift_sz = 3 with index tensors made for shift_sz = 1
         IPSRFunction.apply(x, feat, Vgg(None, None, None, cu(d["ref"])), 3, 1, 1.0, flag, nonmask, midx, fo, sx, sy)
+    with pytest.raises(RuntimeError, match="out of range"):         # foreign mask_point_idx beyond the grid
+        IPSRFunction.apply(x, feat, Vgg(None, None, None, cu(d["ref"])), 1, 1, 1.0, flag, nonmask, midx_plain + 60, fo, sx, sy)
+    with pytest.raises(NotImplementedError):                        # stride != 1
+        IPSRFunction.apply(x, feat, Vgg(None, None, None, cu(d["ref"])), 1, 2, 1.0, flag, nonmask, midx, fo, sx, sy)
 
 
 @pytest.mark.parametrize("name", ["layer_c16_8x8_center", "layer_c32_16x16_stroke", "layer_c512_8x8_cfg1"])
@@ -349,3 +353,49 @@ def test_trainer_bf16_autocast_config5(tmp_path):
         assert m.fake_B.dtype == torch.float32 and m.netG.model.model[0].weight.dtype == torch.float32
         assert all(np.isfinite(v) for v in losses[amp])
     np.testing.assert_allclose(losses[True], losses[False], rtol=0.08)
+
+
+PATCH_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "patch_layer_*.npz")))
+
+
+@pytest.mark.parametrize("name", PATCH_CASES)
+def test_ipsr_model_shift_sz_gt1_vs_reference(name):
+    """IPSR_model(shift_sz=2|3): forward == what the reference's own forward computes before it raises (fixture);
+    autograd backward == the oracle's extension."""
+    from deepinpainting_amd.models.IPSR_model import IPSR_model
+    from oracle import ipsr_oracle as orc
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    p = int(d["patch"])
+    layer = IPSR_model(float(d["threshold"]), 1, p, 1, 1, 0.5)
+    feat = layer.set_mask(cu(d["mask_img"].astype(bool))[None, None], 3, float(d["threshold"]))
+    np.testing.assert_array_equal(feat.cpu().numpy(), d["feat_mask"])
+    layer.set_ref(Vgg(None, None, None, cu(d["ref"])))
+    x = cu(d["x"]).requires_grad_(True)
+    y = layer(x)
+    np.testing.assert_array_equal(layer.mask_point_idx.cpu().numpy(), d["mask_point_idx"])
+    np.testing.assert_array_equal(layer.flag.cpu().numpy(), d["flag"])
+    assert np.abs(y.detach().cpu().numpy() - d["out"]).max() <= ATOL
+    g = np.random.RandomState(3).standard_normal(d["x"].shape).astype(np.float32)
+    y.backward(cu(g))
+    fo = orc.forward(d["x"], d["ref"], d["mask_point_idx"], patch=p)
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), orc.backward_patch(g, len(d["mask_point_idx"]), fo.bwd_index, 0.5, p))
+
+
+def test_trainer_shift_sz3_runs(tmp_path):
+    """The whole training step with 3x3 patches in the IPSR layer (BASELINE config 4's patch size) at 256x256:
+    window grid 30x30 of 4608-number patches.  The reference cannot run this (IPSRFunction.py:134)."""
+    from deepinpainting_amd.options import Option
+    from deepinpainting_amd.models.models import create_model
+    opt = Option(gpu_ids=[0], batchSize=2, use_dropout=False, quiet=True, shift_sz=3, checkpoints_dir=str(tmp_path))
+    torch.manual_seed(4)
+    m = quiet(create_model, opt)
+    img, mask, ref = golden_cases.trainer_inputs(B=2)
+    w0 = m.netG.model.model[0].weight.detach().clone()
+    for _ in range(2):
+        m.set_input(img.cuda(), mask.cuda(), ref.cuda())
+        m.set_ref_latent()
+        m.set_gt_latent()
+        m.optimize_parameters()
+    e = m.get_current_errors()
+    assert all(np.isfinite(v) for v in e.values()), e
+    assert not torch.equal(w0, m.netG.model.model[0].weight.detach())
