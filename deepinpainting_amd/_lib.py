@@ -34,6 +34,8 @@ SIGNATURES = {
     "ipsr_backward_workspace_bytes": (c_size_t, [c_int] * 5),
     "ipsr_backward_patch": (c_int, [c_void_p, c_int, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
+    "ipsr_bias_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ipsr_bias_relu_pool2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "innercos_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "innercos_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                               c_void_p, c_size_t, c_void_p]),

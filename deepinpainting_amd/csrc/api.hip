@@ -288,6 +288,23 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
     return launch_fold(tu, B, C, h, w, patch, grad_in, st, grad_out);
 }
 
+int ipsr_bias_act(float* x, const float* bias, int B, int C, int HW, int act, float slope, void* stream)
+{
+    if (!x) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: null pointer");
+    if (B < 1 || C < 1 || HW < 1) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: bad size B=%d C=%d HW=%d", B, C, HW);
+    if ((HW & 3) == 0 && !aligned16(x)) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: x must be 16-byte aligned");
+    return launch_bias_act(x, bias, B, C, HW, act, slope, static_cast<hipStream_t>(stream));
+}
+
+int ipsr_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H, int W, float* y, void* stream)
+{
+    if (!x || !y) return fail(IPSR_ERR_INVALID, "ipsr_bias_relu_pool2: null pointer");
+    if (B < 1 || C < 1 || H < 2 || W < 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_relu_pool2: bad size B=%d C=%d H=%d W=%d", B, C, H, W);
+    if ((W & 3) == 0 && (!aligned16(x) || (reinterpret_cast<uintptr_t>(y) & 7u)))
+        return fail(IPSR_ERR_INVALID, "ipsr_bias_relu_pool2: x must be 16-byte and y 8-byte aligned");
+    return launch_bias_relu_pool2(x, bias, B, C, H, W, y, static_cast<hipStream_t>(stream));
+}
+
 size_t innercos_workspace_bytes(int B, int Cuse, int N) { return innercos_ws_bytes(B, Cuse, N); }
 
 int innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,

@@ -130,6 +130,10 @@ int launch_attention(const AttnArgs& a, hipStream_t st);
 int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn, const int32_t* bwd_index,
                     float triple_w, int B, int C, int N, float* gin, hipStream_t st, int identity = 1);
 
+// pointwise.hip — VGG16 feature net glue (bias / ReLU / 2x2 max-pool in one pass)
+int launch_bias_act(float* x, const float* bias, int B, int C, int HW, int act, float slope, hipStream_t st);
+int launch_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H, int W, float* y, hipStream_t st);
+
 size_t innercos_ws_bytes(int B, int Cuse, int N);
 int launch_innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,
                          float strength, float* loss, void* ws, size_t ws_bytes, hipStream_t st);

@@ -14,6 +14,7 @@ from collections import namedtuple
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 # torchvision vgg16 'D' configuration up to features[22]
 _CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512]
@@ -77,7 +78,38 @@ class Vgg16(torch.nn.Module):
             raise RuntimeError("VGG16 weights file lacks %s" % missing[:4])
         self.load_state_dict(mapped)
 
+    def _fused_slice(self, seq, x):
+        """No-grad fp32 HIP path of one slice: convolutions without bias (MIOpen has none; PyTorch would add it in a
+        separate pass), then ONE pass for bias + ReLU (+ the 2x2 max-pool when it follows) — ops.bias_act_ /
+        ops.bias_relu_pool2, bit-identical to Conv2d(bias) -> ReLU(inplace) -> MaxPool2d."""
+        from .. import ops
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                y = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+                if i + 2 < len(mods) and isinstance(mods[i + 2], nn.MaxPool2d) and y.size(2) % 2 == 0 and y.size(3) % 2 == 0:
+                    x = ops.bias_relu_pool2(y, m.bias)
+                    i += 3
+                else:
+                    x = ops.bias_act_(y, m.bias, "relu")
+                    i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def forward(self, X):
+        fused = (X.is_cuda and X.dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
+                 and not (torch.is_grad_enabled() and (X.requires_grad or self.slice1[0].weight.requires_grad)))
+        if fused:
+            X = X.contiguous()
+            h1 = self._fused_slice(self.slice1, X)
+            h2 = self._fused_slice(self.slice2, h1)
+            h3 = self._fused_slice(self.slice3, h2)
+            h4 = self._fused_slice(self.slice4, h3)
+            return VggOutputs(h1, h2, h3, h4)
         h1 = self.slice1(X)
         h2 = self.slice2(h1)
         h3 = self.slice3(h2)

@@ -152,6 +152,27 @@ def backward(grad_out, bwd_index, triple_w, M, patch=1):
     return gin
 
 
+def bias_act_(x, bias, act="relu", slope=0.2):
+    """In place x[b,c,...] = act(x + bias[c]) on a contiguous fp32 [B,C,*] tensor.  act: none | relu | leaky."""
+    x = _req(x, torch.float32, "x")
+    B, C = x.shape[0], x.shape[1]
+    hw = x.numel() // (B * C)
+    code = {"none": 0, "relu": 1, "leaky": 2}[act]
+    _lib.check(_lib.lib().ipsr_bias_act(x.data_ptr(), bias.data_ptr() if bias is not None else None, B, C, hw, code,
+                                        float(slope), _stream()), "ipsr_bias_act")
+    return x
+
+
+def bias_relu_pool2(x, bias):
+    """max_pool2d(relu(x + bias[c]), 2, 2) of a contiguous fp32 [B,C,H,W] tensor in one pass."""
+    x = _req(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ipsr_bias_relu_pool2(x.data_ptr(), bias.data_ptr() if bias is not None else None, B, C, H, W,
+                                               y.data_ptr(), _stream()), "ipsr_bias_relu_pool2")
+    return y
+
+
 def innercos_loss(x, cuse, mask_f32, target, strength):
     """K9.  x [B,Cx,h,w] (only the first `cuse` channels are read), target [B,cuse,h,w] -> loss [] fp32."""
     x = _req(x, torch.float32, "in_data")

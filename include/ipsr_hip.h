@@ -126,6 +126,16 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
                         int B, int C, int h, int w, int patch, float* grad_in,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* ---- VGG16 feature-net glue ----------------------------------------------------------------------
+ * replaces the Conv2d bias add + ReLU(inplace) [+ MaxPool2d(2,2)] passes of torchvision's vgg16.features as wrapped by
+ * models/vgg16.py:6-37 (run three times per training step without gradients, models/IPSR.py:163,187,212-213):
+ * the convolution is issued without bias and one pass does the rest, with the same arithmetic (bit-identical).
+ *   ipsr_bias_act          in place  x[b,c,:] = act(x[b,c,:] + bias[c]);  act: 0 none, 1 ReLU, 2 LeakyReLU(slope);
+ *                          bias may be NULL
+ *   ipsr_bias_relu_pool2   y[b,c,i,j] = max over the 2x2 window of relu(x + bias[c]);  y is [B,C,H/2,W/2] */
+int ipsr_bias_act(float* x, const float* bias, int B, int C, int HW, int act, float slope, void* stream);
+int ipsr_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H, int W, float* y, void* stream);
+
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
  * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.

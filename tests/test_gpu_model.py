@@ -399,3 +399,41 @@ def test_trainer_shift_sz3_runs(tmp_path):
     e = m.get_current_errors()
     assert all(np.isfinite(v) for v in e.values()), e
     assert not torch.equal(w0, m.netG.model.model[0].weight.detach())
+
+
+def test_vgg16_fused_glue_bit_identical():
+    """Vgg16's no-grad HIP path (bias-free conv + one bias/ReLU[/max-pool] pass) against the plain module path, and the two
+    pointwise entry points against torch, bit for bit, on odd shapes.  (Whole-net comparison with a tolerance: some
+    MIOpen convolutions are not run-to-run deterministic, the same call twice differs by an ulp.)"""
+    from deepinpainting_amd.models.vgg16 import Vgg16
+    from deepinpainting_amd import ops
+    v = Vgg16().cuda().eval()
+    golden_cases.reinit_deterministic(v, 31)
+    with torch.no_grad():
+        for mod in v.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.bias.copy_(torch.linspace(-0.5, 0.5, mod.bias.numel()))
+    x = torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1
+    with torch.no_grad():
+        fused = v(x)
+        plain = [v.slice1(x)]
+        for s in (v.slice2, v.slice3, v.slice4):
+            plain.append(s(plain[-1]))
+    for a, b in zip(fused, plain):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    # with gradients requested the autograd path is taken and gives the same values
+    xg = x.clone().requires_grad_(True)
+    out = v(xg)
+    assert out.relu4_3.requires_grad
+    torch.testing.assert_close(out.relu4_3.detach(), fused.relu4_3, rtol=1e-5, atol=1e-5)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for shape in ((2, 5, 7, 9), (1, 3, 8, 12), (3, 4, 6, 6)):
+        t = torch.randn(shape, device="cuda", generator=g)
+        b = torch.randn(shape[1], device="cuda", generator=g)
+        ref = t + b.view(1, -1, 1, 1)
+        assert torch.equal(ops.bias_act_(t.clone(), b, "relu"), torch.relu(ref))
+        assert torch.equal(ops.bias_act_(t.clone(), b, "none"), ref)
+        assert torch.equal(ops.bias_act_(t.clone(), b, "leaky", 0.2), torch.nn.functional.leaky_relu(ref, 0.2))
+        assert torch.equal(ops.bias_act_(t.clone(), None, "relu"), torch.relu(t))
+        assert torch.equal(ops.bias_relu_pool2(t, b), torch.nn.functional.max_pool2d(torch.relu(ref), 2, 2))
