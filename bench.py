@@ -57,6 +57,7 @@ def _private_miopen_db():
 
 _private_miopen_db()
 
+STEP_FLOPS_PER_IMAGE = 378.4e9     # conv/mm forward+backward of one training step at 256x256 with 3 VGG passes
 METRIC = "train images/sec at 256x256, batch 8/GPU, 1/2/4/8 MI355X; IPSR layer ms"
 FINE, BATCH, C_FEAT, H_FEAT = 256, 8, 512, 32
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32-input MFMA = 64 FLOP/clk/SIMD
@@ -184,9 +185,11 @@ def main():
                  checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
     torch.manual_seed(1234)                       # identical init on every rank (rank 0 is broadcast anyway)
     model = quiet(create_model, opt)
-    if os.environ.get("IPSR_BENCH_CHANNELS_LAST", "0") == "1":      # experiment knob, not the default
-        for net in (model.netG, model.netP, model.netD, model.netF, model.vgg):
-            net.to(memory_format=torch.channels_last)
+    cl = os.environ.get("IPSR_BENCH_CHANNELS_LAST", "0")             # experiment knob, not the default: "1" = all nets,
+    if cl != "0":                                                    # or a comma list of netG,netP,netD,netF,vgg
+        names = ("netG", "netP", "netD", "netF", "vgg") if cl == "1" else tuple(cl.split(","))
+        for name in names:
+            getattr(model, name).to(memory_format=torch.channels_last)
     img, mask, ref = synthetic_batch(device, args.batch, 1234 + rank)
 
     lib = _lib.lib()
@@ -257,6 +260,13 @@ def main():
                      "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,
                      "traffic": traffic, "flops_per_launch": flops, "kernel_ms": round(kms, 5), "launches_timed": len(kern_ms)},
+        # the whole step against the same roofline: direct-convolution FLOPs of the step AS EXECUTED here (SURVEY §8d:
+        # 414.9 GFLOP/image in the reference, minus the VGG pass it computes twice, models/IPSR.py:187 vs :213)
+        "step_roofline": {"bound": "mfma", "flops_per_image": STEP_FLOPS_PER_IMAGE,
+                          "achieved": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                          "unit": "TFLOP/s per GPU", "frac": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                          "note": "fp32 only; MIOpen's Winograd kernels execute fewer real multiplies than this direct count"}
+        if args.dtype == "f32" else None,
         "losses_last_step": {k: round(v, 4) for k, v in errs.items()},
     }
     if world == 1 and not args.no_cpu_baseline:

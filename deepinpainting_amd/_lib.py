@@ -36,6 +36,11 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     "ipsr_bias_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ipsr_bias_relu_pool2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ipsr_instnorm_act_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ipsr_instnorm_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                           c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ipsr_bias_act_backward": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "innercos_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "innercos_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                               c_void_p, c_size_t, c_void_p]),

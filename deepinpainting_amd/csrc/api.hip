@@ -305,6 +305,37 @@ int ipsr_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H,
     return launch_bias_relu_pool2(x, bias, B, C, H, W, y, static_cast<hipStream_t>(stream));
 }
 
+int ipsr_instnorm_act_forward(const float* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
+                              int B, int C, int HW, float* y, float* mean, float* rstd, void* stream)
+{
+    if (!x || !y || !mean || !rstd) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: null pointer");
+    if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: bad argument B=%d C=%d HW=%d act=%d", B, C, HW, act);
+    if ((HW & 3) == 0 && (!aligned16(x) || !aligned16(y))) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: x/y must be 16-byte aligned");
+    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, y, mean, rstd, static_cast<hipStream_t>(stream));
+}
+
+int ipsr_instnorm_act_backward(const float* dy, const float* y, const float* x, const float* bias, const float* gamma,
+                               const float* mean, const float* rstd, int act, float slope, int B, int C, int HW,
+                               float* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream)
+{
+    if (!dy || !y || !x || !mean || !rstd || !dx) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: null pointer");
+    if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: bad argument");
+    if ((HW & 3) == 0 && (!aligned16(dy) || !aligned16(y) || !aligned16(x) || !aligned16(dx)))
+        return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: tensors must be 16-byte aligned");
+    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, dx, dgamma_p, dbeta_p, dbias_p,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int ipsr_bias_act_backward(const float* dy, const float* y, int act, float slope, int B, int C, int HW, float* dx, float* dbias_p,
+                           void* stream)
+{
+    if (!dy || !y || !dx) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: null pointer");
+    if (B < 1 || C < 1 || HW < 1 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: bad argument");
+    if ((HW & 3) == 0 && (!aligned16(dy) || !aligned16(y) || !aligned16(dx)))
+        return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: tensors must be 16-byte aligned");
+    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, dx, dbias_p, static_cast<hipStream_t>(stream));
+}
+
 size_t innercos_workspace_bytes(int B, int Cuse, int N) { return innercos_ws_bytes(B, Cuse, N); }
 
 int innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,

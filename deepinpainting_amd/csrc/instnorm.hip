@@ -1,0 +1,282 @@
+// instnorm.hip — conv-bias + InstanceNorm2d(affine) + LeakyReLU/ReLU in one pass, forward and backward.
+//
+// Reference: every U-Net level and discriminator stage is  Conv2d/ConvTranspose2d(bias) -> InstanceNorm2d -> (the next
+// level's) LeakyReLU(0.2, inplace) or ReLU(inplace)  (models/networks.py:220-259, 404-432, 470-497, 507-514).  MIOpen
+// convolutions carry no bias, so PyTorch runs a broadcast add, the norm (2-3 passes) and the activation as separate
+// kernels — 4 reads + 3 writes of the activation forward, 6 reads + 2 writes backward (+ a bias-gradient reduction).
+// Here one workgroup owns one (sample, channel) plane, keeps it in REGISTERS between the statistics and the output:
+//     forward   z = x + bias[c];  mean, var over the plane;  y = act((z - mean) * rstd * gamma[c] + beta[c])      1 R + 1 W
+//     backward  dz = dy * act'(y);  xh = (x + bias - mean) * rstd;  s1 = sum dz, s2 = sum dz*xh;
+//               dx = gamma * rstd * (dz - s1/HW - xh * s2/HW);                                                    3 R + 1 W
+//               per-plane partials: dgamma += s2, dbeta += s1, dbias += sum dx   (summed over the batch by the host)
+// HBM-bound.  Planes up to 128x128 (16384 elements) — the largest normalised map of the reference's nets at 256x256.
+// fp32 tolerance vs torch (different summation order): ~1e-6 relative, asserted in tests/test_gpu_model.py.
+#include "ipsr_common.h"
+
+namespace ipsr {
+
+template <int T>
+__device__ __forceinline__ float block_sum(float v, float* red)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    if (T == 64) return v;
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();                       // protect `red` from the previous use
+    if ((threadIdx.x & 63) == 0) red[wv] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < T / 64; ++i) t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope)
+{
+    if (act == 1) return v > 0.0f ? v : 0.0f;
+    if (act == 2) return v > 0.0f ? v : v * slope;
+    return v;
+}
+// derivative from the OUTPUT (slope > 0 keeps the sign, ReLU maps negatives to 0)
+__device__ __forceinline__ float act_bwd(float y, int act, float slope)
+{
+    if (act == 1) return y > 0.0f ? 1.0f : 0.0f;
+    if (act == 2) return y > 0.0f ? 1.0f : slope;
+    return 1.0f;
+}
+
+// NE = plane elements a thread may hold; VEC: 16-byte accesses (HW % 4 == 0)
+template <int T, int NE, bool VEC>
+__global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, int act, float slope, int C, int HW,
+                                                             float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out)
+{
+    __shared__ float red[4];
+    const int plane = blockIdx.x, c = plane % C, tid = threadIdx.x;
+    const float bv = bias ? bias[c] : 0.0f;
+    const float* xp = x + (size_t)plane * HW;
+    float* yp = y + (size_t)plane * HW;
+    float v[NE];
+    float sum = 0.0f;
+    if (VEC) {
+        const int n4 = HW >> 2;
+#pragma unroll
+        for (int k = 0; k < NE / 4; ++k) {
+            const int i = k * T + tid;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n4) {
+                t = reinterpret_cast<const float4*>(xp)[i];
+                t.x += bv; t.y += bv; t.z += bv; t.w += bv;
+                sum += (t.x + t.y) + (t.z + t.w);
+            }
+            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int i = k * T + tid;
+            v[k] = i < HW ? xp[i] + bv : 0.0f;
+            if (i < HW) sum += v[k];
+        }
+    }
+    const float inv_n = 1.0f / (float)HW;
+    const float mean = block_sum<T>(sum, red) * inv_n;
+    float ss = 0.0f;
+    if (VEC) {
+        const int n4 = HW >> 2;
+#pragma unroll
+        for (int k = 0; k < NE / 4; ++k)
+            if (k * T + tid < n4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[4 * k + e] - mean; ss = __builtin_fmaf(d, d, ss); }
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (k * T + tid < HW) { const float d = v[k] - mean; ss = __builtin_fmaf(d, d, ss); }
+    }
+    const float var = block_sum<T>(ss, red) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float g = (gamma ? gamma[c] : 1.0f) * rstd, bt = beta ? beta[c] : 0.0f;
+    if (VEC) {
+        const int n4 = HW >> 2;
+#pragma unroll
+        for (int k = 0; k < NE / 4; ++k) {
+            const int i = k * T + tid;
+            if (i < n4) {
+                float4 o;
+                o.x = act_fwd((v[4 * k] - mean) * g + bt, act, slope);
+                o.y = act_fwd((v[4 * k + 1] - mean) * g + bt, act, slope);
+                o.z = act_fwd((v[4 * k + 2] - mean) * g + bt, act, slope);
+                o.w = act_fwd((v[4 * k + 3] - mean) * g + bt, act, slope);
+                reinterpret_cast<float4*>(yp)[i] = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int i = k * T + tid;
+            if (i < HW) yp[i] = act_fwd((v[k] - mean) * g + bt, act, slope);
+        }
+    }
+    if (tid == 0) { mean_out[plane] = mean; rstd_out[plane] = rstd; }
+}
+
+template <int T, int NE, bool VEC>
+__global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ x, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in, int act, float slope, int C, int HW,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma_p,
+                                                             float* __restrict__ dbeta_p, float* __restrict__ dbias_p)
+{
+    __shared__ float red[4];
+    const int plane = blockIdx.x, c = plane % C, tid = threadIdx.x;
+    const float bv = bias ? bias[c] : 0.0f;
+    const float mean = mean_in[plane], rstd = rstd_in[plane];
+    const size_t off = (size_t)plane * HW;
+    float dz[NE], xh[NE];
+    float s1 = 0.0f, s2 = 0.0f;
+    if (VEC) {
+        const int n4 = HW >> 2;
+#pragma unroll
+        for (int k = 0; k < NE / 4; ++k) {
+            const int i = k * T + tid;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), h = a;
+            if (i < n4) {
+                const float4 d = reinterpret_cast<const float4*>(dy + off)[i];
+                const float4 o = reinterpret_cast<const float4*>(y + off)[i];
+                const float4 xv = reinterpret_cast<const float4*>(x + off)[i];
+                a.x = d.x * act_bwd(o.x, act, slope); a.y = d.y * act_bwd(o.y, act, slope);
+                a.z = d.z * act_bwd(o.z, act, slope); a.w = d.w * act_bwd(o.w, act, slope);
+                h.x = ((xv.x + bv) - mean) * rstd; h.y = ((xv.y + bv) - mean) * rstd;
+                h.z = ((xv.z + bv) - mean) * rstd; h.w = ((xv.w + bv) - mean) * rstd;
+                s1 += (a.x + a.y) + (a.z + a.w);
+                s2 = __builtin_fmaf(a.x, h.x, s2); s2 = __builtin_fmaf(a.y, h.y, s2);
+                s2 = __builtin_fmaf(a.z, h.z, s2); s2 = __builtin_fmaf(a.w, h.w, s2);
+            }
+            dz[4 * k] = a.x; dz[4 * k + 1] = a.y; dz[4 * k + 2] = a.z; dz[4 * k + 3] = a.w;
+            xh[4 * k] = h.x; xh[4 * k + 1] = h.y; xh[4 * k + 2] = h.z; xh[4 * k + 3] = h.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int i = k * T + tid;
+            dz[k] = 0.0f; xh[k] = 0.0f;
+            if (i < HW) {
+                dz[k] = dy[off + i] * act_bwd(y[off + i], act, slope);
+                xh[k] = ((x[off + i] + bv) - mean) * rstd;
+                s1 += dz[k];
+                s2 = __builtin_fmaf(dz[k], xh[k], s2);
+            }
+        }
+    }
+    s1 = block_sum<T>(s1, red);
+    s2 = block_sum<T>(s2, red);
+    const float inv_n = 1.0f / (float)HW;
+    const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+    const float g = (gamma ? gamma[c] : 1.0f) * rstd;
+    float sdx = 0.0f;
+    if (VEC) {
+        const int n4 = HW >> 2;
+#pragma unroll
+        for (int k = 0; k < NE / 4; ++k) {
+            const int i = k * T + tid;
+            if (i < n4) {
+                float4 o;
+                o.x = g * ((dz[4 * k] - m1) - xh[4 * k] * m2);
+                o.y = g * ((dz[4 * k + 1] - m1) - xh[4 * k + 1] * m2);
+                o.z = g * ((dz[4 * k + 2] - m1) - xh[4 * k + 2] * m2);
+                o.w = g * ((dz[4 * k + 3] - m1) - xh[4 * k + 3] * m2);
+                sdx += (o.x + o.y) + (o.z + o.w);
+                reinterpret_cast<float4*>(dx + off)[i] = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int i = k * T + tid;
+            if (i < HW) {
+                const float o = g * ((dz[k] - m1) - xh[k] * m2);
+                sdx += o;
+                dx[off + i] = o;
+            }
+        }
+    }
+    sdx = block_sum<T>(sdx, red);
+    if (tid == 0) {
+        if (dgamma_p) dgamma_p[plane] = s2;
+        if (dbeta_p) dbeta_p[plane] = s1;
+        if (dbias_p) dbias_p[plane] = sdx;
+    }
+}
+
+// act(x + bias) backward: dx = dy * act'(y), per-plane partial of the bias gradient
+__global__ void __launch_bounds__(256) bias_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float slope,
+                                                           int HW, float* __restrict__ dx, float* __restrict__ dbias_p)
+{
+    __shared__ float red[4];
+    const int plane = blockIdx.x, tid = threadIdx.x;
+    const size_t off = (size_t)plane * HW;
+    float s = 0.0f;
+    if ((HW & 3) == 0) {
+        const int n4 = HW >> 2;
+        for (int i = tid; i < n4; i += 256) {
+            const float4 d = reinterpret_cast<const float4*>(dy + off)[i];
+            const float4 o = reinterpret_cast<const float4*>(y + off)[i];
+            float4 r;
+            r.x = d.x * act_bwd(o.x, act, slope); r.y = d.y * act_bwd(o.y, act, slope);
+            r.z = d.z * act_bwd(o.z, act, slope); r.w = d.w * act_bwd(o.w, act, slope);
+            s += (r.x + r.y) + (r.z + r.w);
+            reinterpret_cast<float4*>(dx + off)[i] = r;
+        }
+    } else {
+        for (int i = tid; i < HW; i += 256) {
+            const float r = dy[off + i] * act_bwd(y[off + i], act, slope);
+            s += r;
+            dx[off + i] = r;
+        }
+    }
+    s = block_sum<256>(s, red);
+    if (tid == 0 && dbias_p) dbias_p[plane] = s;
+}
+
+constexpr int IN_MAX_HW = 16384;
+
+// Launch shape: wave-sized workgroups for small planes, 256 threads above; a thread holds at most 64 elements.
+#define IN_DISPATCH(KERNEL, ...)                                                                                        \
+    do {                                                                                                                \
+        const bool vec = (HW & 3) == 0;                                                                                 \
+        if (HW <= 256) { if (vec) KERNEL<64, 4, true><<<planes, 64, 0, st>>>(__VA_ARGS__); else KERNEL<64, 4, false><<<planes, 64, 0, st>>>(__VA_ARGS__); }          \
+        else if (HW <= 1024) { if (vec) KERNEL<64, 16, true><<<planes, 64, 0, st>>>(__VA_ARGS__); else KERNEL<64, 16, false><<<planes, 64, 0, st>>>(__VA_ARGS__); }  \
+        else if (HW <= 4096) { if (vec) KERNEL<256, 16, true><<<planes, 256, 0, st>>>(__VA_ARGS__); else KERNEL<256, 16, false><<<planes, 256, 0, st>>>(__VA_ARGS__); } \
+        else { if (vec) KERNEL<256, 64, true><<<planes, 256, 0, st>>>(__VA_ARGS__); else KERNEL<256, 64, false><<<planes, 256, 0, st>>>(__VA_ARGS__); }              \
+    } while (0)
+
+int launch_instnorm_act_fwd(const float* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
+                            int B, int C, int HW, float* y, float* mean, float* rstd, hipStream_t st)
+{
+    if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: plane of %d elements > %d", HW, IN_MAX_HW);
+    const int planes = B * C;
+    IN_DISPATCH(instnorm_act_fwd_kernel, x, bias, gamma, beta, eps, act, slope, C, HW, y, mean, rstd);
+    return check_launch("instnorm_act_fwd_kernel");
+}
+
+int launch_instnorm_act_bwd(const float* dy, const float* y, const float* x, const float* bias, const float* gamma, const float* mean,
+                            const float* rstd, int act, float slope, int B, int C, int HW, float* dx, float* dgamma_p, float* dbeta_p,
+                            float* dbias_p, hipStream_t st)
+{
+    if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: plane of %d elements > %d", HW, IN_MAX_HW);
+    const int planes = B * C;
+    IN_DISPATCH(instnorm_act_bwd_kernel, dy, y, x, bias, gamma, mean, rstd, act, slope, C, HW, dx, dgamma_p, dbeta_p, dbias_p);
+    return check_launch("instnorm_act_bwd_kernel");
+}
+
+int launch_bias_act_bwd(const float* dy, const float* y, int act, float slope, int B, int C, int HW, float* dx, float* dbias_p, hipStream_t st)
+{
+    bias_act_bwd_kernel<<<B * C, 256, 0, st>>>(dy, y, act, slope, HW, dx, dbias_p);
+    return check_launch("bias_act_bwd_kernel");
+}
+
+}  // namespace ipsr

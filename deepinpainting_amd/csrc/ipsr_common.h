@@ -134,6 +134,14 @@ int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn
 int launch_bias_act(float* x, const float* bias, int B, int C, int HW, int act, float slope, hipStream_t st);
 int launch_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H, int W, float* y, hipStream_t st);
 
+// instnorm.hip — conv-bias + InstanceNorm2d + activation, fused forward / backward (one (sample, channel) plane per workgroup)
+int launch_instnorm_act_fwd(const float* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
+                            int B, int C, int HW, float* y, float* mean, float* rstd, hipStream_t st);
+int launch_instnorm_act_bwd(const float* dy, const float* y, const float* x, const float* bias, const float* gamma, const float* mean,
+                            const float* rstd, int act, float slope, int B, int C, int HW, float* dx, float* dgamma_p, float* dbeta_p,
+                            float* dbias_p, hipStream_t st);
+int launch_bias_act_bwd(const float* dy, const float* y, int act, float slope, int B, int C, int HW, float* dx, float* dbias_p, hipStream_t st);
+
 size_t innercos_ws_bytes(int B, int Cuse, int N);
 int launch_innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,
                          float strength, float* loss, void* ws, size_t ws_bytes, hipStream_t st);

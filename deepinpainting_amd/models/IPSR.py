@@ -41,6 +41,8 @@ class IPSR(BaseModel):
         # BASELINE config 5: convolutions under bf16 autocast (CDNA4 bf16 MFMA); the IPSR layer, the InnerCos taps and all
         # losses stay fp32.  Off by default — the reference is fp32.
         self.amp_bf16 = bool(getattr(opt, 'amp_bf16', False))
+        # conv-bias + InstanceNorm + activation in one HIP kernel each way (models/fused.py); False = plain torch modules
+        networks.FusedSequential.enabled = bool(getattr(opt, 'fused_norm_act', True))
 
         self.vgg = Vgg16(requires_grad=False, weights_path=getattr(opt, 'vgg16_weights', None)).to(self.device)
         self.vgg.eval()

@@ -1,0 +1,159 @@
+"""Fused conv-bias + InstanceNorm2d + activation for the U-Nets and discriminators (HIP kernels of csrc/instnorm.hip).
+
+The reference builds every level as  Conv2d/ConvTranspose2d(bias) -> InstanceNorm2d -> LeakyReLU(0.2, True) / ReLU(True)
+(models/networks.py:220-259, 404-432, 470-497, 507-514), the activation often being the FIRST module of the next
+(child) level, applied in place.  On MIOpen that chain is a bias add, a 2-3 pass norm and an activation pass (and as
+many again backward, plus a bias-gradient reduction).  `FusedSequential` keeps the module tree — children, names and
+therefore state_dict keys are exactly those of nn.Sequential — and only changes HOW a run of such modules is executed:
+
+    conv (called without bias) -> ONE kernel: bias + instance norm + affine + activation      (_InstNormAct)
+    conv (called without bias) -> ONE kernel: bias + activation, in place                     (_BiasAct)
+
+The in-place activation at the head of a child level is absorbed into the parent's kernel (the child is then told to skip
+it), which is value-identical: the reference's in-place LeakyReLU rewrites the very tensor the parent's norm produced,
+so nobody ever sees the un-activated values (that is also why the skip connection carries the activated tensor).
+
+CPU tensors, non-fp32 dtypes, autocast regions, planes above 128x128 and `FusedSequential.enabled = False` take the plain
+module-by-module path.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class _InstNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, gamma, beta, eps, act, slope):
+        y, mean, rstd = ops.instnorm_act_forward(x, bias, gamma, beta, eps, act, slope)
+        ctx.save_for_backward(x, bias, gamma, y, mean, rstd)
+        ctx.act, ctx.slope = act, slope
+        ctx.has_affine = gamma is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bias, gamma, y, mean, rstd = ctx.saved_tensors
+        need_bias = bias is not None and ctx.needs_input_grad[1]
+        need_affine = ctx.has_affine and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        dx, dg, db, dbias = ops.instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, ctx.act, ctx.slope, need_affine, need_bias)
+        return dx, dbias, dg, db, None, None, None
+
+
+class _BiasAct(torch.autograd.Function):
+    """act(x + bias[c]) in place on x (a fresh convolution output nobody else holds)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, act, slope):
+        ops.bias_act_(x, bias, act, slope)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        ctx.act, ctx.slope = act, slope
+        ctx.has_bias = bias is not None
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx, dbias = ops.bias_act_backward(dy, y, ctx.act, ctx.slope, ctx.has_bias and ctx.needs_input_grad[1])
+        return dx, dbias, None, None
+
+
+def _act_of(m):
+    """(name, slope) when m is an activation the kernels implement."""
+    if isinstance(m, nn.LeakyReLU):
+        return "leaky", float(m.negative_slope)
+    if isinstance(m, nn.ReLU):
+        return "relu", 0.0
+    return None
+
+
+def _conv_no_bias(m, x):
+    if isinstance(m, nn.ConvTranspose2d):
+        return F.conv_transpose2d(x, m.weight, None, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
+    return F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+
+
+def _plain_conv(m):
+    return type(m) in (nn.Conv2d, nn.ConvTranspose2d) and m.bias is not None and getattr(m, "padding_mode", "zeros") == "zeros"
+
+
+def _plain_inorm(m):
+    return isinstance(m, nn.InstanceNorm2d) and not m.track_running_stats
+
+
+class FusedSequential(nn.Sequential):
+    enabled = True          # class-wide switch (Option.fused_norm_act); False = behave exactly like nn.Sequential
+
+    def _get_name(self):    # prints like the reference's module tree (train.ipynb cell 1 output)
+        return 'Sequential'
+
+    def _head_act_of_child(self, m):
+        """A skip level whose first module is an in-place activation can have it absorbed by the producer."""
+        inner = getattr(m, "model", None)
+        if isinstance(inner, FusedSequential) and len(inner) > 0 and getattr(inner[0], "inplace", False):
+            return _act_of(inner[0])
+        return None
+
+    def forward(self, x, head_act_done=False):
+        usable = (FusedSequential.enabled and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled('cuda'))
+        mods = list(self)
+        n = len(mods)
+        i = 0
+        if head_act_done:                       # the producer already applied this level's leading in-place activation
+            assert n > 0 and _act_of(mods[0]) is not None
+            i = 1
+        if not usable:
+            for m in mods[i:]:
+                x = m(x)
+            return x
+        while i < n:
+            m = mods[i]
+            conv = _plain_conv(m)
+            norm = mods[i + 1] if (conv and i + 1 < n and _plain_inorm(mods[i + 1])) else (m if _plain_inorm(m) else None)
+            if conv and norm is None:
+                # conv -> activation (same level, or the child's leading in-place one)
+                nxt = mods[i + 1] if i + 1 < n else None
+                act = _act_of(nxt) if nxt is not None else None
+                child_act = self._head_act_of_child(nxt) if (nxt is not None and act is None) else None
+                if act is None and child_act is None:
+                    x = m(x)
+                    i += 1
+                    continue
+                y = _conv_no_bias(m, x)
+                if act is not None:
+                    x = _BiasAct.apply(y, m.bias, act[0], act[1])
+                    i += 2
+                else:
+                    x = nxt(_BiasAct.apply(y, m.bias, child_act[0], child_act[1]), head_act_done=True)
+                    i += 2
+                continue
+            if norm is not None:
+                if conv:
+                    y, bias, j = _conv_no_bias(m, x), m.bias, i + 2
+                else:
+                    y, bias, j = x, None, i + 1
+                hw = y.size(2) * y.size(3)
+                if hw > ops.INSTNORM_MAX_PLANE or hw < 2 or not y.is_contiguous():
+                    if conv:                       # too large for the plane-in-registers kernel: plain modules
+                        y = y + m.bias.view(1, -1, 1, 1)
+                    x = norm(y)
+                    i = j
+                    continue
+                nxt = mods[j] if j < n else None
+                act = _act_of(nxt) if nxt is not None else None
+                child_act = self._head_act_of_child(nxt) if (nxt is not None and act is None) else None
+                a = act or child_act or ("none", 0.0)
+                x = _InstNormAct.apply(y, bias, norm.weight, norm.bias, norm.eps, a[0], a[1])
+                if act is not None:
+                    i = j + 1
+                elif child_act is not None:
+                    x = nxt(x, head_act_done=True)
+                    i = j + 1
+                else:
+                    i = j
+                continue
+            x = m(x)
+            i += 1
+        return x

@@ -24,6 +24,7 @@ from torch.optim import lr_scheduler
 from .IPSR_model import IPSR_model
 from .InnerCos import InnerCos
 from .InnerCos2 import InnerCos2
+from .fused import FusedSequential
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -163,11 +164,12 @@ class GANLoss(nn.Module):
 # ----------------------------------------------------------------------------------------------------
 # U-Net building blocks
 # ----------------------------------------------------------------------------------------------------
-def _cat_skip(block, x):
-    """Shared forward of every skip block (:270-278, :358-366, :443-452)."""
+def _cat_skip(block, x, head_act_done=False):
+    """Shared forward of every skip block (:270-278, :358-366, :443-452).  `head_act_done`: the producer of x has already
+    applied this level's leading in-place activation (fused into its kernel, see models/fused.py)."""
     if block.outermost:
-        return block.model(x)
-    y = block.model(x)
+        return block.model(x, head_act_done=head_act_done)
+    y = block.model(x, head_act_done=head_act_done)
     h, w = x.size(2), x.size(3)
     if h != y.size(2) or w != y.size(3):
         y = F.interpolate(y, (h, w), mode='bilinear')
@@ -222,10 +224,10 @@ class UnetSkipConnectionBlock_3(nn.Module):
         if input_nc is None:
             input_nc = outer_nc
         L = _block3_layers(outer_nc, inner_nc, input_nc, norm_layer)
-        self.model = nn.Sequential(*_assemble3(L, outer_nc, inner_nc, submodule, outermost, innermost, use_dropout))
+        self.model = FusedSequential(*_assemble3(L, outer_nc, inner_nc, submodule, outermost, innermost, use_dropout))
 
-    def forward(self, x):
-        return _cat_skip(self, x)
+    def forward(self, x, head_act_done=False):
+        return _cat_skip(self, x, head_act_done)
 
 
 class IPSR(nn.Module):
@@ -251,11 +253,11 @@ class IPSR(nn.Module):
         innerCos2.set_mask(mask_global, opt, feat_mask=feat)
         cosis_list2.append(innerCos2)
 
-        self.model = nn.Sequential(*_assemble3(L, outer_nc, inner_nc, submodule, outermost, innermost, use_dropout,
+        self.model = FusedSequential(*_assemble3(L, outer_nc, inner_nc, submodule, outermost, innermost, use_dropout,
                                                mid_down=(ipsr, innerCos), head_up=(innerCos2,)))
 
-    def forward(self, x):
-        return _cat_skip(self, x)
+    def forward(self, x, head_act_done=False):
+        return _cat_skip(self, x, head_act_done)
 
 
 class UnetGeneratorIPSR(nn.Module):
@@ -305,10 +307,10 @@ class UnetSkipConnectionBlock(nn.Module):
             model = [downrelu, downconv, downnorm, submodule, uprelu, upconv, upnorm]
             if use_dropout:
                 model.append(nn.Dropout(0.5))
-        self.model = nn.Sequential(*model)
+        self.model = FusedSequential(*model)
 
-    def forward(self, x):
-        return _cat_skip(self, x)
+    def forward(self, x, head_act_done=False):
+        return _cat_skip(self, x, head_act_done)
 
 
 class UnetGenerator(nn.Module):
@@ -350,7 +352,7 @@ class NLayerDiscriminator(nn.Module):
         seq += [nn.Conv2d(ndf * mult, 1, kernel_size=kw, stride=1, padding=padw)]
         if use_sigmoid:
             seq += [nn.Sigmoid()]
-        self.model = nn.Sequential(*seq)
+        self.model = FusedSequential(*seq)
 
     def forward(self, input):
         return self.model(input)
@@ -361,7 +363,7 @@ class PFDiscriminator(nn.Module):
 
     def __init__(self):
         super(PFDiscriminator, self).__init__()
-        self.model = nn.Sequential(
+        self.model = FusedSequential(
             nn.Conv2d(256, 512, kernel_size=4, stride=2, padding=1),
             nn.LeakyReLU(0.2, True),
             nn.Conv2d(512, 512, kernel_size=4, stride=2, padding=1),

@@ -163,6 +163,54 @@ def bias_act_(x, bias, act="relu", slope=0.2):
     return x
 
 
+ACT_CODE = {"none": 0, "relu": 1, "leaky": 2}
+INSTNORM_MAX_PLANE = 16384
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def instnorm_act_forward(x, bias, gamma, beta, eps, act, slope):
+    """y = act(InstanceNorm(x + bias[c]) * gamma[c] + beta[c]) -> (y, mean [B*C], rstd [B*C]); x contiguous fp32 [B,C,H,W]."""
+    x = _req(x, torch.float32, "x")
+    B, C = x.shape[0], x.shape[1]
+    hw = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ipsr_instnorm_act_forward(x.data_ptr(), _ptr(bias), _ptr(gamma), _ptr(beta), float(eps), ACT_CODE[act],
+                                                    float(slope), B, C, hw, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream()),
+               "ipsr_instnorm_act_forward")
+    return y, mean, rstd
+
+
+def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_affine, need_bias):
+    """-> (dx, dgamma [C] | None, dbeta [C] | None, dbias [C] | None)."""
+    dy = _req(dy, torch.float32, "grad_output")
+    B, C = x.shape[0], x.shape[1]
+    hw = x.numel() // (B * C)
+    dx = torch.empty_like(x)
+    part = torch.empty((3, B, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), _ptr(bias), _ptr(gamma), mean.data_ptr(),
+                                                     rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, dx.data_ptr(),
+                                                     part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(), _stream()),
+               "ipsr_instnorm_act_backward")
+    s = part.sum(1)                                     # batch reduction of the per-plane partials: one tiny kernel
+    return dx, (s[0] if need_affine else None), (s[1] if need_affine else None), (s[2] if need_bias else None)
+
+
+def bias_act_backward(dy, y, act, slope, need_bias):
+    dy = _req(dy, torch.float32, "grad_output")
+    B, C = y.shape[0], y.shape[1]
+    hw = y.numel() // (B * C)
+    dx = torch.empty_like(y)
+    part = torch.empty((B, C), dtype=torch.float32, device=y.device) if need_bias else None
+    _lib.check(_lib.lib().ipsr_bias_act_backward(dy.data_ptr(), y.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, dx.data_ptr(),
+                                                 _ptr(part), _stream()), "ipsr_bias_act_backward")
+    return dx, (part.sum(0) if need_bias else None)
+
+
 def bias_relu_pool2(x, bias):
     """max_pool2d(relu(x + bias[c]), 2, 2) of a contiguous fp32 [B,C,H,W] tensor in one pass."""
     x = _req(x, torch.float32, "x")

@@ -136,6 +136,23 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
 int ipsr_bias_act(float* x, const float* bias, int B, int C, int HW, int act, float slope, void* stream);
 int ipsr_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H, int W, float* y, void* stream);
 
+/* ---- conv-bias + InstanceNorm2d + activation ------------------------------------------------------
+ * replaces the chain  Conv2d/ConvTranspose2d bias add -> nn.InstanceNorm2d(affine) -> LeakyReLU(0.2)/ReLU  that follows
+ * every convolution of the U-Nets and discriminators (models/networks.py:220-259, 404-432, 470-497, 507-514) and its
+ * autograd backward: one pass forward (1 read + 1 write), one pass backward (3 reads + 1 write), one (sample, channel)
+ * plane of HW <= 16384 elements per workgroup.  act: 0 none, 1 ReLU, 2 LeakyReLU(slope); bias/gamma/beta may be NULL.
+ *   forward : z = x + bias[c]; y = act((z - mean) * rstd * gamma[c] + beta[c]); mean/rstd [B*C] are kept for backward
+ *   backward: dx [B,C,HW]; per-plane partials dgamma_p/dbeta_p/dbias_p [B*C] (any may be NULL) — the caller sums them
+ *             over the batch.  `y` is the forward OUTPUT (the activation's derivative is taken from its sign).
+ *   ipsr_bias_act_backward: backward of ipsr_bias_act: dx = dy * act'(y), dbias_p[b*C+c] = sum of dx over the plane. */
+int ipsr_instnorm_act_forward(const float* x, const float* bias, const float* gamma, const float* beta, float eps,
+                              int act, float slope, int B, int C, int HW, float* y, float* mean, float* rstd, void* stream);
+int ipsr_instnorm_act_backward(const float* dy, const float* y, const float* x, const float* bias, const float* gamma,
+                               const float* mean, const float* rstd, int act, float slope, int B, int C, int HW,
+                               float* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream);
+int ipsr_bias_act_backward(const float* dy, const float* y, int act, float slope, int B, int C, int HW,
+                           float* dx, float* dbias_p, void* stream);
+
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
  * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.
