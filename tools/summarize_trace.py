@@ -16,7 +16,7 @@ import sys
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
-    ap.add_argument("--marker", default="corr_argmax_kernel")
+    ap.add_argument("--marker", default="corr_argmax_fast_kernel")
     ap.add_argument("--skip", type=int, default=3, help="marker launches to skip (warm-up steps)")
     ap.add_argument("--steps", type=int, default=0, help="marker launches to include (0 = all remaining training steps)")
     ap.add_argument("--top", type=int, default=40)
