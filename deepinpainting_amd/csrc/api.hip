@@ -104,7 +104,7 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 2; }
+int ipsr_abi_version(void) { return 3; }
 
 const char* ipsr_last_error(void) { return g_err; }
 
@@ -288,52 +288,53 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
     return launch_fold(tu, B, C, h, w, patch, grad_in, st, grad_out);
 }
 
-int ipsr_bias_act(float* x, const float* bias, int B, int C, int HW, int act, float slope, void* stream)
+static inline bool aligned_io(const void* p, int io_bf16) { return (reinterpret_cast<uintptr_t>(p) & (io_bf16 ? 7u : 15u)) == 0; }
+
+int ipsr_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* stream)
 {
     if (!x) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: null pointer");
     if (B < 1 || C < 1 || HW < 1) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: bad size B=%d C=%d HW=%d", B, C, HW);
-    if ((HW & 3) == 0 && !aligned16(x)) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: x must be 16-byte aligned");
-    return launch_bias_act(x, bias, B, C, HW, act, slope, static_cast<hipStream_t>(stream));
+    if ((HW & 3) == 0 && !aligned_io(x, io_bf16)) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: x is not vector aligned");
+    return launch_bias_act(x, bias, B, C, HW, act, slope, io_bf16, static_cast<hipStream_t>(stream));
 }
 
-int ipsr_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H, int W, float* y, void* stream)
+int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, void* stream)
 {
     if (!x || !y) return fail(IPSR_ERR_INVALID, "ipsr_bias_relu_pool2: null pointer");
     if (B < 1 || C < 1 || H < 2 || W < 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_relu_pool2: bad size B=%d C=%d H=%d W=%d", B, C, H, W);
-    if ((W & 3) == 0 && (!aligned16(x) || (reinterpret_cast<uintptr_t>(y) & 7u)))
-        return fail(IPSR_ERR_INVALID, "ipsr_bias_relu_pool2: x must be 16-byte and y 8-byte aligned");
-    return launch_bias_relu_pool2(x, bias, B, C, H, W, y, static_cast<hipStream_t>(stream));
+    if ((W & 3) == 0 && !aligned_io(x, io_bf16)) return fail(IPSR_ERR_INVALID, "ipsr_bias_relu_pool2: x is not vector aligned");
+    return launch_bias_relu_pool2(x, bias, B, C, H, W, io_bf16, y, static_cast<hipStream_t>(stream));
 }
 
-int ipsr_instnorm_act_forward(const float* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
-                              int B, int C, int HW, float* y, float* mean, float* rstd, void* stream)
+int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
+                              int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, void* stream)
 {
     if (!x || !y || !mean || !rstd) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: null pointer");
     if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: bad argument B=%d C=%d HW=%d act=%d", B, C, HW, act);
-    if ((HW & 3) == 0 && (!aligned16(x) || !aligned16(y))) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: x/y must be 16-byte aligned");
-    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, y, mean, rstd, static_cast<hipStream_t>(stream));
+    if ((HW & 3) == 0 && (!aligned_io(x, io_bf16) || !aligned_io(y, io_bf16))) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: x/y are not vector aligned");
+    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, io_bf16, y, mean, rstd, static_cast<hipStream_t>(stream));
 }
 
-int ipsr_instnorm_act_backward(const float* dy, const float* y, const float* x, const float* bias, const float* gamma,
-                               const float* mean, const float* rstd, int act, float slope, int B, int C, int HW,
-                               float* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream)
+int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, const float* bias, const float* gamma,
+                               const float* mean, const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16,
+                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream)
 {
     if (!dy || !y || !x || !mean || !rstd || !dx) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: null pointer");
     if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: bad argument");
-    if ((HW & 3) == 0 && (!aligned16(dy) || !aligned16(y) || !aligned16(x) || !aligned16(dx)))
-        return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: tensors must be 16-byte aligned");
-    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, dx, dgamma_p, dbeta_p, dbias_p,
+    if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(x, io_bf16) || !aligned_io(dx, io_bf16)))
+        return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: tensors are not vector aligned");
+    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p,
                                    static_cast<hipStream_t>(stream));
 }
 
-int ipsr_bias_act_backward(const float* dy, const float* y, int act, float slope, int B, int C, int HW, float* dx, float* dbias_p,
-                           void* stream)
+int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx,
+                           float* dbias_p, void* stream)
 {
     if (!dy || !y || !dx) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: null pointer");
     if (B < 1 || C < 1 || HW < 1 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: bad argument");
-    if ((HW & 3) == 0 && (!aligned16(dy) || !aligned16(y) || !aligned16(dx)))
-        return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: tensors must be 16-byte aligned");
-    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, dx, dbias_p, static_cast<hipStream_t>(stream));
+    if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(dx, io_bf16)))
+        return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: tensors are not vector aligned");
+    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, static_cast<hipStream_t>(stream));
 }
 
 size_t innercos_workspace_bytes(int B, int Cuse, int N) { return innercos_ws_bytes(B, Cuse, N); }

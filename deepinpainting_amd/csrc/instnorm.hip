@@ -46,17 +46,17 @@ __device__ __forceinline__ float act_bwd(float y, int act, float slope)
 }
 
 // NE = plane elements a thread may hold; VEC: 16-byte accesses (HW % 4 == 0)
-template <int T, int NE, bool VEC>
-__global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+template <typename IO, int T, int NE, bool VEC>
+__global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const IO* __restrict__ x, const float* __restrict__ bias,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, int act, float slope, int C, int HW,
-                                                             float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out)
+                                                             IO* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out)
 {
     __shared__ float red[4];
     const int plane = blockIdx.x, c = plane % C, tid = threadIdx.x;
     const float bv = bias ? bias[c] : 0.0f;
-    const float* xp = x + (size_t)plane * HW;
-    float* yp = y + (size_t)plane * HW;
+    const IO* xp = x + (size_t)plane * HW;
+    IO* yp = y + (size_t)plane * HW;
     float v[NE];
     float sum = 0.0f;
     if (VEC) {
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const float* __rest
             const int i = k * T + tid;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < n4) {
-                t = reinterpret_cast<const float4*>(xp)[i];
+                t = ld4(xp, i);
                 t.x += bv; t.y += bv; t.z += bv; t.w += bv;
                 sum += (t.x + t.y) + (t.z + t.w);
             }
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const int i = k * T + tid;
-            v[k] = i < HW ? xp[i] + bv : 0.0f;
+            v[k] = i < HW ? ld1(xp, i) + bv : 0.0f;
             if (i < HW) sum += v[k];
         }
     }
@@ -110,25 +110,25 @@ __global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const float* __rest
                 o.y = act_fwd((v[4 * k + 1] - mean) * g + bt, act, slope);
                 o.z = act_fwd((v[4 * k + 2] - mean) * g + bt, act, slope);
                 o.w = act_fwd((v[4 * k + 3] - mean) * g + bt, act, slope);
-                reinterpret_cast<float4*>(yp)[i] = o;
+                st4(yp, i, o);
             }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const int i = k * T + tid;
-            if (i < HW) yp[i] = act_fwd((v[k] - mean) * g + bt, act, slope);
+            if (i < HW) st1(yp, i, act_fwd((v[k] - mean) * g + bt, act, slope));
         }
     }
     if (tid == 0) { mean_out[plane] = mean; rstd_out[plane] = rstd; }
 }
 
-template <int T, int NE, bool VEC>
-__global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             const float* __restrict__ x, const float* __restrict__ bias,
+template <typename IO, int T, int NE, bool VEC>
+__global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restrict__ dy, const IO* __restrict__ y,
+                                                             const IO* __restrict__ x, const float* __restrict__ bias,
                                                              const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                              const float* __restrict__ rstd_in, int act, float slope, int C, int HW,
-                                                             float* __restrict__ dx, float* __restrict__ dgamma_p,
+                                                             IO* __restrict__ dx, float* __restrict__ dgamma_p,
                                                              float* __restrict__ dbeta_p, float* __restrict__ dbias_p)
 {
     __shared__ float red[4];
@@ -145,9 +145,9 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const float* __rest
             const int i = k * T + tid;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), h = a;
             if (i < n4) {
-                const float4 d = reinterpret_cast<const float4*>(dy + off)[i];
-                const float4 o = reinterpret_cast<const float4*>(y + off)[i];
-                const float4 xv = reinterpret_cast<const float4*>(x + off)[i];
+                const float4 d = ld4(dy + off, i);
+                const float4 o = ld4(y + off, i);
+                const float4 xv = ld4(x + off, i);
                 a.x = d.x * act_bwd(o.x, act, slope); a.y = d.y * act_bwd(o.y, act, slope);
                 a.z = d.z * act_bwd(o.z, act, slope); a.w = d.w * act_bwd(o.w, act, slope);
                 h.x = ((xv.x + bv) - mean) * rstd; h.y = ((xv.y + bv) - mean) * rstd;
@@ -165,8 +165,8 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const float* __rest
             const int i = k * T + tid;
             dz[k] = 0.0f; xh[k] = 0.0f;
             if (i < HW) {
-                dz[k] = dy[off + i] * act_bwd(y[off + i], act, slope);
-                xh[k] = ((x[off + i] + bv) - mean) * rstd;
+                dz[k] = ld1(dy, off + i) * act_bwd(ld1(y, off + i), act, slope);
+                xh[k] = ((ld1(x, off + i) + bv) - mean) * rstd;
                 s1 += dz[k];
                 s2 = __builtin_fmaf(dz[k], xh[k], s2);
             }
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const float* __rest
                 o.z = g * ((dz[4 * k + 2] - m1) - xh[4 * k + 2] * m2);
                 o.w = g * ((dz[4 * k + 3] - m1) - xh[4 * k + 3] * m2);
                 sdx += (o.x + o.y) + (o.z + o.w);
-                reinterpret_cast<float4*>(dx + off)[i] = o;
+                st4(dx + off, i, o);
             }
         }
     } else {
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const float* __rest
             if (i < HW) {
                 const float o = g * ((dz[k] - m1) - xh[k] * m2);
                 sdx += o;
-                dx[off + i] = o;
+                st1(dx, off + i, o);
             }
         }
     }
@@ -213,8 +213,9 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const float* __rest
 }
 
 // act(x + bias) backward: dx = dy * act'(y), per-plane partial of the bias gradient
-__global__ void __launch_bounds__(256) bias_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float slope,
-                                                           int HW, float* __restrict__ dx, float* __restrict__ dbias_p)
+template <typename IO>
+__global__ void __launch_bounds__(256) bias_act_bwd_kernel(const IO* __restrict__ dy, const IO* __restrict__ y, int act, float slope,
+                                                           int HW, IO* __restrict__ dx, float* __restrict__ dbias_p)
 {
     __shared__ float red[4];
     const int plane = blockIdx.x, tid = threadIdx.x;
@@ -223,19 +224,19 @@ __global__ void __launch_bounds__(256) bias_act_bwd_kernel(const float* __restri
     if ((HW & 3) == 0) {
         const int n4 = HW >> 2;
         for (int i = tid; i < n4; i += 256) {
-            const float4 d = reinterpret_cast<const float4*>(dy + off)[i];
-            const float4 o = reinterpret_cast<const float4*>(y + off)[i];
+            const float4 d = ld4(dy + off, i);
+            const float4 o = ld4(y + off, i);
             float4 r;
             r.x = d.x * act_bwd(o.x, act, slope); r.y = d.y * act_bwd(o.y, act, slope);
             r.z = d.z * act_bwd(o.z, act, slope); r.w = d.w * act_bwd(o.w, act, slope);
             s += (r.x + r.y) + (r.z + r.w);
-            reinterpret_cast<float4*>(dx + off)[i] = r;
+            st4(dx + off, i, r);
         }
     } else {
         for (int i = tid; i < HW; i += 256) {
-            const float r = dy[off + i] * act_bwd(y[off + i], act, slope);
+            const float r = ld1(dy, off + i) * act_bwd(ld1(y, off + i), act, slope);
             s += r;
-            dx[off + i] = r;
+            st1(dx, off + i, r);
         }
     }
     s = block_sum<256>(s, red);
@@ -245,37 +246,53 @@ __global__ void __launch_bounds__(256) bias_act_bwd_kernel(const float* __restri
 constexpr int IN_MAX_HW = 16384;
 
 // Launch shape: wave-sized workgroups for small planes, 256 threads above; a thread holds at most 64 elements.
-#define IN_DISPATCH(KERNEL, ...)                                                                                        \
+#define IN_DISPATCH(KERNEL, IO, ...)                                                                                    \
     do {                                                                                                                \
         const bool vec = (HW & 3) == 0;                                                                                 \
-        if (HW <= 256) { if (vec) KERNEL<64, 4, true><<<planes, 64, 0, st>>>(__VA_ARGS__); else KERNEL<64, 4, false><<<planes, 64, 0, st>>>(__VA_ARGS__); }          \
-        else if (HW <= 1024) { if (vec) KERNEL<64, 16, true><<<planes, 64, 0, st>>>(__VA_ARGS__); else KERNEL<64, 16, false><<<planes, 64, 0, st>>>(__VA_ARGS__); }  \
-        else if (HW <= 4096) { if (vec) KERNEL<256, 16, true><<<planes, 256, 0, st>>>(__VA_ARGS__); else KERNEL<256, 16, false><<<planes, 256, 0, st>>>(__VA_ARGS__); } \
-        else { if (vec) KERNEL<256, 64, true><<<planes, 256, 0, st>>>(__VA_ARGS__); else KERNEL<256, 64, false><<<planes, 256, 0, st>>>(__VA_ARGS__); }              \
+        if (HW <= 256) { if (vec) KERNEL<IO, 64, 4, true><<<planes, 64, 0, st>>>(__VA_ARGS__); else KERNEL<IO, 64, 4, false><<<planes, 64, 0, st>>>(__VA_ARGS__); }          \
+        else if (HW <= 1024) { if (vec) KERNEL<IO, 64, 16, true><<<planes, 64, 0, st>>>(__VA_ARGS__); else KERNEL<IO, 64, 16, false><<<planes, 64, 0, st>>>(__VA_ARGS__); }  \
+        else if (HW <= 4096) { if (vec) KERNEL<IO, 256, 16, true><<<planes, 256, 0, st>>>(__VA_ARGS__); else KERNEL<IO, 256, 16, false><<<planes, 256, 0, st>>>(__VA_ARGS__); } \
+        else { if (vec) KERNEL<IO, 256, 64, true><<<planes, 256, 0, st>>>(__VA_ARGS__); else KERNEL<IO, 256, 64, false><<<planes, 256, 0, st>>>(__VA_ARGS__); }              \
     } while (0)
 
-int launch_instnorm_act_fwd(const float* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
-                            int B, int C, int HW, float* y, float* mean, float* rstd, hipStream_t st)
+int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
+                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, hipStream_t st)
 {
     if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: plane of %d elements > %d", HW, IN_MAX_HW);
     const int planes = B * C;
-    IN_DISPATCH(instnorm_act_fwd_kernel, x, bias, gamma, beta, eps, act, slope, C, HW, y, mean, rstd);
+    if (io_bf16)
+        IN_DISPATCH(instnorm_act_fwd_kernel, bf16_t, static_cast<const bf16_t*>(x), bias, gamma, beta, eps, act, slope, C, HW,
+                    static_cast<bf16_t*>(y), mean, rstd);
+    else
+        IN_DISPATCH(instnorm_act_fwd_kernel, float, static_cast<const float*>(x), bias, gamma, beta, eps, act, slope, C, HW,
+                    static_cast<float*>(y), mean, rstd);
     return check_launch("instnorm_act_fwd_kernel");
 }
 
-int launch_instnorm_act_bwd(const float* dy, const float* y, const float* x, const float* bias, const float* gamma, const float* mean,
-                            const float* rstd, int act, float slope, int B, int C, int HW, float* dx, float* dgamma_p, float* dbeta_p,
-                            float* dbias_p, hipStream_t st)
+int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const float* bias, const float* gamma, const float* mean,
+                            const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dgamma_p,
+                            float* dbeta_p, float* dbias_p, hipStream_t st)
 {
     if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: plane of %d elements > %d", HW, IN_MAX_HW);
     const int planes = B * C;
-    IN_DISPATCH(instnorm_act_bwd_kernel, dy, y, x, bias, gamma, mean, rstd, act, slope, C, HW, dx, dgamma_p, dbeta_p, dbias_p);
+    if (io_bf16)
+        IN_DISPATCH(instnorm_act_bwd_kernel, bf16_t, static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y),
+                    static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p);
+    else
+        IN_DISPATCH(instnorm_act_bwd_kernel, float, static_cast<const float*>(dy), static_cast<const float*>(y),
+                    static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p);
     return check_launch("instnorm_act_bwd_kernel");
 }
 
-int launch_bias_act_bwd(const float* dy, const float* y, int act, float slope, int B, int C, int HW, float* dx, float* dbias_p, hipStream_t st)
+int launch_bias_act_bwd(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dbias_p,
+                        hipStream_t st)
 {
-    bias_act_bwd_kernel<<<B * C, 256, 0, st>>>(dy, y, act, slope, HW, dx, dbias_p);
+    if (io_bf16)
+        bias_act_bwd_kernel<bf16_t><<<B * C, 256, 0, st>>>(static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y), act, slope, HW,
+                                                           static_cast<bf16_t*>(dx), dbias_p);
+    else
+        bias_act_bwd_kernel<float><<<B * C, 256, 0, st>>>(static_cast<const float*>(dy), static_cast<const float*>(y), act, slope, HW,
+                                                          static_cast<float*>(dx), dbias_p);
     return check_launch("bias_act_bwd_kernel");
 }
 

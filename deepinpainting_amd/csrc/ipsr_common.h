@@ -73,6 +73,36 @@ __device__ __forceinline__ void merged_argmax(const CorrPartials& cp, int b, int
     }
 }
 
+// I/O element types: fp32, or bf16 (BASELINE config 5: activations under bf16 autocast) with all arithmetic in fp32.
+// A "vector" is 4 elements: 16 bytes of fp32 or 8 bytes of bf16.
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);                   // round to nearest even (inputs are finite)
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float ld1(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ld1(const bf16_t* p, size_t i) { return bf2f(p[i]); }
+__device__ __forceinline__ void st1(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void st1(bf16_t* p, size_t i, float v) { p[i] = f2bf(v); }
+__device__ __forceinline__ float4 ld4(const float* p, size_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+__device__ __forceinline__ float4 ld4(const bf16_t* p, size_t i4)
+{
+    const uint2 r = reinterpret_cast<const uint2*>(p)[i4];
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, size_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
+__device__ __forceinline__ void st4(bf16_t* p, size_t i4, float4 v)
+{
+    uint2 r;
+    r.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    r.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    reinterpret_cast<uint2*>(p)[i4] = r;
+}
+
 // mask_point_idx[l] as the kernels use it: the caller promises values in [0, N) (the host wrappers check what they can
 // without a device sync); a stray value must give a wrong answer, never an out-of-bounds access.
 __device__ __forceinline__ int mpi_at(const int32_t* __restrict__ mpi, int l, int N)
@@ -131,16 +161,17 @@ int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn
                     float triple_w, int B, int C, int N, float* gin, hipStream_t st, int identity = 1);
 
 // pointwise.hip — VGG16 feature net glue (bias / ReLU / 2x2 max-pool in one pass)
-int launch_bias_act(float* x, const float* bias, int B, int C, int HW, int act, float slope, hipStream_t st);
-int launch_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H, int W, float* y, hipStream_t st);
+int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, hipStream_t st);
+int launch_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, hipStream_t st);
 
 // instnorm.hip — conv-bias + InstanceNorm2d + activation, fused forward / backward (one (sample, channel) plane per workgroup)
-int launch_instnorm_act_fwd(const float* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
-                            int B, int C, int HW, float* y, float* mean, float* rstd, hipStream_t st);
-int launch_instnorm_act_bwd(const float* dy, const float* y, const float* x, const float* bias, const float* gamma, const float* mean,
-                            const float* rstd, int act, float slope, int B, int C, int HW, float* dx, float* dgamma_p, float* dbeta_p,
-                            float* dbias_p, hipStream_t st);
-int launch_bias_act_bwd(const float* dy, const float* y, int act, float slope, int B, int C, int HW, float* dx, float* dbias_p, hipStream_t st);
+int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
+                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, hipStream_t st);
+int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const float* bias, const float* gamma, const float* mean,
+                            const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dgamma_p,
+                            float* dbeta_p, float* dbias_p, hipStream_t st);
+int launch_bias_act_bwd(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dbias_p,
+                        hipStream_t st);
 
 size_t innercos_ws_bytes(int B, int Cuse, int N);
 int launch_innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,

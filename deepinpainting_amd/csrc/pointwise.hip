@@ -20,63 +20,61 @@ __device__ __forceinline__ float act_apply(float v, float slope)
     return v;
 }
 
-template <int ACT>
-__global__ void __launch_bounds__(256) bias_act_kernel(float* __restrict__ x, const float* __restrict__ bias, int C, int HW, float slope)
+template <typename IO, int ACT>
+__global__ void __launch_bounds__(256) bias_act_kernel(IO* __restrict__ x, const float* __restrict__ bias, int C, int HW, float slope)
 {
     const int plane = blockIdx.y;                       // b*C + c
     const float bv = bias ? bias[plane % C] : 0.0f;
-    float* p = x + (size_t)plane * HW;
+    IO* p = x + (size_t)plane * HW;
     if ((HW & 3) == 0) {
         const int n4 = HW >> 2;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
-            float4 v = reinterpret_cast<float4*>(p)[i];
+            float4 v = ld4(p, i);
             v.x = act_apply<ACT>(v.x + bv, slope); v.y = act_apply<ACT>(v.y + bv, slope);
             v.z = act_apply<ACT>(v.z + bv, slope); v.w = act_apply<ACT>(v.w + bv, slope);
-            reinterpret_cast<float4*>(p)[i] = v;
+            st4(p, i, v);
         }
     } else {
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) p[i] = act_apply<ACT>(p[i] + bv, slope);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) st1(p, i, act_apply<ACT>(ld1(p, i) + bv, slope));
     }
 }
 
 // one thread -> two horizontally adjacent pooled outputs (reads two float4-aligned row segments when W % 4 == 0)
-__global__ void __launch_bounds__(256) bias_relu_pool2_kernel(const float* __restrict__ x, const float* __restrict__ bias, int C, int H, int W,
-                                                              float* __restrict__ y)
+template <typename IO>
+__global__ void __launch_bounds__(256) bias_relu_pool2_kernel(const IO* __restrict__ x, const float* __restrict__ bias, int C, int H, int W,
+                                                              IO* __restrict__ y)
 {
     const int plane = blockIdx.y;
     const float bv = bias ? bias[plane % C] : 0.0f;
     const int Ho = H >> 1, Wo = W >> 1;
-    const float* p = x + (size_t)plane * H * W;
-    float* q = y + (size_t)plane * Ho * Wo;
+    const IO* p = x + (size_t)plane * H * W;
+    IO* q = y + (size_t)plane * Ho * Wo;
     if ((W & 3) == 0) {
         const int Wp = Wo >> 1;                          // output pairs per row
         const int n = Ho * Wp;
         for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
             const int i = t / Wp, jp = t - i * Wp;
-            const float4 a = *reinterpret_cast<const float4*>(p + (size_t)(2 * i) * W + 4 * jp);
-            const float4 b = *reinterpret_cast<const float4*>(p + (size_t)(2 * i + 1) * W + 4 * jp);
+            const float4 a = ld4(p + (size_t)(2 * i) * W, jp);
+            const float4 b = ld4(p + (size_t)(2 * i + 1) * W, jp);
             // relu(v + bias) per element, then the window max in torch's order (row-major over the window)
             const float a0 = fmaxf(a.x + bv, 0.0f), a1 = fmaxf(a.y + bv, 0.0f), a2 = fmaxf(a.z + bv, 0.0f), a3 = fmaxf(a.w + bv, 0.0f);
             const float b0 = fmaxf(b.x + bv, 0.0f), b1 = fmaxf(b.y + bv, 0.0f), b2 = fmaxf(b.z + bv, 0.0f), b3 = fmaxf(b.w + bv, 0.0f);
-            float2 o;
-            o.x = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
-            o.y = fmaxf(fmaxf(a2, a3), fmaxf(b2, b3));
-            *reinterpret_cast<float2*>(q + (size_t)i * Wo + 2 * jp) = o;
+            st1(q, (size_t)i * Wo + 2 * jp, fmaxf(fmaxf(a0, a1), fmaxf(b0, b1)));
+            st1(q, (size_t)i * Wo + 2 * jp + 1, fmaxf(fmaxf(a2, a3), fmaxf(b2, b3)));
         }
     } else {
         const int n = Ho * Wo;
         for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
             const int i = t / Wo, j = t - i * Wo;
-            const float* r0 = p + (size_t)(2 * i) * W + 2 * j;
-            const float* r1 = r0 + W;
-            const float v0 = fmaxf(r0[0] + bv, 0.0f), v1 = fmaxf(r0[1] + bv, 0.0f);
-            const float v2 = fmaxf(r1[0] + bv, 0.0f), v3 = fmaxf(r1[1] + bv, 0.0f);
-            q[t] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+            const size_t r0 = (size_t)(2 * i) * W + 2 * j, r1 = r0 + W;
+            const float v0 = fmaxf(ld1(p, r0) + bv, 0.0f), v1 = fmaxf(ld1(p, r0 + 1) + bv, 0.0f);
+            const float v2 = fmaxf(ld1(p, r1) + bv, 0.0f), v3 = fmaxf(ld1(p, r1 + 1) + bv, 0.0f);
+            st1(q, t, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
         }
     }
 }
 
-int launch_bias_act(float* x, const float* bias, int B, int C, int HW, int act, float slope, hipStream_t st)
+int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, hipStream_t st)
 {
     const int planes = B * C;
     if (planes > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_bias_act: B*C=%d > 65535 planes", planes);
@@ -84,16 +82,19 @@ int launch_bias_act(float* x, const float* bias, int B, int C, int HW, int act, 
     int gx = cdiv(per, 256 * 4);                        // ~4 vectors per thread
     if (gx < 1) gx = 1;
     const dim3 grid(gx, planes);
-    switch (act) {
-        case 0: bias_act_kernel<0><<<grid, 256, 0, st>>>(x, bias, C, HW, slope); break;
-        case 1: bias_act_kernel<1><<<grid, 256, 0, st>>>(x, bias, C, HW, slope); break;
-        case 2: bias_act_kernel<2><<<grid, 256, 0, st>>>(x, bias, C, HW, slope); break;
-        default: return fail(IPSR_ERR_INVALID, "ipsr_bias_act: unknown activation %d", act);
+    if (act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: unknown activation %d", act);
+#define BA_LAUNCH(IO)                                                                                         \
+    switch (act) {                                                                                            \
+        case 0: bias_act_kernel<IO, 0><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope); break; \
+        case 1: bias_act_kernel<IO, 1><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope); break; \
+        default: bias_act_kernel<IO, 2><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope); break; \
     }
+    if (io_bf16) { BA_LAUNCH(bf16_t) } else { BA_LAUNCH(float) }
+#undef BA_LAUNCH
     return check_launch("bias_act_kernel");
 }
 
-int launch_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H, int W, float* y, hipStream_t st)
+int launch_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, hipStream_t st)
 {
     const int planes = B * C;
     if (planes > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_bias_relu_pool2: B*C=%d > 65535 planes", planes);
@@ -101,7 +102,10 @@ int launch_bias_relu_pool2(const float* x, const float* bias, int B, int C, int 
     const int per = (W & 3) == 0 ? Ho * (Wo >> 1) : Ho * Wo;
     int gx = cdiv(per, 256 * 2);
     if (gx < 1) gx = 1;
-    bias_relu_pool2_kernel<<<dim3(gx, planes), 256, 0, st>>>(x, bias, C, H, W, y);
+    if (io_bf16)
+        bias_relu_pool2_kernel<bf16_t><<<dim3(gx, planes), 256, 0, st>>>(static_cast<const bf16_t*>(x), bias, C, H, W, static_cast<bf16_t*>(y));
+    else
+        bias_relu_pool2_kernel<float><<<dim3(gx, planes), 256, 0, st>>>(static_cast<const float*>(x), bias, C, H, W, static_cast<float*>(y));
     return check_launch("bias_relu_pool2_kernel");
 }
 

@@ -13,8 +13,9 @@ The in-place activation at the head of a child level is absorbed into the parent
 it), which is value-identical: the reference's in-place LeakyReLU rewrites the very tensor the parent's norm produced,
 so nobody ever sees the un-activated values (that is also why the skip connection carries the activated tensor).
 
-CPU tensors, non-fp32 dtypes, autocast regions, planes above 128x128 and `FusedSequential.enabled = False` take the plain
-module-by-module path.
+Activations may be fp32 or bf16 (BASELINE config 5 runs the convolutions under bf16 autocast; the kernels then read and
+write bf16 and compute in fp32).  CPU tensors, other dtypes, planes above 128x128 and `FusedSequential.enabled = False`
+take the plain module-by-module path.
 """
 import torch
 import torch.nn as nn
@@ -97,7 +98,7 @@ class FusedSequential(nn.Sequential):
         return None
 
     def forward(self, x, head_act_done=False):
-        usable = (FusedSequential.enabled and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled('cuda'))
+        usable = FusedSequential.enabled and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
         mods = list(self)
         n = len(mods)
         i = 0
@@ -122,6 +123,10 @@ class FusedSequential(nn.Sequential):
                     i += 1
                     continue
                 y = _conv_no_bias(m, x)
+                if not y.is_contiguous() or y.dtype not in (torch.float32, torch.bfloat16):      # e.g. channels_last: plain modules
+                    x = y + m.bias.view(1, -1, 1, 1).to(y.dtype)
+                    i += 1
+                    continue
                 if act is not None:
                     x = _BiasAct.apply(y, m.bias, act[0], act[1])
                     i += 2
@@ -135,7 +140,7 @@ class FusedSequential(nn.Sequential):
                 else:
                     y, bias, j = x, None, i + 1
                 hw = y.size(2) * y.size(3)
-                if hw > ops.INSTNORM_MAX_PLANE or hw < 2 or not y.is_contiguous():
+                if hw > ops.INSTNORM_MAX_PLANE or hw < 2 or not y.is_contiguous() or y.dtype not in (torch.float32, torch.bfloat16):
                     if conv:                       # too large for the plane-in-registers kernel: plain modules
                         y = y + m.bias.view(1, -1, 1, 1)
                     x = norm(y)

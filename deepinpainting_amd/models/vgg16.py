@@ -79,7 +79,7 @@ class Vgg16(torch.nn.Module):
         self.load_state_dict(mapped)
 
     def _fused_slice(self, seq, x):
-        """No-grad fp32 HIP path of one slice: convolutions without bias (MIOpen has none; PyTorch would add it in a
+        """No-grad HIP path of one slice (fp32, or bf16 activations under autocast): convolutions without bias (MIOpen has none; PyTorch would add it in a
         separate pass), then ONE pass for bias + ReLU (+ the 2x2 max-pool when it follows) — ops.bias_act_ /
         ops.bias_relu_pool2, bit-identical to Conv2d(bias) -> ReLU(inplace) -> MaxPool2d."""
         from .. import ops
@@ -101,7 +101,7 @@ class Vgg16(torch.nn.Module):
         return x
 
     def forward(self, X):
-        fused = (X.is_cuda and X.dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
+        fused = (X.is_cuda and X.dtype in (torch.float32, torch.bfloat16)
                  and not (torch.is_grad_enabled() and (X.requires_grad or self.slice1[0].weight.requires_grad)))
         if fused:
             X = X.contiguous()

@@ -152,14 +152,29 @@ def backward(grad_out, bwd_index, triple_w, M, patch=1):
     return gin
 
 
+def _req_io(t, name):
+    """Activation tensors of the glue kernels: contiguous fp32 or bf16 on the GPU -> (tensor, io_bf16 flag)."""
+    if not torch.is_tensor(t) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA/HIP tensor" % name)
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
+    return (t if t.is_contiguous() else t.contiguous()), int(t.dtype == torch.bfloat16)
+
+
+def _f32(t):
+    """bias / gamma / beta are fp32 parameters."""
+    return None if t is None else _req(t, torch.float32, "parameter")
+
+
 def bias_act_(x, bias, act="relu", slope=0.2):
-    """In place x[b,c,...] = act(x + bias[c]) on a contiguous fp32 [B,C,*] tensor.  act: none | relu | leaky."""
-    x = _req(x, torch.float32, "x")
+    """In place x[b,c,...] = act(x + bias[c]) on a contiguous fp32/bf16 [B,C,*] tensor.  act: none | relu | leaky."""
+    if not x.is_contiguous():
+        raise RuntimeError("bias_act_ works in place and needs a contiguous tensor")
+    x, bf = _req_io(x, "x")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
-    code = {"none": 0, "relu": 1, "leaky": 2}[act]
-    _lib.check(_lib.lib().ipsr_bias_act(x.data_ptr(), bias.data_ptr() if bias is not None else None, B, C, hw, code,
-                                        float(slope), _stream()), "ipsr_bias_act")
+    _lib.check(_lib.lib().ipsr_bias_act(x.data_ptr(), _ptr(_f32(bias)), B, C, hw, ACT_CODE[act], float(slope), bf, _stream()),
+               "ipsr_bias_act")
     return x
 
 
@@ -173,51 +188,51 @@ def _ptr(t):
 
 def instnorm_act_forward(x, bias, gamma, beta, eps, act, slope):
     """y = act(InstanceNorm(x + bias[c]) * gamma[c] + beta[c]) -> (y, mean [B*C], rstd [B*C]); x contiguous fp32 [B,C,H,W]."""
-    x = _req(x, torch.float32, "x")
+    x, bf = _req_io(x, "x")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
     y = torch.empty_like(x)
     mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().ipsr_instnorm_act_forward(x.data_ptr(), _ptr(bias), _ptr(gamma), _ptr(beta), float(eps), ACT_CODE[act],
-                                                    float(slope), B, C, hw, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream()),
-               "ipsr_instnorm_act_forward")
+    _lib.check(_lib.lib().ipsr_instnorm_act_forward(x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps),
+                                                    ACT_CODE[act], float(slope), B, C, hw, bf, y.data_ptr(), mean.data_ptr(),
+                                                    rstd.data_ptr(), _stream()), "ipsr_instnorm_act_forward")
     return y, mean, rstd
 
 
 def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_affine, need_bias):
     """-> (dx, dgamma [C] | None, dbeta [C] | None, dbias [C] | None)."""
-    dy = _req(dy, torch.float32, "grad_output")
+    dy, bf = _req_io(dy.to(x.dtype), "grad_output")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
     dx = torch.empty_like(x)
     part = torch.empty((3, B, C), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), _ptr(bias), _ptr(gamma), mean.data_ptr(),
-                                                     rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, dx.data_ptr(),
-                                                     part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(), _stream()),
+    _lib.check(_lib.lib().ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)),
+                                                     mean.data_ptr(), rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
+                                                     dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(), _stream()),
                "ipsr_instnorm_act_backward")
     s = part.sum(1)                                     # batch reduction of the per-plane partials: one tiny kernel
     return dx, (s[0] if need_affine else None), (s[1] if need_affine else None), (s[2] if need_bias else None)
 
 
 def bias_act_backward(dy, y, act, slope, need_bias):
-    dy = _req(dy, torch.float32, "grad_output")
+    dy, bf = _req_io(dy.to(y.dtype), "grad_output")
     B, C = y.shape[0], y.shape[1]
     hw = y.numel() // (B * C)
     dx = torch.empty_like(y)
     part = torch.empty((B, C), dtype=torch.float32, device=y.device) if need_bias else None
-    _lib.check(_lib.lib().ipsr_bias_act_backward(dy.data_ptr(), y.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, dx.data_ptr(),
+    _lib.check(_lib.lib().ipsr_bias_act_backward(dy.data_ptr(), y.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf, dx.data_ptr(),
                                                  _ptr(part), _stream()), "ipsr_bias_act_backward")
     return dx, (part.sum(0) if need_bias else None)
 
 
 def bias_relu_pool2(x, bias):
     """max_pool2d(relu(x + bias[c]), 2, 2) of a contiguous fp32 [B,C,H,W] tensor in one pass."""
-    x = _req(x, torch.float32, "x")
+    x, bf = _req_io(x, "x")
     B, C, H, W = x.shape
-    y = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().ipsr_bias_relu_pool2(x.data_ptr(), bias.data_ptr() if bias is not None else None, B, C, H, W,
-                                               y.data_ptr(), _stream()), "ipsr_bias_relu_pool2")
+    y = torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().ipsr_bias_relu_pool2(x.data_ptr(), _ptr(_f32(bias)), B, C, H, W, bf, y.data_ptr(), _stream()),
+               "ipsr_bias_relu_pool2")
     return y
 
 

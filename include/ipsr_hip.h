@@ -132,9 +132,11 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
  * the convolution is issued without bias and one pass does the rest, with the same arithmetic (bit-identical).
  *   ipsr_bias_act          in place  x[b,c,:] = act(x[b,c,:] + bias[c]);  act: 0 none, 1 ReLU, 2 LeakyReLU(slope);
  *                          bias may be NULL
- *   ipsr_bias_relu_pool2   y[b,c,i,j] = max over the 2x2 window of relu(x + bias[c]);  y is [B,C,H/2,W/2] */
-int ipsr_bias_act(float* x, const float* bias, int B, int C, int HW, int act, float slope, void* stream);
-int ipsr_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H, int W, float* y, void* stream);
+ *   ipsr_bias_relu_pool2   y[b,c,i,j] = max over the 2x2 window of relu(x + bias[c]);  y is [B,C,H/2,W/2]
+ * io_bf16 (here and in the norm entry points below): 0 = the activation tensors are fp32, 1 = bf16 (BASELINE config 5:
+ * convolutions under bf16 autocast); bias/gamma/beta, statistics and all arithmetic are fp32 either way. */
+int ipsr_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* stream);
+int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, void* stream);
 
 /* ---- conv-bias + InstanceNorm2d + activation ------------------------------------------------------
  * replaces the chain  Conv2d/ConvTranspose2d bias add -> nn.InstanceNorm2d(affine) -> LeakyReLU(0.2)/ReLU  that follows
@@ -145,13 +147,14 @@ int ipsr_bias_relu_pool2(const float* x, const float* bias, int B, int C, int H,
  *   backward: dx [B,C,HW]; per-plane partials dgamma_p/dbeta_p/dbias_p [B*C] (any may be NULL) — the caller sums them
  *             over the batch.  `y` is the forward OUTPUT (the activation's derivative is taken from its sign).
  *   ipsr_bias_act_backward: backward of ipsr_bias_act: dx = dy * act'(y), dbias_p[b*C+c] = sum of dx over the plane. */
-int ipsr_instnorm_act_forward(const float* x, const float* bias, const float* gamma, const float* beta, float eps,
-                              int act, float slope, int B, int C, int HW, float* y, float* mean, float* rstd, void* stream);
-int ipsr_instnorm_act_backward(const float* dy, const float* y, const float* x, const float* bias, const float* gamma,
-                               const float* mean, const float* rstd, int act, float slope, int B, int C, int HW,
-                               float* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream);
-int ipsr_bias_act_backward(const float* dy, const float* y, int act, float slope, int B, int C, int HW,
-                           float* dx, float* dbias_p, void* stream);
+int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gamma, const float* beta, float eps,
+                              int act, float slope, int B, int C, int HW, int io_bf16,
+                              void* y, float* mean, float* rstd, void* stream);
+int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, const float* bias, const float* gamma,
+                               const float* mean, const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16,
+                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream);
+int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16,
+                           void* dx, float* dbias_p, void* stream);
 
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward

@@ -578,3 +578,43 @@ def test_fused_small_unet_against_fp64():
             FusedSequential.enabled = True
         print(type(net).__name__, "rel. error vs fp64  fused:", err[True], " plain:", err[False])
         assert err[True][0] <= max(3 * err[False][0], 2e-5) and err[True][1] <= max(3 * err[False][1], 2e-4), err
+
+
+@pytest.mark.parametrize("shape,act", [((2, 6, 16, 16), "leaky"), ((4, 32, 64, 64), "relu"), ((2, 5, 7, 9), "none"), ((2, 64, 128, 128), "leaky")])
+def test_fused_instnorm_act_bf16_io(shape, act):
+    """bf16 activations (BASELINE config 5): same kernels with bf16 loads/stores and fp32 arithmetic, against the fp32 torch
+    chain evaluated on the SAME bf16-rounded inputs; the outputs agree to bf16 rounding (2^-8 relative)."""
+    from deepinpainting_amd.models.fused import _InstNormAct, _BiasAct
+    g = torch.Generator(device="cuda").manual_seed(17)
+    C = shape[1]
+    xb = (torch.randn(shape, device="cuda", generator=g) * 2 + 0.5).to(torch.bfloat16)
+    bias = torch.randn(C, device="cuda", generator=g).requires_grad_(True)
+    gamma = (torch.rand(C, device="cuda", generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, device="cuda", generator=g).requires_grad_(True)
+    dyb = torch.randn(shape, device="cuda", generator=g).to(torch.bfloat16)
+    f = {"leaky": lambda t: torch.nn.functional.leaky_relu(t, 0.2), "relu": torch.relu, "none": lambda t: t}[act]
+    x32 = xb.float().requires_grad_(True)
+    y_ref = f(torch.nn.functional.instance_norm(x32 + bias.view(1, -1, 1, 1), None, None, gamma, beta, True, 0.1, 1e-5))
+    g_ref = torch.autograd.grad(y_ref, (x32, gamma, beta), dyb.float())
+    xh = xb.clone().requires_grad_(True)
+    y = _InstNormAct.apply(xh, bias, gamma, beta, 1e-5, act, 0.2)
+    assert y.dtype == torch.bfloat16
+    g_hip = torch.autograd.grad(y, (xh, gamma, beta), dyb)
+    assert g_hip[0].dtype == torch.bfloat16 and g_hip[1].dtype == torch.float32
+    tol = 2.0 ** -7
+    assert float((y.float() - y_ref).abs().max()) <= tol * max(1.0, float(y_ref.abs().max()))
+    # the activation mask is taken from the bf16-rounded output: elements within rounding of 0 may flip -> compare in aggregate
+    num = float((g_hip[0].float() - g_ref[0]).norm()); den = float(g_ref[0].norm())
+    assert num <= 2e-2 * den, (num, den)
+    for a, b in zip(g_hip[1:], g_ref[1:]):
+        assert float((a - b).abs().max()) <= 2e-2 * max(1.0, float(b.abs().max()))
+    # bias + activation in place, bf16
+    t = xb.clone()
+    out = _BiasAct.apply(t, bias.detach(), "leaky", 0.2)
+    want = torch.nn.functional.leaky_relu(xb.float() + bias.detach().view(1, -1, 1, 1), 0.2).to(torch.bfloat16)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, want)
+    from deepinpainting_amd import ops
+    if shape[2] % 2 == 0 and shape[3] % 2 == 0:
+        pooled = ops.bias_relu_pool2(xb, bias.detach())
+        wantp = torch.nn.functional.max_pool2d(torch.relu(xb.float() + bias.detach().view(1, -1, 1, 1)), 2, 2).to(torch.bfloat16)
+        assert torch.equal(pooled, wantp)

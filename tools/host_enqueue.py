@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Is the training step GPU-bound or launch-bound?  Times (a) the host-side enqueue of one step with an EMPTY GPU queue
+(synchronise, then time the Python call alone) and (b) the synchronised step.  enqueue << step  =>  GPU-bound."""
+import contextlib, io, os, sys, time, gc
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from deepinpainting_amd.models.models import create_model  # noqa: E402
+from deepinpainting_amd.options import Option  # noqa: E402
+
+opt = Option(gpu_ids=[0], batchSize=8, use_dropout=True, quiet=True, checkpoints_dir="/tmp/ipsr_enq_ck")
+torch.manual_seed(1234)
+with contextlib.redirect_stdout(io.StringIO()):
+    model = create_model(opt)
+img, mask, ref = bench.synthetic_batch(torch.device("cuda", 0), 8, 1234)
+for _ in range(5):
+    bench.train_step(model, img, mask, ref)
+torch.cuda.synchronize()
+gc.collect(); gc.freeze()
+enq, tot = [], []
+for i in range(20):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bench.train_step(model, img, mask, ref)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
+enq.sort(); tot.sort()
+print("host enqueue of one step: median %.1f ms (min %.1f)   synchronised step: median %.1f ms (min %.1f)" %
+      (enq[len(enq) // 2], enq[0], tot[len(tot) // 2], tot[0]))
