@@ -58,3 +58,66 @@ def cal_sps_for_Advanced_Indexing(h, w):
     sp_y = torch.arange(0, w).long().repeat(h)
     sp_x = torch.arange(0, h).long().repeat_interleave(w)
     return sp_x, sp_y
+
+
+# ----------------------------------------------------------------------------------------------------
+# Image / bookkeeping helpers of the reference's util/util.py that its drivers import next to the mask
+# functions (train.ipynb, test.ipynb, app.py).  Host-side, no GPU work; present so that the package alias
+# of INTEGRATION.md §2a covers the whole `util.util` surface.
+# ----------------------------------------------------------------------------------------------------
+def tensor2im(image_tensor, imtype=None):
+    """reference :15-21 — first image of a [-1,1] batch as an HxWx3 array scaled to [0,255] (grey -> 3 channels)."""
+    import numpy as np
+    arr = image_tensor[0].detach().float().cpu().numpy()
+    if arr.shape[0] == 1:
+        arr = np.repeat(arr, 3, axis=0)
+    arr = (arr.transpose(1, 2, 0) + 1.0) * 127.5
+    return arr.astype(np.uint8 if imtype is None else imtype)
+
+
+def diagnose_network(net, name='network'):
+    """reference :23-31 — mean absolute gradient over the parameters that have one (the reference computes it and
+    drops it; here it is returned as well)."""
+    vals = [p.grad.detach().abs().mean() for p in net.parameters() if p.grad is not None]
+    return float(torch.stack(vals).mean()) if vals else 0.0
+
+
+def binary_mask(in_mask, threshold):
+    """reference :33-39.  NB the reference thresholds an UNINITIALISED ByteTensor of the mask's size (:36-37), i.e. its
+    result does not depend on `in_mask`; no caller uses it.  This one thresholds the mask itself."""
+    assert in_mask.dim() == 2, "mask must be 2 dimensions"
+    return (in_mask > threshold).float()
+
+
+def create_gMask(gMask_opts):
+    """reference :41-64 — crop a fineSize window whose masked area is between 20 % and maxPartition % out of a big
+    pattern.  `pattern` [MAX_SIZE,MAX_SIZE] 0/1 tensor; returns it expanded to mask_global's rank."""
+    import random
+    pattern = gMask_opts['pattern']
+    mask_global = gMask_opts['mask_global']
+    big, fine, most = gMask_opts['MAX_SIZE'], gMask_opts['fineSize'], gMask_opts['maxPartition']
+    if pattern is None:
+        raise ValueError
+    while True:
+        x, y = random.randint(1, big - fine), random.randint(1, big - fine)
+        window = pattern[y:y + fine, x:x + fine]
+        percent = float(window.sum()) * 100.0 / (fine * fine)
+        if 20 < percent < most:
+            break
+    lead = (1,) if mask_global.dim() == 3 else (1, 1)
+    return window.expand(*lead, window.size(0), window.size(1))
+
+
+def save_image(image_numpy, image_path):
+    """reference :177-179."""
+    from PIL import Image
+    Image.fromarray(image_numpy).save(image_path)
+
+
+def info(object, spacing=10, collapse=1):
+    """reference :181-191 — print the callables of an object with their doc strings."""
+    squeeze = (lambda s: " ".join(s.split())) if collapse else (lambda s: s)
+    for name in dir(object):
+        attr = getattr(object, name)
+        if callable(attr):
+            print("%s %s" % (name.ljust(spacing), squeeze(str(attr.__doc__))))

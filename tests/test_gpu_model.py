@@ -286,9 +286,9 @@ import sys, os
 sys.path.insert(0, %r)
 import deepinpainting_amd.models as _m, deepinpainting_amd.util as _u
 sys.modules["models"], sys.modules["util"] = _m, _u
-for _n in ("models", "IPSR", "IPSR_model", "IPSRFunction", "InnerCos", "InnerCos2", "networks", "base_model", "vgg16"):
+for _n in ("models", "IPSR", "IPSR_model", "IPSRFunction", "InnerCos", "InnerCos2", "networks", "base_model", "vgg16", "Early"):
     __import__("deepinpainting_amd.models." + _n); sys.modules["models." + _n] = sys.modules["deepinpainting_amd.models." + _n]
-for _n in ("util", "NonparametricShift", "MaxCoord"):
+for _n in ("util", "NonparametricShift", "MaxCoord", "data_load", "ref_data_load"):
     __import__("deepinpainting_amd.util." + _n); sys.modules["util." + _n] = sys.modules["deepinpainting_amd.util." + _n]
 
 # ---- train.ipynb cell 0 (the fields the models read; paths replaced)
@@ -306,10 +306,14 @@ class Option():
         self.epoch_count = 1; self.phase = 'train'; self.which_epoch = ''; self.niter = 20; self.niter_decay = 100
         self.beta1 = 0.5; self.lr = 0.0002; self.lr_policy = 'lambda'; self.lr_decay_iters = 50; self.isTrain = True
 
-# ---- cell 1
+# ---- cell 1 (the imports the notebook makes from the two packages)
+from util.data_load import Data_load
+from util.ref_data_load import Ref_Data_load
 from models.models import create_model
+from models.Early import EarlyStopping
 import torch
 opt = Option()
+early = EarlyStopping(20)
 model = create_model(opt)
 # ---- cell 2, loop body (one synthetic batch instead of the DataLoader)
 image = torch.rand(1, 3, 256, 256) * 2 - 1
