@@ -85,35 +85,59 @@ def train_step(model, img, mask, ref):
     model.optimize_parameters()
 
 
-def layer_timing(device, iters=50):
-    """IPSR layer forward+backward (ms, median) at [8,512,32,32], M=256 — `x = |N(0,1)|`, `ref = relu(N(0,1))`."""
+def _layer_case(device, B, h, fine, mask_img, patch, iters):
+    """Median forward / backward ms of the IPSR layer alone on synthetic features (`x = |N(0,1)|`, `ref = relu(N(0,1))`)."""
     from deepinpainting_amd import ops
     g = torch.Generator(device=device).manual_seed(7)
-    x = torch.randn(BATCH, C_FEAT, H_FEAT, H_FEAT, device=device, generator=g).abs()
-    ref = torch.relu(torch.randn(BATCH, C_FEAT, H_FEAT, H_FEAT, device=device, generator=g))
-    grad = torch.randn(BATCH, C_FEAT, H_FEAT, H_FEAT, device=device, generator=g)
-    m = torch.zeros(FINE, FINE, dtype=torch.uint8, device=device)
-    m[FINE // 4:3 * FINE // 4, FINE // 4:3 * FINE // 4] = 1
-    feat = ops.feat_mask(m, 3, 5 / 16.0)
-    _, mpi, cnt = ops.index_prep(feat, 1, 1, 1)
+    x = torch.randn(B, C_FEAT, h, h, device=device, generator=g).abs()
+    ref = torch.relu(torch.randn(B, C_FEAT, h, h, device=device, generator=g))
+    grad = torch.randn(B, C_FEAT, h, h, device=device, generator=g)
+    feat = ops.feat_mask(mask_img, 3, 5 / 16.0)
+    _, mpi, cnt = ops.index_prep(feat, patch, 1, 1)
     M = int(cnt.item())
     mpi = mpi[:M].contiguous()
-    for _ in range(5):
-        f = ops.forward(x, ref, mpi)
-        ops.backward(grad, f.bwd_index, 1.0, M)
+    for _ in range(3):
+        f = ops.forward(x, ref, mpi, patch=patch)
+        ops.backward(grad, f.bwd_index, 1.0, M, patch=patch)
     torch.cuda.synchronize()
     fwd, bwd = [], []
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for _ in range(iters):
         ev[0].record()
-        f = ops.forward(x, ref, mpi)
+        f = ops.forward(x, ref, mpi, patch=patch)
         ev[1].record()
-        ops.backward(grad, f.bwd_index, 1.0, M)
+        ops.backward(grad, f.bwd_index, 1.0, M, patch=patch)
         ev[2].record()
         torch.cuda.synchronize()
         fwd.append(ev[0].elapsed_time(ev[1]))
         bwd.append(ev[1].elapsed_time(ev[2]))
-    return statistics.median(fwd), statistics.median(bwd)
+    return statistics.median(fwd), statistics.median(bwd), M
+
+
+def _centre(device, size):
+    m = torch.zeros(size, size, dtype=torch.uint8, device=device)
+    m[size // 4:3 * size // 4, size // 4:3 * size // 4] = 1
+    return m
+
+
+def layer_timing(device, iters=50):
+    """IPSR layer forward+backward (ms, median) at [8,512,32,32], M=256 (BASELINE config 2)."""
+    f, b, _ = _layer_case(device, BATCH, H_FEAT, FINE, _centre(device, FINE), 1, iters)
+    return f, b
+
+
+def layer_timing_other_configs(device):
+    """The layer at the other BASELINE.json configurations (parity-test cases, reported for reference only)."""
+    from deepinpainting_amd.util.staging import random_stroke_mask
+    out = {}
+    stroke = random_stroke_mask(FINE, torch.Generator().manual_seed(3), device=device)[0, 0].to(torch.uint8)
+    for key, (B, h, fine, mimg, patch, iters) in {
+            "config3_freeform_256": (BATCH, H_FEAT, FINE, stroke, 1, 20),
+            "config4_512_patch1": (4, 64, 512, _centre(device, 512), 1, 10),
+            "config4_512_patch3": (4, 64, 512, _centre(device, 512), 3, 5)}.items():
+        f, b, M = _layer_case(device, B, h, fine, mimg, patch, iters)
+        out[key] = {"forward": round(f, 4), "backward": round(b, 4), "shape": "[%d,%d,%d,%d], shift_sz=%d, M=%d" % (B, C_FEAT, h, h, patch, M)}
+    return out
 
 
 def cpu_baseline(sample_batch=2, steps=1):
@@ -256,6 +280,7 @@ def main():
                    "vgg16": "seeded random init (no pretrained weights offline)"},
         "ipsr_layer_ms": {"forward": round(fwd_ms, 4), "backward": round(bwd_ms, 4), "total": round(fwd_ms + bwd_ms, 4),
                           "shape": "[%d,%d,%d,%d], M=256" % (BATCH, C_FEAT, H_FEAT, H_FEAT)},
+        "ipsr_layer_ms_other_configs": layer_timing_other_configs(device),
         "roofline": {"kernel": "ipsr::corr_argmax_kernel (fp32 MFMA correlation + arg-max)", "bound": "mfma",
                      "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,
