@@ -44,7 +44,9 @@ def main():
     w.writerow(["# steady state: %d training steps, wall %.3f ms/step, kernel time %.3f ms/step (GPU busy %.1f%%), %d dispatches/step"
                 % (nsteps, wall / nsteps / 1e6, tot / nsteps / 1e6, 100.0 * tot / wall, len(sel) // nsteps)])
     w.writerow(["Name", "CallsPerStep", "AverageNs", "MinNs", "MaxNs", "TotalPerStepUs", "Percentage"])
-    for name, e in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
+    ranked = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    keep = ranked[:a.top] + [kv for kv in ranked[a.top:] if "ipsr::" in kv[0]]      # this repo's own kernels are always listed
+    for name, e in keep:
         w.writerow([name[:160], round(e[0] / nsteps, 2), round(e[1] / e[0], 1), e[2], e[3], round(e[1] / nsteps / 1e3, 2), round(100.0 * e[1] / tot, 2)])
 
 
