@@ -57,7 +57,9 @@ def _private_miopen_db():
 
 _private_miopen_db()
 
-STEP_FLOPS_PER_IMAGE = 378.4e9     # conv/mm forward+backward of one training step at 256x256 with 3 VGG passes
+STEP_FLOPS_PER_IMAGE = 366.3e9     # conv/mm forward+backward of one training step at 256x256 as executed (414.9
+                                   # in the reference, minus its duplicate VGG pass 36.5, minus VGG slice 4 of the generated-
+                                   # image pass 12.1, whose output nobody reads)
 METRIC = "train images/sec at 256x256, batch 8/GPU, 1/2/4/8 MI355X; IPSR layer ms"
 FINE, BATCH, C_FEAT, H_FEAT = 256, 8, 512, 32
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32-input MFMA = 64 FLOP/clk/SIMD
@@ -285,8 +287,7 @@ def main():
                      "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,
                      "traffic": traffic, "flops_per_launch": flops, "kernel_ms": round(kms, 5), "launches_timed": len(kern_ms)},
-        # the whole step against the same roofline: direct-convolution FLOPs of the step AS EXECUTED here (SURVEY §8d:
-        # 414.9 GFLOP/image in the reference, minus the VGG pass it computes twice, models/IPSR.py:187 vs :213)
+        # the whole step against the same roofline: direct-convolution FLOPs of the step AS EXECUTED here
         "step_roofline": {"bound": "mfma", "flops_per_image": STEP_FLOPS_PER_IMAGE,
                           "achieved": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                           "unit": "TFLOP/s per GPU", "frac": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),

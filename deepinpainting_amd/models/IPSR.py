@@ -15,6 +15,10 @@ What is new (none of it changes results):
   * one cal_feat_mask per set_input instead of three (:155-158 computes the same pyramid 3x);
   * VGG(input_B) of set_gt_latent is reused by backward_D (:187 vs :213 recompute the same features) —
     switch off with `opt.strict_reference = True`;
+  * the VGG pass over the generated image stops after slice 3: only its relu3_3 is ever read (:192,218), the three
+    512-channel convolutions of slice 4 were computed and dropped (same switch);
+  * bias / InstanceNorm / activation between the convolutions run as fused HIP kernels (models/fused.py), the frozen
+    VGG's bias / ReLU / max-pool likewise (models/vgg16.py) — same values up to fp32 rounding;
   * data parallelism: with torch.distributed initialised (one process per GPU, RCCL) the gradients are
     bucket-all-reduced by deepinpainting_amd.dist.GradBucketReducer, overlapped with the backward.
 """
@@ -221,7 +225,9 @@ class IPSR(BaseModel):
     def backward_D(self):
         fake_AB = self.fake_B
         with torch.no_grad(), self._amp():
-            self.gt_latent_fake = self.vgg(self.fake_B.data)
+            # only relu3_3 of the generated image is read (below and in backward_G): skip VGG slice 4 unless asked for
+            # the reference's exact sequence
+            self.gt_latent_fake = self.vgg(self.fake_B.data, last_slice=4 if self.strict_reference else 3)
             if self._gt_latent is not None and not self.strict_reference:
                 self.gt_latent_real = self._gt_latent                               # same features as :213 recomputes
             else:

@@ -100,18 +100,21 @@ class Vgg16(torch.nn.Module):
                 i += 1
         return x
 
-    def forward(self, X):
+    def forward(self, X, last_slice=4):
+        """`last_slice` < 4 stops after that slice (later outputs are None): the trainer's pass over the generated image
+        only feeds relu3_3 to the feature discriminator (models/IPSR.py:234,249 here; reference :192,218), so the three
+        512-channel convolutions of slice 4 would be computed and thrown away."""
         fused = (X.is_cuda and X.dtype in (torch.float32, torch.bfloat16)
                  and not (torch.is_grad_enabled() and (X.requires_grad or self.slice1[0].weight.requires_grad)))
         if fused:
             X = X.contiguous()
             h1 = self._fused_slice(self.slice1, X)
-            h2 = self._fused_slice(self.slice2, h1)
-            h3 = self._fused_slice(self.slice3, h2)
-            h4 = self._fused_slice(self.slice4, h3)
+            h2 = self._fused_slice(self.slice2, h1) if last_slice >= 2 else None
+            h3 = self._fused_slice(self.slice3, h2) if last_slice >= 3 else None
+            h4 = self._fused_slice(self.slice4, h3) if last_slice >= 4 else None
             return VggOutputs(h1, h2, h3, h4)
         h1 = self.slice1(X)
-        h2 = self.slice2(h1)
-        h3 = self.slice3(h2)
-        h4 = self.slice4(h3)
+        h2 = self.slice2(h1) if last_slice >= 2 else None
+        h3 = self.slice3(h2) if last_slice >= 3 else None
+        h4 = self.slice4(h3) if last_slice >= 4 else None
         return VggOutputs(h1, h2, h3, h4)
