@@ -17,6 +17,8 @@ What is new (none of it changes results):
     switch off with `opt.strict_reference = True`;
   * the VGG pass over the generated image stops after slice 3: only its relu3_3 is ever read (:192,218), the three
     512-channel convolutions of slice 4 were computed and dropped (same switch);
+  * backward_G runs with the discriminators' parameters frozen: the gradients it would leave in netD / netF are cleared
+    unused by the next optimize_parameters (:269-270) (same switch);
   * bias / InstanceNorm / activation between the convolutions run as fused HIP kernels (models/fused.py), the frozen
     VGG's bias / ReLU / max-pool likewise (models/vgg16.py) — same values up to fp32 rounding;
   * data parallelism: with torch.distributed initialised (one process per GPU, RCCL) the gradients are
@@ -250,6 +252,20 @@ class IPSR(BaseModel):
             self._reducer_D.finish()
 
     def backward_G(self):
+        # What loss_G.backward() deposits in netD / netF is never used: optimize_parameters() clears those gradients
+        # before the next backward_D (:269-270).  With the discriminators' parameters frozen for this backward, autograd
+        # skips their weight gradients and the whole graph of the two "real" branches and of the feature discriminator
+        # (whose inputs do not depend on the generator); the generator's gradients are unchanged.
+        frozen = [] if self.strict_reference else [p for net in (self.netD, self.netF) for p in net.parameters() if p.requires_grad]
+        for p in frozen:
+            p.requires_grad_(False)
+        try:
+            self._backward_G()
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+
+    def _backward_G(self):
         with self._amp():
             pred_fake = self.netD(self.fake_B).float()
             pred_fake_f = self.netF(self.gt_latent_fake.relu3_3).float()

@@ -106,11 +106,43 @@ def test_scheduler_lambda_rule():
 
 @pytest.fixture(scope="module")
 def trainer(tmp_path_factory):
-    opt = Option(gpu_ids=[], batchSize=1, use_dropout=False, quiet=True, checkpoints_dir=str(tmp_path_factory.mktemp("ckpt")))
+    # strict_reference: the reference's exact sequence, including the work whose results it never uses (the fixture holds
+    # the gradients backward_G leaves in netD / netF); the default mode is compared with this one in
+    # test_default_mode_changes_no_live_value
+    opt = Option(gpu_ids=[], batchSize=1, use_dropout=False, quiet=True, strict_reference=True,
+                 checkpoints_dir=str(tmp_path_factory.mktemp("ckpt")))
     m = quiet(cpu_model.create_cpu_model, opt)
     for i, net in enumerate((m.netG, m.netP, m.netD, m.netF, m.vgg)):
         golden_cases.reinit_deterministic(net, 500 + i)
     return m
+
+
+def test_default_mode_changes_no_live_value(tmp_path):
+    """The default trainer drops work whose results the reference never uses (duplicate VGG pass, VGG slice 4 of the
+    generated image, discriminator gradients of backward_G).  Two steps from identical weights in both modes: every logged
+    error, both generated images and every parameter of all four nets after the optimizer steps must agree."""
+    img, mask, ref = golden_cases.trainer_inputs()
+    runs = {}
+    for strict in (True, False):
+        opt = Option(gpu_ids=[], batchSize=1, use_dropout=False, quiet=True, strict_reference=strict,
+                     checkpoints_dir=str(tmp_path / ("ck%d" % strict)))
+        m = quiet(cpu_model.create_cpu_model, opt)
+        for i, net in enumerate((m.netG, m.netP, m.netD, m.netF, m.vgg)):
+            golden_cases.reinit_deterministic(net, 500 + i)
+        errs = []
+        for _ in range(2):
+            m.set_input(img, mask, ref)
+            m.set_ref_latent()
+            m.set_gt_latent()
+            m.optimize_parameters()
+            e = m.get_current_errors()
+            errs.append([e['G_GAN'], e['G_L1'], e['D'], e['F'], float(m.ng_loss_value), float(m.ng_loss_value2)])
+        runs[strict] = (errs, m.fake_B.detach().clone(), m.fake_P.detach().clone(),
+                        {n + "." + k: v.clone() for n in ("netG", "netP", "netD", "netF") for k, v in getattr(m, n).state_dict().items()})
+    np.testing.assert_allclose(runs[False][0], runs[True][0], rtol=1e-6)
+    assert torch.equal(runs[False][1], runs[True][1]) and torch.equal(runs[False][2], runs[True][2])
+    for k, v in runs[True][3].items():
+        assert torch.equal(runs[False][3][k], v), k
 
 
 def test_trainer_step_matches_reference(trainer):
