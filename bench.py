@@ -142,7 +142,39 @@ def layer_timing_other_configs(device):
             "config4_512_patch3": (4, 64, 512, _centre(device, 512), 3, 5)}.items():
         f, b, M = _layer_case(device, B, h, fine, mimg, patch, iters)
         out[key] = {"forward": round(f, 4), "backward": round(b, 4), "shape": "[%d,%d,%d,%d], shift_sz=%d, M=%d" % (B, C_FEAT, h, h, patch, M)}
+    out["config3_per_sample_masks_256"] = _per_sample_case(device)
     return out
+
+
+def _per_sample_case(device, iters=10):
+    """Extension: one free-form mask PER SAMPLE (models/IPSR_model.py) — the layer then runs sample by sample."""
+    from collections import namedtuple
+    from deepinpainting_amd.models.IPSR_model import IPSR_model
+    from deepinpainting_amd.util.staging import random_stroke_mask
+    Vgg = namedtuple("VggOutputs", ["relu1_2", "relu2_2", "relu3_3", "relu4_3"])
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.randn(BATCH, C_FEAT, H_FEAT, H_FEAT, device=device, generator=g).abs().requires_grad_(True)
+    ref = Vgg(None, None, None, torch.relu(torch.randn(BATCH, C_FEAT, H_FEAT, H_FEAT, device=device, generator=g)))
+    grad = torch.randn(BATCH, C_FEAT, H_FEAT, H_FEAT, device=device, generator=g)
+    masks = torch.cat([random_stroke_mask(FINE, torch.Generator().manual_seed(100 + b), device=device) for b in range(BATCH)], 0)
+    layer = IPSR_model(5 / 16.0, 1, 1, 1, 1, 1.0)
+    layer.set_mask(masks, 3, 5 / 16.0)
+    layer.set_ref(ref)
+    fwd, bwd = [], []
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for i in range(iters + 2):
+        ev[0].record()
+        y = layer(x)
+        ev[1].record()
+        torch.autograd.grad(y, x, grad)
+        ev[2].record()
+        torch.cuda.synchronize()
+        if i >= 2:
+            fwd.append(ev[0].elapsed_time(ev[1]))
+            bwd.append(ev[1].elapsed_time(ev[2]))
+    Ms = [int(ix[3].numel()) for ix in layer._per_sample_index]
+    return {"forward": round(statistics.median(fwd), 4), "backward": round(statistics.median(bwd), 4),
+            "shape": "[%d,%d,%d,%d], M per sample %d..%d (incl. the autograd wrapper)" % (BATCH, C_FEAT, H_FEAT, H_FEAT, min(Ms), max(Ms))}
 
 
 def cpu_baseline(sample_batch=2, steps=1):

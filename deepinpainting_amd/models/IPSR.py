@@ -137,7 +137,8 @@ class IPSR(BaseModel):
 
     # ------------------------------------------------------------------------------------------------
     def set_input(self, input, mask, ref):
-        """reference :120-152.  input [B,3,H,W] in [-1,1] (ground truth), mask [1,1,H,W] bool, ref [B,3,H,W]."""
+        """reference :120-152.  input [B,3,H,W] in [-1,1] (ground truth), mask [1,1,H,W] bool, ref [B,3,H,W].
+        Extension: a [B,1,H,W] mask gives every sample its own hole (models/IPSR_model.py)."""
         self.input_A.resize_(input.size()).copy_(input)
         self.input_B.resize_(input.size()).copy_(input)
         self.input_ref.resize_(ref.size()).copy_(ref)
@@ -152,7 +153,7 @@ class IPSR(BaseModel):
             raise ValueError("Mask_type [%s] not recognized." % self.opt.mask_type)
 
         mg = self.mask_global
-        self.ex_mask = mg.expand(1, 3, mg.size(2), mg.size(3))
+        self.ex_mask = mg.expand(mg.size(0), 3, mg.size(2), mg.size(3))
         self.inv_ex_mask = torch.add(torch.neg(self.ex_mask.float()), 1).bool()
         # fill the hole with the ImageNet channel means mapped to [-1,1] (:148-150)
         for ch, mean in enumerate((123.0, 104.0, 117.0)):
@@ -162,7 +163,7 @@ class IPSR(BaseModel):
     def set_latent_mask(self, mask_global, layer_to_last, threshold):
         """reference :155-158 — one feature-mask pyramid shared by the layer and both loss taps."""
         feat = self.CSA_model[0].set_mask(mask_global, layer_to_last, threshold)
-        feat4 = feat[None, None]
+        feat4 = feat[:, None] if feat.dim() == 3 else feat[None, None]
         shared = feat4 if (layer_to_last == 3 and threshold == self.opt.threshold) else None
         self.Cosis_list[0].set_mask(mask_global, self.opt, feat_mask=shared)
         self.Cosis_list2[0].set_mask(mask_global, self.opt, feat_mask=shared)

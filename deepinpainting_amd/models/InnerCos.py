@@ -47,8 +47,13 @@ class InnerCos(nn.Module):
 
     def set_mask(self, mask_global, opt, feat_mask=None):
         """reference InnerCos.py:16-21: the 3-level feature mask as a float [h,w] tensor."""
-        mask = feat_mask if feat_mask is not None else util.cal_feat_mask(mask_global, 3, opt.threshold)
-        self.mask = mask.squeeze().float()
+        if feat_mask is not None:
+            mask = feat_mask
+        elif mask_global.size(0) > 1:                                   # per-sample masks (extension, see IPSR_model)
+            mask = util.cal_feat_mask_batch(mask_global, 3, opt.threshold)
+        else:
+            mask = util.cal_feat_mask(mask_global, 3, opt.threshold)
+        self.mask = (mask[:, 0] if mask.size(0) > 1 else mask.squeeze()).float()
 
     def set_target(self, targetIn):
         self.target = targetIn
@@ -61,7 +66,12 @@ class InnerCos(nn.Module):
             cuse = in_data.size(1) if self._narrow is None else self._narrow
             self.bs, self.c = in_data.size(0), cuse
             self.former = in_data if self._narrow is None else in_data.narrow(1, 0, cuse)
-            self.loss = _InnerCosLoss.apply(in_data, cuse, self.mask, self.target, float(self.strength))
+            if self.mask.dim() == 3:      # per-sample masks: equal-sized samples, so the batch mean is the mean of the per-sample means
+                per = [_InnerCosLoss.apply(in_data[b:b + 1], cuse, self.mask[b], self.target[b:b + 1], float(self.strength))
+                       for b in range(in_data.size(0))]
+                self.loss = torch.stack(per).mean()
+            else:
+                self.loss = _InnerCosLoss.apply(in_data, cuse, self.mask, self.target, float(self.strength))
             self.output = in_data
         else:
             self.loss = 0

@@ -20,6 +20,12 @@ def cal_feat_mask(inMask, conv_layers, threshold):
     return feat[None, None]
 
 
+def cal_feat_mask_batch(inMask, conv_layers, threshold):
+    """Per-sample masks (extension): cal_feat_mask of every [1,1,H,W] slice of a [B,1,H,W] mask -> [B,1,h,w] byte."""
+    assert inMask.dim() == 4, "mask must be 4 dimensions"
+    return torch.cat([cal_feat_mask(inMask[b:b + 1], conv_layers, threshold) for b in range(inMask.size(0))], 0)
+
+
 def flatten_offsets_from_flag(flag):
     """The reference's `flatten_offsets` (util/util.py:149-157).  Dead data — IPSRFunction stores it on ctx
     and never reads it (models/IPSRFunction.py:21,88-89) — kept because it is part of the 12-argument

@@ -622,3 +622,60 @@ def test_fused_instnorm_act_bf16_io(shape, act):
         pooled = ops.bias_relu_pool2(xb, bias.detach())
         wantp = torch.nn.functional.max_pool2d(torch.relu(xb.float() + bias.detach().view(1, -1, 1, 1)), 2, 2).to(torch.bfloat16)
         assert torch.equal(pooled, wantp)
+
+
+def test_per_sample_masks_equal_batch_of_one_calls(tmp_path):
+    """Extension: a [B,1,H,W] mask gives every sample its own hole.  The layer and the loss taps must give, per sample,
+    exactly what a batch-of-one call with that sample's mask gives (the reference's semantics for batchSize = 1), forward
+    and backward; and the whole training step runs with per-sample free-form masks."""
+    from deepinpainting_amd.models.IPSR_model import IPSR_model
+    from deepinpainting_amd.models.InnerCos import InnerCos
+    from deepinpainting_amd.util.staging import random_stroke_mask
+    from deepinpainting_amd.options import Option
+    from deepinpainting_amd.models.models import create_model
+    B, C, h = 3, 64, 16
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn(B, C, h, h, device="cuda", generator=g).abs()
+    ref = Vgg(None, None, None, torch.rand(B, C, h, h, device="cuda", generator=g))
+    tgt = torch.rand(B, C, h, h, device="cuda", generator=g)
+    dy = torch.randn(B, C, h, h, device="cuda", generator=g)
+    masks = torch.cat([random_stroke_mask(128, torch.Generator().manual_seed(40 + b), width=(8, 24)) for b in range(B)], 0).cuda()
+    opt = Option(gpu_ids=[0])
+    layer = IPSR_model(opt.threshold, 1, 1, 1, 1, 0.5)
+    feat = layer.set_mask(masks, 3, opt.threshold)
+    assert feat.shape == (B, h, h) and len({int(f.sum()) for f in feat}) > 1            # different hole sizes
+    layer.set_ref(ref)
+    ic = InnerCos(strength=0.7)
+    ic.set_mask(masks, opt)
+    ic.set_target(tgt)
+    xa = x.clone().requires_grad_(True)
+    y = layer(xa)
+    ic(y)
+    (gx,) = torch.autograd.grad(y, xa, dy)
+    losses = []
+    for b in range(B):
+        one = IPSR_model(opt.threshold, 1, 1, 1, 1, 0.5)
+        one.set_mask(masks[b:b + 1], 3, opt.threshold)
+        one.set_ref(Vgg(None, None, None, ref.relu4_3[b:b + 1]))
+        xb = x[b:b + 1].clone().requires_grad_(True)
+        yb = one(xb)
+        assert torch.equal(yb, y[b:b + 1])
+        assert torch.equal(torch.autograd.grad(yb, xb, dy[b:b + 1])[0], gx[b:b + 1])
+        icb = InnerCos(strength=0.7)
+        icb.set_mask(masks[b:b + 1], opt)
+        icb.set_target(tgt[b:b + 1])
+        icb(yb)
+        losses.append(float(icb.loss))
+    assert abs(float(ic.loss) - sum(losses) / B) <= 1e-6 * max(1.0, abs(float(ic.loss)))
+    # the whole step with per-sample free-form masks
+    opt = Option(gpu_ids=[0], batchSize=2, use_dropout=False, quiet=True, checkpoints_dir=str(tmp_path))
+    m = quiet(create_model, opt)
+    img, _, refimg = golden_cases.trainer_inputs(B=2)
+    big = torch.cat([random_stroke_mask(256, torch.Generator().manual_seed(60 + b)) for b in range(2)], 0)
+    for _ in range(2):
+        m.set_input(img.cuda(), big.cuda(), refimg.cuda())
+        m.set_ref_latent()
+        m.set_gt_latent()
+        m.optimize_parameters()
+    assert all(np.isfinite(v) for v in m.get_current_errors().values())
+    assert float(m.real_A[0][:, big[0, 0]].abs().max()) == 0.0 and float(m.real_A[1][:, big[1, 0]].abs().max()) == 0.0
