@@ -24,7 +24,7 @@ class DeviceStager(object):
         if self.stream is None:
             return t.to(self.device)
         if not t.is_pinned():
-            t = t.pin_memory()
+            t = t.contiguous().pin_memory()
         return t.to(self.device, non_blocking=True)
 
     def _prefetch(self):
