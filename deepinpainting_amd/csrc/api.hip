@@ -82,7 +82,8 @@ static FwdPlan plan_forward(int B, int C, int h, int w, int M, int patch, size_t
     sz[WS_XT] = (size_t)B * p.N * p.Cp * 4;
     sz[WS_INV] = (size_t)B * p.N * 4;
     sz[WS_CORR] = corr_argmax_ws_bytes(B, p.K, p.N);
-    sz[WS_XU] = sz[WS_RU] = patch > 1 ? (size_t)B * p.K * p.ld * 4 : 0;
+    sz[WS_XU] = 0;                                        // (the unfolded x is no longer materialised)
+    sz[WS_RU] = patch > 1 ? (size_t)B * p.K * p.ld * 4 : 0;
     sz[WS_OU] = patch > 1 ? (size_t)B * p.K * p.N * 4 : 0;
     sz[WS_WN] = sz[WS_WO] = sz[WS_KQ] = sz[WS_JQ] = (size_t)B * Mx * 4;
     sz[WS_DLIST] = (size_t)B * p.Mc * 4;
@@ -228,14 +229,16 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     const float* rs = ref;
     float* outs = out;
     if (patch > 1) {
-        float* xu = reinterpret_cast<float*>(slice[WS_XU]);
+        // x is consumed through its normalised / patch-major copies only: those are produced straight from the feature;
+        // only the reference side (operand B of the correlation) is materialised unfolded
         float* ru = reinterpret_cast<float*>(slice[WS_RU]);
-        if (int rc = launch_unfold(x, B, C, h, w, patch, p.ld, xu, st)) return rc;
         if (int rc = launch_unfold(ref, B, C, h, w, patch, p.ld, ru, st)) return rc;
-        xs = xu; rs = ru;
+        if (int rc = launch_unfold_normalize(x, B, C, h, w, patch, p.ld, xn, xT, p.Cp, inv, st)) return rc;
+        xs = nullptr; rs = ru;
         outs = reinterpret_cast<float*>(slice[WS_OU]);
+    } else {
+        if (int rc = launch_patch_normalize(xs, B, p.K, p.N, xn, xT, p.Cp, inv, st, p.ld, p.ld)) return rc;
     }
-    if (int rc = launch_patch_normalize(xs, B, p.K, p.N, xn, xT, p.Cp, inv, st, p.ld, p.ld)) return rc;
     AttnArgs a;
     if (int rc = launch_corr_argmax(xn, rs, B, p.K, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
     a.x = xs; a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;

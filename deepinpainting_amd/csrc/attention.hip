@@ -338,15 +338,20 @@ __device__ __forceinline__ void recurrence_quad_body(int* lds_raw, int b, const 
     for (int d = 0; d < QD; ++d) { load_row_quad<NW>(pu[d], xTb, rl.q_s[d], Cp, J); load_row_quad<NW>(pk[d], xTb, rl.kq_s[d], Cp, J); }
 
     const int nsteps = M - 1;
-    auto step = [&](const RowRegs<NW>& ru, const RowRegs<NW>& rk, int s) {
-        const float iq = rl.iv_s[s], v = rl.vm_s[s];
+    // The chain is bound by VALU issue (4 cycles per wave instruction), so the lanes whose chunk lies past Cp are handled
+    // with 2*NW selects per step instead of one per element: their row registers hold chunk 0 of the row (finite), which
+    // is multiplied by a zeroed copy of the step's scalars; their slice of o stays (+-)0 and adds nothing to the dot.
+    bool live[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) live[i] = (J + 256 * i) * 8 < Cp;
+    auto step = [&](const RowRegs<NW>& ru, const RowRegs<NW>& rk, int s, float iq, float v) {
         float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const bool live = (J + 256 * i) * 8 < Cp;
+            const float iqi = live[i] ? iq : 0.0f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float u = (live ? ru.v[i][e] : 0.0f) * iq;
+                const float u = ru.v[i][e] * iqi;
                 acc = __builtin_fmaf(u, o.v[i][e], acc);
             }
         }
@@ -360,11 +365,11 @@ __device__ __forceinline__ void recurrence_quad_body(int* lds_raw, int b, const 
         const float wn = at / sden, wo = v / sden;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const bool live = (J + 256 * i) * 8 < Cp;
+            const float woi = live[i] ? wo : 0.0f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float t0 = wn * o.v[i][e];
-                const float t1 = wo * (live ? rk.v[i][e] : 0.0f);
+                const float t1 = woi * rk.v[i][e];
                 o.v[i][e] = t0 + t1;
             }
         }
@@ -373,16 +378,22 @@ __device__ __forceinline__ void recurrence_quad_body(int* lds_raw, int b, const 
 
     int t = 0;
     for (; t + QD <= nsteps; t += QD) {
+        // the scalars and row indices of the whole turn in one go (the barrier's memory clobber would otherwise pin one
+        // LDS round trip into every step)
+        float ivs[QD], vms[QD];
+        int qn[QD], kn[QD];
+#pragma unroll
+        for (int d = 0; d < QD; ++d) { ivs[d] = rl.iv_s[t + d]; vms[d] = rl.vm_s[t + d]; qn[d] = rl.q_s[t + d + QD]; kn[d] = rl.kq_s[t + d + QD]; }
 #pragma unroll
         for (int d = 0; d < QD; ++d) {
-            step(pu[d], pk[d], t + d);
-            load_row_quad<NW>(pu[d], xTb, rl.q_s[t + d + QD], Cp, J);        // padding entries repeat a valid row
-            load_row_quad<NW>(pk[d], xTb, rl.kq_s[t + d + QD], Cp, J);
+            step(pu[d], pk[d], t + d, ivs[d], vms[d]);
+            load_row_quad<NW>(pu[d], xTb, qn[d], Cp, J);        // padding entries repeat a valid row
+            load_row_quad<NW>(pk[d], xTb, kn[d], Cp, J);
         }
     }
 #pragma unroll
     for (int d = 0; d < QD - 1; ++d)
-        if (t + d < nsteps) step(pu[d], pk[d], t + d);        // uniform across the block: every wave reaches the barrier
+        if (t + d < nsteps) step(pu[d], pk[d], t + d, rl.iv_s[t + d], rl.vm_s[t + d]);   // uniform across the block: every wave reaches the barrier
     __syncthreads();
     for (int l = J; l < M; l += 256) { wn_out[(size_t)b * M + l] = rl.wn_s[l]; wo_out[(size_t)b * M + l] = rl.wo_s[l]; }
 }

@@ -16,21 +16,32 @@
 
 namespace ipsr {
 
+// one thread -> 4 consecutive columns of one row: four gathered loads, one 16-byte store (ld % 4 == 0 or scalar tail)
 __global__ void __launch_bounds__(256) unfold_kernel(const float* __restrict__ x, int C, int h, int w, int patch, int nW,
                                                      int Np, int ld, float* __restrict__ xu)
 {
-    const int col = blockIdx.x * 256 + threadIdx.x;      // window index (or pad column)
-    const int k = blockIdx.y;                            // row of the unfolded matrix
+    const int col0 = (blockIdx.x * 256 + threadIdx.x) * 4;   // first window index (or pad column) of this thread
+    const int k = blockIdx.y;                                // row of the unfolded matrix
     const int b = blockIdx.z;
-    if (col >= ld) return;
+    if (col0 >= ld) return;
     const int pp = patch * patch;
     const int c = k / pp, d = k - c * pp, dy = d / patch, dx = d - dy * patch;
-    float v = 0.0f;
-    if (col < Np) {
-        const int i = col / nW, j = col - i * nW;
-        v = x[(((size_t)b * C + c) * h + i + dy) * w + j + dx];
+    const float* src = x + (((size_t)b * C + c) * h + dy) * w + dx;
+    float v[4];
+    int i = col0 / nW, j = col0 - i * nW;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = (col0 + e < Np) ? src[(size_t)i * w + j] : 0.0f;
+        if (++j == nW) { j = 0; ++i; }
     }
-    xu[((size_t)b * C * pp + k) * ld + col] = v;
+    float* dst = xu + ((size_t)b * C * pp + k) * ld + col0;
+    if ((ld & 3) == 0) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col0 + e < ld) dst[e] = v[e];
+    }
 }
 
 __global__ void __launch_bounds__(256) fold_kernel(const float* __restrict__ yu, int C, int h, int w, int patch, int nH, int nW,
@@ -60,7 +71,7 @@ int launch_unfold(const float* x, int B, int C, int h, int w, int patch, int ld,
 {
     const int nH = h - patch + 1, nW = w - patch + 1, Np = nH * nW, K = C * patch * patch;
     if (K > 65535 || B > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: C*p*p=%d exceeds the unfold grid", K);
-    unfold_kernel<<<dim3(cdiv(ld, 256), K, B), 256, 0, st>>>(x, C, h, w, patch, nW, Np, ld, xu);
+    unfold_kernel<<<dim3(cdiv(ld, 1024), K, B), 256, 0, st>>>(x, C, h, w, patch, nW, Np, ld, xu);
     return check_launch("unfold_kernel");
 }
 
