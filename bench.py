@@ -163,10 +163,11 @@ def _per_sample_case(device, iters=10):
     fwd, bwd = [], []
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for i in range(iters + 2):
+        xin = x * 1.0                     # a non-leaf, as in the network (a leaf's AccumulateGrad lives on ONE stream)
         ev[0].record()
-        y = layer(x)
+        y = layer(xin)
         ev[1].record()
-        torch.autograd.grad(y, x, grad)
+        torch.autograd.grad(y, xin, grad)
         ev[2].record()
         torch.cuda.synchronize()
         if i >= 2:
