@@ -178,7 +178,7 @@ def _per_sample_case(device, iters=10):
             "shape": "[%d,%d,%d,%d], M per sample %d..%d (incl. the autograd wrapper)" % (BATCH, C_FEAT, H_FEAT, H_FEAT, min(Ms), max(Ms))}
 
 
-def cpu_baseline(sample_batch=2, steps=1):
+def cpu_baseline(sample_batch=2, steps=3):
     """The CPU twin on this host's cores: same trainer class, PyTorch-CPU convs, oracle-backed IPSR layer."""
     from deepinpainting_amd.options import Option
     from oracle import cpu_model, ipsr_oracle as orc
