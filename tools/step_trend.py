@@ -20,7 +20,7 @@ _gc_t = {}
 def _cb(phase, info):
     if phase == 'start':
         _gc_t['t'] = time.perf_counter()
-    else:
+    elif info['generation'] >= 2:
         print('gc gen%d collected=%d took %.1f ms' % (info['generation'], info['collected'], (time.perf_counter() - _gc_t['t']) * 1e3))
 gc.callbacks.append(_cb)
 ts = []
@@ -30,4 +30,6 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 print(" ".join("%.1f" % t for t in ts))
+errs = model.get_current_errors()
+print("median %.2f ms  max %.2f ms  losses %s" % (sorted(ts)[len(ts) // 2], max(ts), {k: round(v, 3) for k, v in errs.items()}))
 print("mem allocated %.2f GB reserved %.2f GB" % (torch.cuda.memory_allocated() / 2**30, torch.cuda.memory_reserved() / 2**30))
