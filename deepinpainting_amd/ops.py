@@ -26,9 +26,17 @@ def _workspace(nbytes, device):
     return buf
 
 
+def _on_current_device(t, name):
+    # the kernels are launched on the CURRENT device's stream with raw pointers: a tensor living on another GPU would fault
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError("%s is on %s but the current device is cuda:%d — wrap the call in torch.cuda.device(...) "
+                           "(one process per GPU sets it once)" % (name, t.device, torch.cuda.current_device()))
+
+
 def _req(t, dtype, name):
     if not torch.is_tensor(t) or not t.is_cuda:
         raise RuntimeError("%s must be a CUDA/HIP tensor — the IPSR layer has no CPU path" % name)
+    _on_current_device(t, name)
     if t.dtype != dtype:
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
     return t if t.is_contiguous() else t.contiguous()
@@ -158,6 +166,7 @@ def _req_io(t, name):
         raise RuntimeError("%s must be a CUDA/HIP tensor" % name)
     if t.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
+    _on_current_device(t, name)
     return (t if t.is_contiguous() else t.contiguous()), int(t.dtype == torch.bfloat16)
 
 
