@@ -223,9 +223,8 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     float* xT = reinterpret_cast<float*>(slice[WS_XT]);
     float* inv = reinterpret_cast<float*>(slice[WS_INV]);
 
-    // shift_sz > 1: unfold both operands (unfold.hip); from here on a "channel" is one of the K numbers of a patch and a
-    // "position" one of the N' windows.  The result comes back as patches and is overlap-added at the end.
-    const float* xs = x;
+    // shift_sz > 1: from here on a "channel" is one of the K numbers of a patch and a "position" one of the N' windows.
+    // The result comes back as patches and is overlap-added at the end.
     const float* rs = ref;
     float* outs = out;
     if (patch > 1) {
@@ -234,14 +233,14 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
         float* ru = reinterpret_cast<float*>(slice[WS_RU]);
         if (int rc = launch_unfold(ref, B, C, h, w, patch, p.ld, ru, st)) return rc;
         if (int rc = launch_unfold_normalize(x, B, C, h, w, patch, p.ld, xn, xT, p.Cp, inv, st)) return rc;
-        xs = nullptr; rs = ru;
+        rs = ru;
         outs = reinterpret_cast<float*>(slice[WS_OU]);
     } else {
-        if (int rc = launch_patch_normalize(xs, B, p.K, p.N, xn, xT, p.Cp, inv, st, p.ld, p.ld)) return rc;
+        if (int rc = launch_patch_normalize(x, B, p.K, p.N, xn, xT, p.Cp, inv, st, p.ld, p.ld)) return rc;
     }
     AttnArgs a;
     if (int rc = launch_corr_argmax(xn, rs, B, p.K, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
-    a.x = xs; a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
+    a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
     a.B = B; a.C = p.K; a.Cp = p.Cp; a.N = p.N; a.M = M; a.Mc = p.Mc;
     a.wn = reinterpret_cast<float*>(slice[WS_WN]);
     a.wo = reinterpret_cast<float*>(slice[WS_WO]);

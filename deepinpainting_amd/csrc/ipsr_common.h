@@ -136,7 +136,6 @@ int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, i
                        float* S_out, void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials = nullptr, int ld = 0);
 
 struct AttnArgs {
-    const float* x;        // [B,C,N] raw features
     const float* xT;       // [B,N,Cp] patch-major raw copy, zero padded to Cp = roundup(C,8)
     const float* inv;      // [B,N]
     int32_t* ind;          // [B,N]  written by the stage kernel (merged arg-max)
