@@ -12,7 +12,8 @@ Design for the MI355X node (8 GPUs, full xGMI mesh, 7 links x ~153 GB/s per GPU)
     all-reduces, each big enough to be bandwidth- not latency-bound on the mesh);
   * a bucket's all-reduce is launched asynchronously from the post-accumulate-grad hook of its last
     parameter, i.e. while autograd is still producing earlier layers' gradients (overlap with backward);
-  * `finish()` waits, scales by 1/world and scatters the flat result back into the .grad tensors.
+  * the 1/world scaling is applied to the bucket before its collective (under the backward); `finish()` only waits and
+    points every .grad at its slice of the reduced bucket (no copy back).
 Works with any torch.distributed backend ("nccl" == RCCL on ROCm; "gloo" for the CPU tests).
 """
 import os
@@ -113,6 +114,7 @@ class GradBucketReducer(object):
             off += n
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b["params"]]
         torch._foreach_copy_(views, grads)
+        flat.mul_(1.0 / self.world)          # the mean's scaling happens here, under the backward, not after the wait
         self._work.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), views))
 
     def finish(self):
@@ -125,16 +127,12 @@ class GradBucketReducer(object):
         for bi in range(len(self.buckets)):
             if bi not in launched:
                 self._launch(bi)
-        inv = 1.0 / self.world
         for bi, work, views in self._work:
             work.wait()
-            b = self.buckets[bi]
-            b["flat"].mul_(inv)
-            for p, v in zip(b["params"], views):
-                if p.grad is None:
-                    p.grad = v.clone()
-                else:
-                    p.grad.copy_(v)
+            # the rank-averaged gradients stay where the collective left them: .grad becomes a view of the bucket (no copy
+            # back).  The bucket is rewritten only by the next armed backward, after the optimizer has consumed these.
+            for p, v in zip(self.buckets[bi]["params"], views):
+                p.grad = v
         self._work = []
         self.armed = False
 
