@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libipsr_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -34,6 +34,8 @@ SIGNATURES = {
     "ipsr_backward_workspace_bytes": (c_size_t, [c_int] * 5),
     "ipsr_backward_patch": (c_int, [c_void_p, c_int, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
+    "ipsr_cat_relu_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ipsr_cat_relu_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ipsr_bias_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "ipsr_bias_relu_pool2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ipsr_instnorm_act_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_int, c_int, c_int, c_int,

@@ -105,7 +105,7 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 3; }
+int ipsr_abi_version(void) { return 4; }
 
 const char* ipsr_last_error(void) { return g_err; }
 
@@ -306,6 +306,24 @@ int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, 
     if (B < 1 || C < 1 || H < 2 || W < 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_relu_pool2: bad size B=%d C=%d H=%d W=%d", B, C, H, W);
     if ((W & 3) == 0 && !aligned_io(x, io_bf16)) return fail(IPSR_ERR_INVALID, "ipsr_bias_relu_pool2: x is not vector aligned");
     return launch_bias_relu_pool2(x, bias, B, C, H, W, io_bf16, y, static_cast<hipStream_t>(stream));
+}
+
+int ipsr_cat_relu_forward(const void* y, const void* x, int B, int C1, int C2, int HW, int io_bf16, void* out, void* stream)
+{
+    if (!y || !x || !out) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_forward: null pointer");
+    if (B < 1 || C1 < 1 || C2 < 1 || HW < 1) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_forward: bad size");
+    if ((HW & 3) == 0 && (!aligned_io(y, io_bf16) || !aligned_io(x, io_bf16) || !aligned_io(out, io_bf16)))
+        return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_forward: tensors are not vector aligned");
+    return launch_cat_relu_fwd(y, x, B, C1, C2, HW, io_bf16, out, static_cast<hipStream_t>(stream));
+}
+
+int ipsr_cat_relu_backward(const void* grad_out, const void* out, int B, int C1, int C2, int HW, int io_bf16, void* dy, void* dx, void* stream)
+{
+    if (!grad_out || !out || !dy || !dx) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_backward: null pointer");
+    if (B < 1 || C1 < 1 || C2 < 1 || HW < 1) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_backward: bad size");
+    if ((HW & 3) == 0 && (!aligned_io(grad_out, io_bf16) || !aligned_io(out, io_bf16) || !aligned_io(dy, io_bf16) || !aligned_io(dx, io_bf16)))
+        return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_backward: tensors are not vector aligned");
+    return launch_cat_relu_bwd(grad_out, out, B, C1, C2, HW, io_bf16, dy, dx, static_cast<hipStream_t>(stream));
 }
 
 int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,

@@ -165,6 +165,8 @@ int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn
 // pointwise.hip — VGG16 feature net glue (bias / ReLU / 2x2 max-pool in one pass)
 int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, hipStream_t st);
 int launch_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, hipStream_t st);
+int launch_cat_relu_fwd(const void* y, const void* x, int B, int C1, int C2, int HW, int io_bf16, void* out, hipStream_t st);
+int launch_cat_relu_bwd(const void* g, const void* out, int B, int C1, int C2, int HW, int io_bf16, void* dy, void* dx, hipStream_t st);
 
 // instnorm.hip — conv-bias + InstanceNorm2d + activation, fused forward / backward (one (sample, channel) plane per workgroup)
 int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,

@@ -74,6 +74,81 @@ __global__ void __launch_bounds__(256) bias_relu_pool2_kernel(const IO* __restri
     }
 }
 
+// torch.cat([y, x], 1) followed by the parent level's in-place ReLU (models/networks.py:270-278 + :229 `uprelu`): one pass
+//     out[b, :C1] = relu(y[b]),  out[b, C1:] = relu(x[b])
+// and its backward (threshold_backward + the two channel slices, written as two contiguous tensors):
+//     dy = g[b, :C1] * (out[b, :C1] > 0),  dx = g[b, C1:] * (out[b, C1:] > 0)
+template <typename IO>
+__global__ void __launch_bounds__(256) cat_relu_fwd_kernel(const IO* __restrict__ y, const IO* __restrict__ x, int C1, int C2, int HW,
+                                                           IO* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const size_t n1 = (size_t)C1 * HW, n2 = (size_t)C2 * HW, n = n1 + n2;
+    const IO* yb = y + (size_t)b * n1;
+    const IO* xb = x + (size_t)b * n2;
+    IO* ob = out + (size_t)b * n;
+    if ((HW & 3) == 0) {
+        const size_t n4 = n >> 2, n14 = n1 >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            float4 v = i < n14 ? ld4(yb, i) : ld4(xb, i - n14);
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            st4(ob, i, v);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+            st1(ob, i, fmaxf(i < n1 ? ld1(yb, i) : ld1(xb, i - n1), 0.0f));
+    }
+}
+
+template <typename IO>
+__global__ void __launch_bounds__(256) cat_relu_bwd_kernel(const IO* __restrict__ g, const IO* __restrict__ out, int C1, int C2, int HW,
+                                                           IO* __restrict__ dy, IO* __restrict__ dx)
+{
+    const int b = blockIdx.y;
+    const size_t n1 = (size_t)C1 * HW, n2 = (size_t)C2 * HW, n = n1 + n2;
+    const IO* gb = g + (size_t)b * n;
+    const IO* ob = out + (size_t)b * n;
+    IO* dyb = dy + (size_t)b * n1;
+    IO* dxb = dx + (size_t)b * n2;
+    if ((HW & 3) == 0) {
+        const size_t n4 = n >> 2, n14 = n1 >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const float4 gv = ld4(gb, i), ov = ld4(ob, i);
+            float4 r;
+            r.x = ov.x > 0.0f ? gv.x : 0.0f; r.y = ov.y > 0.0f ? gv.y : 0.0f;
+            r.z = ov.z > 0.0f ? gv.z : 0.0f; r.w = ov.w > 0.0f ? gv.w : 0.0f;
+            if (i < n14) st4(dyb, i, r); else st4(dxb, i - n14, r);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+            const float r = ld1(ob, i) > 0.0f ? ld1(gb, i) : 0.0f;
+            if (i < n1) st1(dyb, i, r); else st1(dxb, i - n1, r);
+        }
+    }
+}
+
+int launch_cat_relu_fwd(const void* y, const void* x, int B, int C1, int C2, int HW, int io_bf16, void* out, hipStream_t st)
+{
+    if (B > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_cat_relu: batch %d > 65535", B);
+    const size_t n = (size_t)(C1 + C2) * HW;
+    int gx = (int)((((HW & 3) == 0 ? n >> 2 : n) + 256 * 4 - 1) / (256 * 4));
+    if (gx < 1) gx = 1;
+    if (io_bf16) cat_relu_fwd_kernel<bf16_t><<<dim3(gx, B), 256, 0, st>>>(static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(x), C1, C2, HW, static_cast<bf16_t*>(out));
+    else cat_relu_fwd_kernel<float><<<dim3(gx, B), 256, 0, st>>>(static_cast<const float*>(y), static_cast<const float*>(x), C1, C2, HW, static_cast<float*>(out));
+    return check_launch("cat_relu_fwd_kernel");
+}
+
+int launch_cat_relu_bwd(const void* g, const void* out, int B, int C1, int C2, int HW, int io_bf16, void* dy, void* dx, hipStream_t st)
+{
+    if (B > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_cat_relu: batch %d > 65535", B);
+    const size_t n = (size_t)(C1 + C2) * HW;
+    int gx = (int)((((HW & 3) == 0 ? n >> 2 : n) + 256 * 4 - 1) / (256 * 4));
+    if (gx < 1) gx = 1;
+    if (io_bf16) cat_relu_bwd_kernel<bf16_t><<<dim3(gx, B), 256, 0, st>>>(static_cast<const bf16_t*>(g), static_cast<const bf16_t*>(out), C1, C2, HW, static_cast<bf16_t*>(dy), static_cast<bf16_t*>(dx));
+    else cat_relu_bwd_kernel<float><<<dim3(gx, B), 256, 0, st>>>(static_cast<const float*>(g), static_cast<const float*>(out), C1, C2, HW, static_cast<float*>(dy), static_cast<float*>(dx));
+    return check_launch("cat_relu_bwd_kernel");
+}
+
 int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, hipStream_t st)
 {
     const int planes = B * C;

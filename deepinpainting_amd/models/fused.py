@@ -61,6 +61,31 @@ class _BiasAct(torch.autograd.Function):
         return dx, dbias, None, None
 
 
+class _CatReLU(torch.autograd.Function):
+    """relu(cat([y, x], 1)): the skip concatenation of a level followed by the parent's in-place ReLU."""
+
+    @staticmethod
+    def forward(ctx, y, x):
+        out = ops.cat_relu_forward(y, x)
+        ctx.save_for_backward(out)
+        ctx.c1 = y.size(1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return ops.cat_relu_backward(g, out, ctx.c1)
+
+
+def cat_skip(y, x, tail_relu):
+    """torch.cat([y, x], 1), with the consumer's in-place ReLU folded in when it asked for that."""
+    if tail_relu and y.is_cuda and y.dtype == x.dtype and y.dtype in (torch.float32, torch.bfloat16) \
+            and y.is_contiguous() and x.is_contiguous() and y.shape[2:] == x.shape[2:]:
+        return _CatReLU.apply(y, x)
+    out = torch.cat([y, x], 1)
+    return torch.relu_(out) if tail_relu else out
+
+
 def _act_of(m):
     """(name, slope) when m is an activation the kernels implement."""
     if isinstance(m, nn.LeakyReLU):
@@ -97,6 +122,10 @@ class FusedSequential(nn.Sequential):
             return _act_of(inner[0])
         return None
 
+    def _tail_relu_after(self, mods, j):
+        """True when mods[j] is the in-place ReLU a skip level's concatenated output runs into (models/networks.py:229,408)."""
+        return j < len(mods) and type(mods[j]) is nn.ReLU and mods[j].inplace
+
     def forward(self, x, head_act_done=False):
         usable = FusedSequential.enabled and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
         mods = list(self)
@@ -131,8 +160,9 @@ class FusedSequential(nn.Sequential):
                     x = _BiasAct.apply(y, m.bias, act[0], act[1])
                     i += 2
                 else:
-                    x = nxt(_BiasAct.apply(y, m.bias, child_act[0], child_act[1]), head_act_done=True)
-                    i += 2
+                    tail = self._tail_relu_after(mods, i + 2)
+                    x = nxt(_BiasAct.apply(y, m.bias, child_act[0], child_act[1]), head_act_done=True, tail_relu=tail)
+                    i += 3 if tail else 2
                 continue
             if norm is not None:
                 if conv:
@@ -154,8 +184,9 @@ class FusedSequential(nn.Sequential):
                 if act is not None:
                     i = j + 1
                 elif child_act is not None:
-                    x = nxt(x, head_act_done=True)
-                    i = j + 1
+                    tail = self._tail_relu_after(mods, j + 1)
+                    x = nxt(x, head_act_done=True, tail_relu=tail)
+                    i = j + 2 if tail else j + 1
                 else:
                     i = j
                 continue

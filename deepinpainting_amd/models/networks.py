@@ -24,7 +24,7 @@ from torch.optim import lr_scheduler
 from .IPSR_model import IPSR_model
 from .InnerCos import InnerCos
 from .InnerCos2 import InnerCos2
-from .fused import FusedSequential
+from .fused import FusedSequential, cat_skip
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -164,16 +164,18 @@ class GANLoss(nn.Module):
 # ----------------------------------------------------------------------------------------------------
 # U-Net building blocks
 # ----------------------------------------------------------------------------------------------------
-def _cat_skip(block, x, head_act_done=False):
+def _cat_skip(block, x, head_act_done=False, tail_relu=False):
     """Shared forward of every skip block (:270-278, :358-366, :443-452).  `head_act_done`: the producer of x has already
-    applied this level's leading in-place activation (fused into its kernel, see models/fused.py)."""
+    applied this level's leading in-place activation; `tail_relu`: the consumer's in-place ReLU is to be applied to the
+    concatenated result here (both fused into kernels, see models/fused.py)."""
     if block.outermost:
-        return block.model(x, head_act_done=head_act_done)
+        y = block.model(x, head_act_done=head_act_done)
+        return torch.relu_(y) if tail_relu else y
     y = block.model(x, head_act_done=head_act_done)
     h, w = x.size(2), x.size(3)
     if h != y.size(2) or w != y.size(3):
         y = F.interpolate(y, (h, w), mode='bilinear')
-    return torch.cat([y, x], 1)
+    return cat_skip(y, x, tail_relu)
 
 
 def _block3_layers(outer_nc, inner_nc, input_nc, norm_layer):
@@ -226,8 +228,8 @@ class UnetSkipConnectionBlock_3(nn.Module):
         L = _block3_layers(outer_nc, inner_nc, input_nc, norm_layer)
         self.model = FusedSequential(*_assemble3(L, outer_nc, inner_nc, submodule, outermost, innermost, use_dropout))
 
-    def forward(self, x, head_act_done=False):
-        return _cat_skip(self, x, head_act_done)
+    def forward(self, x, head_act_done=False, tail_relu=False):
+        return _cat_skip(self, x, head_act_done, tail_relu)
 
 
 class IPSR(nn.Module):
@@ -256,8 +258,8 @@ class IPSR(nn.Module):
         self.model = FusedSequential(*_assemble3(L, outer_nc, inner_nc, submodule, outermost, innermost, use_dropout,
                                                mid_down=(ipsr, innerCos), head_up=(innerCos2,)))
 
-    def forward(self, x, head_act_done=False):
-        return _cat_skip(self, x, head_act_done)
+    def forward(self, x, head_act_done=False, tail_relu=False):
+        return _cat_skip(self, x, head_act_done, tail_relu)
 
 
 class UnetGeneratorIPSR(nn.Module):
@@ -309,8 +311,8 @@ class UnetSkipConnectionBlock(nn.Module):
                 model.append(nn.Dropout(0.5))
         self.model = FusedSequential(*model)
 
-    def forward(self, x, head_act_done=False):
-        return _cat_skip(self, x, head_act_done)
+    def forward(self, x, head_act_done=False, tail_relu=False):
+        return _cat_skip(self, x, head_act_done, tail_relu)
 
 
 class UnetGenerator(nn.Module):

@@ -235,6 +235,32 @@ def bias_act_backward(dy, y, act, slope, need_bias):
     return dx, (part.sum(0) if need_bias else None)
 
 
+def cat_relu_forward(y, x):
+    """relu(torch.cat([y, x], 1)) in one pass; y [B,C1,H,W], x [B,C2,H,W] contiguous, same fp32/bf16 dtype."""
+    y, bf = _req_io(y, "y")
+    x, bf2 = _req_io(x, "x")
+    if bf != bf2 or y.shape[0] != x.shape[0] or y.shape[2:] != x.shape[2:]:
+        raise RuntimeError("cat_relu: mismatched operands %s %s / %s %s" % (tuple(y.shape), y.dtype, tuple(x.shape), x.dtype))
+    B, C1, C2 = y.shape[0], y.shape[1], x.shape[1]
+    hw = y.numel() // (B * C1)
+    out = torch.empty((B, C1 + C2) + tuple(y.shape[2:]), dtype=y.dtype, device=y.device)
+    _lib.check(_lib.lib().ipsr_cat_relu_forward(y.data_ptr(), x.data_ptr(), B, C1, C2, hw, bf, out.data_ptr(), _stream()),
+               "ipsr_cat_relu_forward")
+    return out
+
+
+def cat_relu_backward(grad_out, out, C1):
+    g, bf = _req_io(grad_out.to(out.dtype), "grad_output")
+    B, C = out.shape[0], out.shape[1]
+    C2 = C - C1
+    hw = out.numel() // (B * C)
+    dy = torch.empty((B, C1) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)
+    dx = torch.empty((B, C2) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)
+    _lib.check(_lib.lib().ipsr_cat_relu_backward(g.data_ptr(), out.data_ptr(), B, C1, C2, hw, bf, dy.data_ptr(), dx.data_ptr(), _stream()),
+               "ipsr_cat_relu_backward")
+    return dy, dx
+
+
 def bias_relu_pool2(x, bias):
     """max_pool2d(relu(x + bias[c]), 2, 2) of a contiguous fp32 [B,C,H,W] tensor in one pass."""
     x, bf = _req_io(x, "x")

@@ -135,6 +135,11 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
  *   ipsr_bias_relu_pool2   y[b,c,i,j] = max over the 2x2 window of relu(x + bias[c]);  y is [B,C,H/2,W/2]
  * io_bf16 (here and in the norm entry points below): 0 = the activation tensors are fp32, 1 = bf16 (BASELINE config 5:
  * convolutions under bf16 autocast); bias/gamma/beta, statistics and all arithmetic are fp32 either way. */
+/* skip connection: torch.cat([y, x], 1) + the parent level's in-place ReLU (models/networks.py:270-278 with the `uprelu`
+ * of :229 / :408) in one pass, and its backward (ReLU mask from `out`, the two channel slices as contiguous tensors). */
+int ipsr_cat_relu_forward(const void* y, const void* x, int B, int C1, int C2, int HW, int io_bf16, void* out, void* stream);
+int ipsr_cat_relu_backward(const void* grad_out, const void* out, int B, int C1, int C2, int HW, int io_bf16,
+                           void* dy, void* dx, void* stream);
 int ipsr_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* stream);
 int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, void* stream);
 

@@ -680,3 +680,19 @@ def test_per_sample_masks_equal_batch_of_one_calls(tmp_path):
         m.optimize_parameters()
     assert all(np.isfinite(v) for v in m.get_current_errors().values())
     assert float(m.real_A[0][:, big[0, 0]].abs().max()) == 0.0 and float(m.real_A[1][:, big[1, 0]].abs().max()) == 0.0
+
+
+def test_fused_cat_relu_vs_torch():
+    """relu(cat([y, x], 1)) and its backward in one pass each: bit-identical to torch (fp32 and bf16, odd planes too)."""
+    from deepinpainting_amd.models.fused import _CatReLU
+    g = torch.Generator(device="cuda").manual_seed(23)
+    for shape_y, shape_x, dt in (((2, 5, 7, 9), (2, 3, 7, 9), torch.float32), ((4, 64, 32, 32), (4, 64, 32, 32), torch.float32),
+                                 ((2, 16, 8, 8), (2, 48, 8, 8), torch.bfloat16)):
+        y = torch.randn(shape_y, device="cuda", generator=g).to(dt).requires_grad_(True)
+        x = torch.randn(shape_x, device="cuda", generator=g).to(dt).requires_grad_(True)
+        go = torch.randn((shape_y[0], shape_y[1] + shape_x[1]) + shape_y[2:], device="cuda", generator=g).to(dt)
+        ref = torch.relu(torch.cat([y, x], 1))
+        gr = torch.autograd.grad(ref, (y, x), go)
+        out = _CatReLU.apply(y, x)
+        gh = torch.autograd.grad(out, (y, x), go)
+        assert torch.equal(out, ref) and torch.equal(gh[0], gr[0]) and torch.equal(gh[1], gr[1])
