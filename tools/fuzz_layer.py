@@ -22,9 +22,9 @@ for it in range(a.n):
     p = int(rs.choice([1, 1, 1, 2, 3]))
     B = int(rs.randint(1, 4))
     C = int(rs.choice([3, 8, 12, 16, 20, 32, 64, 96, 128, 200, 256, 512]))
-    if p > 1:
-        C = min(C, 128)
     h, w = int(rs.randint(p, 22)), int(rs.randint(p, 22))
+    if p > 1 and C > 128:                   # wide patches (C*p*p up to 4608: the multi-wave recurrence): keep the oracle fast
+        h, w = int(rs.randint(p, 11)), int(rs.randint(p, 11))
     if p == 1 and rs.rand() < 0.2:
         h = w = int(rs.choice([16, 32]))
     signed = rs.rand() < 0.3
