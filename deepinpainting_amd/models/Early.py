@@ -1,23 +1,21 @@
-"""EarlyStopping — mirror of the reference's models/Early.py (train.ipynb cell 2: `early = EarlyStopping(20)`,
-`early(valid_loss)`, `early.early_stop`).  Bookkeeping only."""
+"""EarlyStopping — the patience counter train.ipynb drives (cell 2: `early = EarlyStopping(20)`, `early(valid_loss)`,
+then `early.early_stop`); mirrors the behaviour of the reference's models/Early.py:4-21.  Bookkeeping only."""
 
 
 class EarlyStopping:
-    """Raises `early_stop` once the validation loss has failed to improve `patience` times in a row (reference :4-21;
-    an equal loss counts as an improvement there and here)."""
+    """Tracks the best (lowest) validation loss.  A loss that is not worse than the best resets the counter — equality
+    counts as an improvement, as in the reference — and `patience` worse losses in a row set `early_stop`.
+    `best_score` keeps the reference's sign convention (the negated loss)."""
 
     def __init__(self, patience=8):
-        self.patience = patience
-        self.counter = 0
-        self.best_score = None
-        self.early_stop = False
+        self.patience, self.counter = patience, 0
+        self.best_score, self.early_stop = None, False
 
     def __call__(self, val_loss):
-        score = -val_loss
-        if self.best_score is None or score >= self.best_score:
-            self.best_score = score
-            self.counter = 0
-            return
-        self.counter += 1
-        if self.counter >= self.patience:
-            self.early_stop = True
+        candidate = -val_loss
+        improved = self.best_score is None or candidate >= self.best_score
+        if improved:
+            self.best_score, self.counter = candidate, 0
+        else:
+            self.counter += 1
+            self.early_stop = self.early_stop or self.counter >= self.patience

@@ -21,20 +21,9 @@ class BaseModel():
         """fp32 buffer on the model's device (the reference aliases torch.cuda.FloatTensor, :12)."""
         return torch.empty(*size, dtype=torch.float32, device=self.device)
 
+    # ---- hooks a concrete trainer overrides (reference :21-41: all of them are no-ops there too) ----
     def set_input(self, input):
         self.input = input
-
-    def forward(self):
-        pass
-
-    def test(self):
-        pass
-
-    def get_image_paths(self):
-        pass
-
-    def optimize_parameters(self):
-        pass
 
     def get_current_visuals(self):
         return self.input
@@ -42,22 +31,28 @@ class BaseModel():
     def get_current_errors(self):
         return {}
 
-    def save(self, label):
-        pass
+    def _noop(self, *args, **kwargs):
+        return None
+
+    forward = test = get_image_paths = optimize_parameters = save = _noop
+
+    def _checkpoint_path(self, network_label, epoch_label):
+        """`{epoch}_net_{label}.pt` under the run directory — the reference's file naming (:48,61)."""
+        return os.path.join(self.save_dir, '%s_net_%s.pt' % (epoch_label, network_label))
 
     def save_network(self, network, network_label, epoch_label, gpu_ids):
         os.makedirs(self.save_dir, exist_ok=True)
-        save_path = os.path.join(self.save_dir, '%s_net_%s.pt' % (epoch_label, network_label))
         # the reference moves the net to the CPU and back (:56-58); saving a CPU copy of the state_dict
         # writes the same file without disturbing the resident parameters
-        torch.save({k: v.detach().cpu() for k, v in network.state_dict().items()}, save_path)
+        cpu_state = {key: value.detach().cpu() for key, value in network.state_dict().items()}
+        torch.save(cpu_state, self._checkpoint_path(network_label, epoch_label))
 
     def load_network(self, network, network_label, epoch_label):
-        save_path = os.path.join(self.save_dir, '%s_net_%s.pt' % (epoch_label, network_label))
-        network.load_state_dict(torch.load(save_path, map_location=self.device))
+        state = torch.load(self._checkpoint_path(network_label, epoch_label), map_location=self.device)
+        network.load_state_dict(state)
 
     def update_learning_rate(self):
-        for scheduler in self.schedulers:
-            scheduler.step()
-        lr = self.optimizers[0].param_groups[0]['lr']
-        print('learning rate = %.7f' % lr)
+        """One scheduler tick per optimizer, then report the generator's rate like the reference (:66-70)."""
+        for sched in self.schedulers:
+            sched.step()
+        print('learning rate = %.7f' % self.optimizers[0].param_groups[0]['lr'])
