@@ -71,3 +71,16 @@ def test_oracle_library_exports_cpu_twins():
     for name in ("ipsr_feat_mask", "ipsr_index_prep", "ipsr_patch_normalize", "ipsr_corr_argmax", "ipsr_forward",
                  "ipsr_backward", "ipsr_backward_patch", "ipsr_unfold", "ipsr_fold", "innercos_loss", "innercos_loss_backward"):
         assert hasattr(o, name + "_cpu")
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ipsr_hip.h is the C-ABI: it must compile as C99 (and as C++) on its own, with no HIP or torch headers."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "ipsr_hip.h"\nint main(void) { return ipsr_abi_version == 0; }\n')
+    for cc, flags in (("gcc", ["-std=c99", "-pedantic"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip("%s not available" % cc)
+        subprocess.check_call([cc, "-Wall", "-Werror", "-I", os.path.join(root, "include")] + flags + ["-c", str(src), "-o", str(tmp_path / (cc + ".o"))])
