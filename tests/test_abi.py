@@ -79,7 +79,7 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "hdr.c"
-    src.write_text('#include "ipsr_hip.h"\nint main(void) { return ipsr_abi_version == 0; }\n')
+    src.write_text('#include "ipsr_hip.h"\nint (*take_address)(void) = ipsr_abi_version;\nint main(void) { return take_address == 0; }\n')
     for cc, flags in (("gcc", ["-std=c99", "-pedantic"]), ("g++", ["-std=c++17", "-x", "c++"])):
         if shutil.which(cc) is None:
             pytest.skip("%s not available" % cc)
