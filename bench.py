@@ -18,7 +18,14 @@ Rank 0 prints ONE JSON line.  `value` = images/s of the whole job (all ranks).  
                 the launch stream inside the timed steps (C-ABI hook ipsr_profile_*).
   cpu_baseline  the CPU twin (oracle C restatement of the layer + PyTorch-CPU convs, oracle/cpu_model.py)
                 timed on this host's cores on a bounded sample (rank 0, N=1 only).
-  ipsr_layer_ms IPSR layer forward+backward at the same shape (second half of BASELINE.json's metric).
+  ipsr_layer_ms IPSR layer forward+backward at the same shape (second half of BASELINE.json's metric): `in_step` = HIP
+                events around every ipsr_forward / ipsr_backward call INSIDE the timed steps (the real, signed conv
+                features: truncation survivors make the backward slower than on synthetic features), `standalone` = the
+                layer alone on synthetic non-negative features (median of 50).
+  strict_reference  the same step with opt.strict_reference=True (the reference's exact sequence incl. the work whose
+                results it never reads, 414.9 GFLOP/image), timed after the headline loop.
+`value` = batch * world * K / wall time of the K timed steps (the driver's contract); `ms_per_step_median` and
+`images_per_sec_median_step` (SURVEY §8d's definition) come from HIP events recorded at every step boundary.
 """
 import argparse
 import contextlib
@@ -65,6 +72,7 @@ STEP_FLOPS_PER_IMAGE = 340.6e9     # conv/mm forward+backward of one training st
                                    # test_default_mode_changes_no_live_value
 METRIC = "train images/sec at 256x256, batch 8/GPU, 1/2/4/8 MI355X; IPSR layer ms"
 FINE, BATCH, C_FEAT, H_FEAT = 256, 8, 512, 32
+REF_FLOPS_PER_IMAGE = 414.9e9      # the reference's own sequence (torch FlopCounterMode)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32-input MFMA = 64 FLOP/clk/SIMD
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_corr_argmax.json")
 
@@ -90,7 +98,7 @@ def train_step(model, img, mask, ref):
     model.optimize_parameters()
 
 
-def _layer_case(device, B, h, fine, mask_img, patch, iters):
+def _layer_case(device, B, h, fine, mask_img, patch, iters, corr="fp32"):
     """Median forward / backward ms of the IPSR layer alone on synthetic features (`x = |N(0,1)|`, `ref = relu(N(0,1))`)."""
     from deepinpainting_amd import ops
     g = torch.Generator(device=device).manual_seed(7)
@@ -102,14 +110,14 @@ def _layer_case(device, B, h, fine, mask_img, patch, iters):
     M = int(cnt.item())
     mpi = mpi[:M].contiguous()
     for _ in range(3):
-        f = ops.forward(x, ref, mpi, patch=patch)
+        f = ops.forward(x, ref, mpi, patch=patch, corr=corr)
         ops.backward(grad, f.bwd_index, 1.0, M, patch=patch)
     torch.cuda.synchronize()
     fwd, bwd = [], []
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for _ in range(iters):
         ev[0].record()
-        f = ops.forward(x, ref, mpi, patch=patch)
+        f = ops.forward(x, ref, mpi, patch=patch, corr=corr)
         ev[1].record()
         ops.backward(grad, f.bwd_index, 1.0, M, patch=patch)
         ev[2].record()
@@ -129,6 +137,33 @@ def layer_timing(device, iters=50):
     """IPSR layer forward+backward (ms, median) at [8,512,32,32], M=256 (BASELINE config 2)."""
     f, b, _ = _layer_case(device, BATCH, H_FEAT, FINE, _centre(device, FINE), 1, iters)
     return f, b
+
+
+def layer_timing_bf16corr(device, iters=50):
+    """BASELINE config 5's layer: the same [8,512,32,32] / M=256 case with the correlation on the bf16 MFMA kernel, the
+    kernel's own time (HIP events through the C-ABI hook) and its arg-max agreement with the fp32 kernel."""
+    from deepinpainting_amd import _lib, ops
+    lib = _lib.lib()
+    f, b, _ = _layer_case(device, BATCH, H_FEAT, FINE, _centre(device, FINE), 1, iters, corr="bf16")
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.randn(BATCH, C_FEAT, H_FEAT * H_FEAT, device=device, generator=g).abs()
+    ref = torch.relu(torch.randn(BATCH, C_FEAT, H_FEAT * H_FEAT, device=device, generator=g))
+    xn, _ = ops.patch_normalize(x)
+    i32, _, _ = ops.corr_argmax(xn, ref)
+    lib.ipsr_profile_enable(20)
+    for _ in range(20):
+        i16, _, _ = ops.corr_argmax(xn, ref, corr="bf16")
+    buf = (ctypes.c_float * 20)()
+    n = lib.ipsr_profile_read_region(0, ctypes.cast(buf, ctypes.c_void_p), 20)
+    lib.ipsr_profile_enable(0)
+    kms = statistics.median([buf[i] for i in range(n)]) if n else None
+    flops = 2.0 * (H_FEAT * H_FEAT) ** 2 * C_FEAT * BATCH
+    return {"dtype": "bf16", "forward": round(f, 4), "backward": round(b, 4), "total": round(f + b, 4),
+            "shape": "[%d,%d,%d,%d], M=256, correlation on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32 accumulate), "
+                     "rest of the layer fp32" % (BATCH, C_FEAT, H_FEAT, H_FEAT),
+            "corr_kernel_ms": round(kms, 5) if kms else None,
+            "corr_kernel_tflops": round(flops / (kms * 1e-3) / 1e12, 1) if kms else None,
+            "argmax_agreement_with_fp32": round(float((i16 == i32).float().mean().item()), 5)}
 
 
 def layer_timing_other_configs(device):
@@ -184,7 +219,7 @@ def cpu_baseline(sample_batch=2, steps=3):
     from oracle import cpu_model, ipsr_oracle as orc
     orc.build()
     cores = torch.get_num_threads()
-    opt = Option(gpu_ids=[], batchSize=sample_batch, use_dropout=True, quiet=True,
+    opt = Option(gpu_ids=[], batchSize=sample_batch, use_dropout=True, quiet=True, allow_random_vgg=True,
                  checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_cpu"))
     torch.manual_seed(1234)
     model = quiet(cpu_model.create_cpu_model, opt)
@@ -193,11 +228,11 @@ def cpu_baseline(sample_batch=2, steps=3):
     for _ in range(steps):
         train_step(model, img, mask, ref)
     dt = time.perf_counter() - t0
-    # layer alone (oracle C restatement), one sample of the same shape, forward + backward
+    # layer alone (oracle C restatement) at the SAME shape as the GPU figure: [8,512,32,32], M=256, forward + backward
     import numpy as np
     rs = np.random.RandomState(7)
-    x = np.abs(rs.standard_normal((1, C_FEAT, H_FEAT, H_FEAT))).astype(np.float32)
-    rf = np.maximum(rs.standard_normal((1, C_FEAT, H_FEAT, H_FEAT)), 0).astype(np.float32)
+    x = np.abs(rs.standard_normal((BATCH, C_FEAT, H_FEAT, H_FEAT))).astype(np.float32)
+    rf = np.maximum(rs.standard_normal((BATCH, C_FEAT, H_FEAT, H_FEAT)), 0).astype(np.float32)
     mpi = model.CSA_model[0].mask_point_idx
     t1 = time.perf_counter()
     f = orc.forward(x, rf, mpi)
@@ -207,7 +242,8 @@ def cpu_baseline(sample_batch=2, steps=3):
         "value": round(sample_batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
         "sample": "%d full training step(s) at batch %d (same 256x256 workload, oracle-backed IPSR layer + "
                   "PyTorch-CPU convs, torch %s, %d threads): %.1f s" % (steps, sample_batch, torch.__version__, cores, dt),
-        "ipsr_layer_ms_per_sample": round(layer_ms, 2),
+        "ipsr_layer_ms": round(layer_ms, 2),
+        "ipsr_layer_shape": "[%d,%d,%d,%d], M=%d, forward+backward, oracle C restatement (OpenMP over samples / column blocks)" % (BATCH, C_FEAT, H_FEAT, H_FEAT, len(mpi)),
     }
 
 
@@ -224,6 +260,9 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 = the reference's precision and the headline metric; bf16 = BASELINE config 5 (convs under "
                          "bf16 autocast, IPSR layer and losses fp32) — a separate, clearly labelled measurement")
+    ap.add_argument("--rccl-algo", default=None, help="NCCL_ALGO for the gradient all-reduce (default: RCCL's tuner)")
+    ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO (e.g. Simple)")
+    ap.add_argument("--rccl-min-channels", default=None, help="NCCL_MIN_NCHANNELS")
     args = ap.parse_args()
 
     from deepinpainting_amd import _lib, dist as idist
@@ -232,7 +271,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the IPSR layer has no CPU path (the CPU twin is only the reported baseline)")
-    rank, world, local_rank = idist.init_distributed(backend="nccl")
+    rank, world, local_rank = idist.init_distributed(backend="nccl", rccl_algo=args.rccl_algo, rccl_proto=args.rccl_proto,
+                                                        rccl_channels=args.rccl_min_channels)
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
@@ -242,7 +282,7 @@ def main():
     # step; off by default so the run finishes quickly, opt in with IPSR_BENCH_MIOPEN_FIND=1
     torch.backends.cudnn.benchmark = os.environ.get("IPSR_BENCH_MIOPEN_FIND", "0") == "1"
 
-    opt = Option(gpu_ids=[local_rank], batchSize=args.batch, use_dropout=True, quiet=True,
+    opt = Option(gpu_ids=[local_rank], batchSize=args.batch, use_dropout=True, quiet=True, allow_random_vgg=True,
                  batch_vgg=os.environ.get("IPSR_BENCH_BATCH_VGG", "0") == "1", amp_bf16=(args.dtype == "bf16"),
                  checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
     torch.manual_seed(1234)                       # identical init on every rank (rank 0 is broadcast anyway)
@@ -267,22 +307,56 @@ def main():
     gc.collect()
     gc.freeze()
     lib.ipsr_profile_enable(max(args.steps, 1))
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for i in range(args.steps):
         train_step(model, img, mask, ref)
+        step_ev[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    buf = (ctypes.c_float * max(args.steps, 1))()
-    n_ev = lib.ipsr_profile_read(ctypes.cast(buf, ctypes.c_void_p), args.steps)
+    step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+
+    def read_region(region):
+        buf = (ctypes.c_float * max(args.steps, 1))()
+        n = lib.ipsr_profile_read_region(region, ctypes.cast(buf, ctypes.c_void_p), args.steps)
+        return [buf[i] for i in range(n)]
+    kern_ms, fwd_in_step, bwd_in_step = read_region(0), read_region(1), read_region(2)
     lib.ipsr_profile_enable(0)
-    kern_ms = [buf[i] for i in range(n_ev)]
+
+    # the reference's exact sequence (strict_reference), same model and inputs, timed the same way after the headline loop
+    strict = None
+    if args.dtype == "f32" and os.environ.get("IPSR_BENCH_NO_STRICT", "0") != "1":
+        ksteps = max(3, min(10, args.steps))
+        model.strict_reference = True
+        for _ in range(2):
+            train_step(model, img, mask, ref)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        ts = time.perf_counter()
+        for _ in range(ksteps):
+            train_step(model, img, mask, ref)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        strict_elapsed = time.perf_counter() - ts
+        model.strict_reference = False
+        if world > 1:
+            t = torch.tensor([strict_elapsed], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            strict_elapsed = float(t.item())
+        strict = {"value": round(args.batch * world * ksteps / strict_elapsed, 3), "unit": "images/sec", "steps": ksteps,
+                  "ms_per_step": round(strict_elapsed / ksteps * 1e3, 3), "flops_per_image": REF_FLOPS_PER_IMAGE,
+                  "note": "opt.strict_reference=True: the reference's sequence incl. the duplicate VGG pass, VGG slice 4 of "
+                          "the generated image and the discriminator gradients of backward_G (dead work, bit-identical live values)"}
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -300,14 +374,20 @@ def main():
     flops = 2.0 * n_feat * n_feat * C_FEAT * args.batch
     kms = statistics.mean(kern_ms) if kern_ms else float("nan")
     achieved = flops / (kms * 1e-3) / 1e12 if kern_ms else None
-    traffic = None
+    traffic, traffic_src = None, None
     if os.path.exists(TRAFFIC_FILE):
         with open(TRAFFIC_FILE) as fh:
-            traffic = json.load(fh).get("hbm_bytes_per_launch")
+            tj = json.load(fh)
+        # a stored PMC figure (two separate rocprofv3 --pmc passes, tools/collect_traffic.py), NOT re-measured in this run;
+        # only quoted when it was taken on this kernel at this shape
+        if "corr_argmax" in tj.get("kernel", "") and tj.get("workload", "").endswith("[%d,%d,%d,%d]" % (args.batch, C_FEAT, H_FEAT, H_FEAT)):
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_src = "stored rocprofv3 --pmc figure (profiles/traffic_corr_argmax.json, FETCH_SIZE x2 + WRITE_SIZE), not re-measured in this run"
     fwd_ms, bwd_ms = layer_timing(device)
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(statistics.median(step_ms), 3),
+        "images_per_sec_median_step": round(args.batch * world / (statistics.median(step_ms) * 1e-3), 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: 256x256 synthetic images, 128x128 centre mask (M=256 of N=1024 "
                                 "feature positions), batch %d/GPU, fp32, full IPSR training step" % args.batch)
@@ -317,18 +397,28 @@ def main():
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "dropout": True,
                    "vgg16": "seeded random init (no pretrained weights offline)"},
         "ipsr_layer_ms": {"forward": round(fwd_ms, 4), "backward": round(bwd_ms, 4), "total": round(fwd_ms + bwd_ms, 4),
-                          "shape": "[%d,%d,%d,%d], M=256" % (BATCH, C_FEAT, H_FEAT, H_FEAT)},
+                          "shape": "[%d,%d,%d,%d], M=256" % (BATCH, C_FEAT, H_FEAT, H_FEAT),
+                          "inputs": "standalone, synthetic x=|N(0,1)|, ref=relu(N(0,1)), median of 50",
+                          "in_step": {"forward": round(statistics.median(fwd_in_step), 4) if fwd_in_step else None,
+                                      "backward": round(statistics.median(bwd_in_step), 4) if bwd_in_step else None,
+                                      "total": round(statistics.median(fwd_in_step) + statistics.median(bwd_in_step), 4)
+                                      if fwd_in_step and bwd_in_step else None,
+                                      "calls_timed": [len(fwd_in_step), len(bwd_in_step)],
+                                      "inputs": "HIP events around ipsr_forward / ipsr_backward inside the timed training steps "
+                                                "(real signed conv features, batch %d)" % args.batch}},
+        "ipsr_layer_ms_bf16corr": layer_timing_bf16corr(device),
         "ipsr_layer_ms_other_configs": layer_timing_other_configs(device),
         "roofline": {"kernel": "ipsr::corr_argmax_kernel (fp32 MFMA correlation + arg-max)", "bound": "mfma",
                      "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,
-                     "traffic": traffic, "flops_per_launch": flops, "kernel_ms": round(kms, 5), "launches_timed": len(kern_ms)},
+                     "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": flops, "kernel_ms": round(kms, 5), "launches_timed": len(kern_ms)},
         # the whole step against the same roofline: direct-convolution FLOPs of the step AS EXECUTED here
         "step_roofline": {"bound": "mfma", "flops_per_image": STEP_FLOPS_PER_IMAGE,
                           "achieved": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                           "unit": "TFLOP/s per GPU", "frac": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                           "note": "fp32 only; MIOpen's Winograd kernels execute fewer real multiplies than this direct count"}
         if args.dtype == "f32" else None,
+        "strict_reference": strict,
         "losses_last_step": {k: round(v, 4) for k, v in errs.items()},
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libipsr_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -29,6 +29,11 @@ SIGNATURES = {
     "ipsr_forward_workspace_bytes": (c_size_t, [c_int] * 7),
     "ipsr_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ipsr_forward_bf16corr_workspace_bytes": (c_size_t, [c_int] * 7),
+    "ipsr_forward_bf16corr": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ipsr_corr_argmax_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ipsr_corr_argmax_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ipsr_backward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p]),
     "ipsr_backward_workspace_bytes": (c_size_t, [c_int] * 5),
@@ -50,6 +55,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p]),
     "ipsr_profile_enable": (c_int, [c_int]),
     "ipsr_profile_read": (c_int, [c_void_p, c_int]),
+    "ipsr_profile_read_region": (c_int, [c_int, c_void_p, c_int]),
 }
 
 

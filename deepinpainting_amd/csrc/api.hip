@@ -34,25 +34,40 @@ int check_launch(const char* what)
     return IPSR_OK;
 }
 
-// ---- opt-in profiling ring --------------------------------------------------------------------------
-static hipEvent_t* g_ev = nullptr;      // 2*capacity events: start0, stop0, start1, ...
-static int g_ev_cap = 0, g_ev_n = 0;
-static bool g_ev_open = false;
+// ---- opt-in profiling rings ----------------------------------------------------------------------------
+// region 0: the correlation + arg-max kernel; 1: a whole ipsr_forward; 2: a whole ipsr_backward(_patch)
+constexpr int N_REGIONS = 3;
+struct EvRing {
+    hipEvent_t* ev = nullptr;      // 2*capacity events: start0, stop0, start1, ...
+    int cap = 0, n = 0;
+    bool open = false;
+};
+static EvRing g_ring[N_REGIONS];
 
-void profile_mark_start(hipStream_t st)
+void profile_mark_start(hipStream_t st, int region)
 {
-    if (g_ev_cap == 0 || g_ev_n >= g_ev_cap) return;
-    (void)hipEventRecord(g_ev[2 * g_ev_n], st);
-    g_ev_open = true;
+    EvRing& r = g_ring[region];
+    if (r.cap == 0 || r.n >= r.cap) return;
+    (void)hipEventRecord(r.ev[2 * r.n], st);
+    r.open = true;
 }
 
-void profile_mark_stop(hipStream_t st)
+void profile_mark_stop(hipStream_t st, int region)
 {
-    if (!g_ev_open) return;
-    (void)hipEventRecord(g_ev[2 * g_ev_n + 1], st);
-    g_ev_open = false;
-    ++g_ev_n;
+    EvRing& r = g_ring[region];
+    if (!r.open) return;
+    (void)hipEventRecord(r.ev[2 * r.n + 1], st);
+    r.open = false;
+    ++r.n;
 }
+
+// brackets a whole entry point (every return path)
+struct ProfileScope {
+    hipStream_t st;
+    int region;
+    ProfileScope(hipStream_t s, int r) : st(s), region(r) { profile_mark_start(st, region); }
+    ~ProfileScope() { profile_mark_stop(st, region); }
+};
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -68,7 +83,7 @@ enum { WS_XN, WS_XT, WS_INV, WS_CORR, WS_WN, WS_WO, WS_KQ, WS_JQ, WS_DLIST, WS_M
 
 // patch == 1: the feature IS the patch matrix.  patch > 1: C/N below are the unfolded K = C*p*p and the window grid
 // N' = (h-p+1)(w-p+1); three more slices hold the unfolded x, the unfolded ref and the un-folded result.
-static FwdPlan plan_forward(int B, int C, int h, int w, int M, int patch, size_t* sizes)
+static FwdPlan plan_forward(int B, int C, int h, int w, int M, int patch, size_t* sizes, bool corr_bf16 = false)
 {
     FwdPlan p;
     p.K = C * patch * patch;
@@ -81,7 +96,7 @@ static FwdPlan plan_forward(int B, int C, int h, int w, int M, int patch, size_t
     sz[WS_XN] = (size_t)B * p.K * p.ld * 4;
     sz[WS_XT] = (size_t)B * p.N * p.Cp * 4;
     sz[WS_INV] = (size_t)B * p.N * 4;
-    sz[WS_CORR] = corr_argmax_ws_bytes(B, p.K, p.N);
+    sz[WS_CORR] = corr_bf16 ? corr_argmax_bf16_ws_bytes(B, p.K, p.N, p.ld) : corr_argmax_ws_bytes(B, p.K, p.N);
     sz[WS_XU] = 0;                                        // (the unfolded x is no longer materialised)
     sz[WS_RU] = patch > 1 ? (size_t)B * p.K * p.ld * 4 : 0;
     sz[WS_OU] = patch > 1 ? (size_t)B * p.K * p.N * 4 : 0;
@@ -105,38 +120,43 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 4; }
+int ipsr_abi_version(void) { return 5; }
 
 const char* ipsr_last_error(void) { return g_err; }
 
 int ipsr_profile_enable(int capacity)
 {
-    for (int i = 0; i < 2 * g_ev_cap; ++i) (void)hipEventDestroy(g_ev[i]);
-    delete[] g_ev;
-    g_ev = nullptr;
-    g_ev_cap = g_ev_n = 0;
-    g_ev_open = false;
+    for (EvRing& r : g_ring) {
+        for (int i = 0; i < 2 * r.cap; ++i) (void)hipEventDestroy(r.ev[i]);
+        delete[] r.ev;
+        r = EvRing();
+    }
     if (capacity <= 0) return IPSR_OK;
-    g_ev = new hipEvent_t[2 * (size_t)capacity];
-    for (int i = 0; i < 2 * capacity; ++i)
-        if (hipEventCreate(&g_ev[i]) != hipSuccess) return fail(IPSR_ERR_LAUNCH, "ipsr_profile_enable: hipEventCreate failed");
-    g_ev_cap = capacity;
+    for (EvRing& r : g_ring) {
+        r.ev = new hipEvent_t[2 * (size_t)capacity];
+        for (int i = 0; i < 2 * capacity; ++i)
+            if (hipEventCreate(&r.ev[i]) != hipSuccess) return fail(IPSR_ERR_LAUNCH, "ipsr_profile_enable: hipEventCreate failed");
+        r.cap = capacity;
+    }
     return IPSR_OK;
 }
 
-int ipsr_profile_read(float* ms, int max_n)
+int ipsr_profile_read_region(int region, float* ms, int max_n)
 {
-    if (!ms || max_n < 0) return fail(IPSR_ERR_INVALID, "ipsr_profile_read: bad arguments");
+    if (!ms || max_n < 0 || region < 0 || region >= N_REGIONS) return fail(IPSR_ERR_INVALID, "ipsr_profile_read_region: bad arguments");
+    EvRing& r = g_ring[region];
     int n = 0;
-    for (int i = 0; i < g_ev_n && n < max_n; ++i) {
+    for (int i = 0; i < r.n && n < max_n; ++i) {
         float t = 0.0f;
-        if (hipEventSynchronize(g_ev[2 * i + 1]) != hipSuccess) break;
-        if (hipEventElapsedTime(&t, g_ev[2 * i], g_ev[2 * i + 1]) != hipSuccess) break;
+        if (hipEventSynchronize(r.ev[2 * i + 1]) != hipSuccess) break;
+        if (hipEventElapsedTime(&t, r.ev[2 * i], r.ev[2 * i + 1]) != hipSuccess) break;
         ms[n++] = t;
     }
-    g_ev_n = 0;
+    r.n = 0;
     return n;
 }
+
+int ipsr_profile_read(float* ms, int max_n) { return ipsr_profile_read_region(0, ms, max_n); }
 
 size_t ipsr_feat_mask_workspace_bytes(int H, int W, int layers)
 {
@@ -197,10 +217,10 @@ size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch
     return plan_forward(B, C, h, w, M, patch, nullptr).total;
 }
 
-int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
-                 int B, int C, int h, int w, int patch, int stride,
-                 float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
-                 void* ws, size_t ws_bytes, void* stream)
+static int forward_impl(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
+                        int B, int C, int h, int w, int patch, int stride,
+                        float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
+                        void* ws, size_t ws_bytes, void* stream, bool corr_bf16)
 {
     if (!x || !ref || !out || !ind || !vmax || !ws) return fail(IPSR_ERR_INVALID, "ipsr_forward: null pointer");
     if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return fail(IPSR_ERR_INVALID, "ipsr_forward: bad size B=%d C=%d h=%d w=%d M=%d", B, C, h, w, M);
@@ -212,9 +232,12 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     if (!aligned16(x) || !aligned16(ref) || !aligned16(out) || !aligned16(ws) || (attn_rows && !aligned16(attn_rows)))
         return fail(IPSR_ERR_INVALID, "ipsr_forward: x/ref/out/attn_rows/ws must be 16-byte aligned");
     size_t sz[WS_COUNT];
-    const FwdPlan p = plan_forward(B, C, h, w, M, patch, sz);
+    const FwdPlan p = plan_forward(B, C, h, w, M, patch, sz, corr_bf16);
+    if (corr_bf16 && !corr_bf16_supported(p.K, p.ld))
+        return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward_bf16corr: the bf16 correlation needs C*p*p %% 64 == 0 and N %% 128 == 0 for shift_sz = 1 (got %d, %d)", p.K, p.N);
     if (ws_bytes < p.total) return fail(IPSR_ERR_WORKSPACE, "ipsr_forward: workspace %zu < %zu", ws_bytes, p.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfileScope scope(st, 1);
 
     char* slice[WS_COUNT];
     char* base = static_cast<char*>(ws);
@@ -239,7 +262,11 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
         if (int rc = launch_patch_normalize(x, B, p.K, p.N, xn, xT, p.Cp, inv, st, p.ld, p.ld)) return rc;
     }
     AttnArgs a;
-    if (int rc = launch_corr_argmax(xn, rs, B, p.K, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
+    if (corr_bf16) {
+        if (int rc = launch_corr_argmax_bf16(xn, rs, B, p.K, p.N, ind, vmax, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
+    } else {
+        if (int rc = launch_corr_argmax(xn, rs, B, p.K, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
+    }
     a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
     a.B = B; a.C = p.K; a.Cp = p.Cp; a.N = p.N; a.M = M; a.Mc = p.Mc;
     a.wn = reinterpret_cast<float*>(slice[WS_WN]);
@@ -256,11 +283,49 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
     return IPSR_OK;
 }
 
+int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
+                 int B, int C, int h, int w, int patch, int stride,
+                 float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
+                 void* ws, size_t ws_bytes, void* stream)
+{
+    return forward_impl(x, ref, mask_point_idx, M, B, C, h, w, patch, stride, out, ind, vmax, attn_rows, bwd_index, ws, ws_bytes, stream, false);
+}
+
+size_t ipsr_forward_bf16corr_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride)
+{
+    if (B < 1 || C < 1 || patch < 1 || h < patch || w < patch || M < 0 || stride != 1) return 0;
+    return plan_forward(B, C, h, w, M, patch, nullptr, true).total;
+}
+
+int ipsr_forward_bf16corr(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
+                          int B, int C, int h, int w, int patch, int stride,
+                          float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
+                          void* ws, size_t ws_bytes, void* stream)
+{
+    return forward_impl(x, ref, mask_point_idx, M, B, C, h, w, patch, stride, out, ind, vmax, attn_rows, bwd_index, ws, ws_bytes, stream, true);
+}
+
+size_t ipsr_corr_argmax_bf16_workspace_bytes(int B, int C, int N)
+{
+    if (B < 1 || C < 1 || N < 1) return 0;
+    return corr_argmax_bf16_ws_bytes(B, C, N);
+}
+
+int ipsr_corr_argmax_bf16(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
+                          void* ws, size_t ws_bytes, void* stream)
+{
+    if (!xn || !ref || !ind || !vmax || !ws) return fail(IPSR_ERR_INVALID, "ipsr_corr_argmax_bf16: null pointer");
+    if (B < 1 || C < 1 || N < 1) return fail(IPSR_ERR_INVALID, "ipsr_corr_argmax_bf16: bad size B=%d C=%d N=%d", B, C, N);
+    if (!aligned16(xn) || !aligned16(ref) || !aligned16(ws)) return fail(IPSR_ERR_INVALID, "ipsr_corr_argmax_bf16: xn/ref/ws must be 16-byte aligned");
+    return launch_corr_argmax_bf16(xn, ref, B, C, N, ind, vmax, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
 int ipsr_backward(const float* grad_out, const int32_t* mask_point_idx, int M, const float* attn_rows,
                   const int32_t* bwd_index, float triple_w, int B, int C, int h, int w, float* grad_in, void* stream)
 {
     if (!grad_out || !grad_in || !bwd_index) return fail(IPSR_ERR_INVALID, "ipsr_backward: null pointer");
     if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return fail(IPSR_ERR_INVALID, "ipsr_backward: bad size");
+    ProfileScope scope(static_cast<hipStream_t>(stream), 2);
     return launch_backward(grad_out, mask_point_idx, M, attn_rows, bwd_index, triple_w, B, C, h * w, grad_in, static_cast<hipStream_t>(stream));
 }
 
@@ -278,6 +343,7 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
     if (!grad_out || !grad_in || !bwd_index) return fail(IPSR_ERR_INVALID, "ipsr_backward_patch: null pointer");
     if (B < 1 || C < 1 || patch < 1 || h < patch || w < patch || M < 0) return fail(IPSR_ERR_INVALID, "ipsr_backward_patch: bad size");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfileScope scope(st, 2);
     if (patch == 1) return launch_backward(grad_out, nullptr, M, nullptr, bwd_index, triple_w, B, C, h * w, grad_in, st);
     const size_t need = ipsr_backward_workspace_bytes(B, C, h, w, patch);
     if (!ws || ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "ipsr_backward_patch: workspace %zu < %zu", ws_bytes, need);

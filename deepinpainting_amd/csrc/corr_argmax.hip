@@ -77,11 +77,13 @@ corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, 
     const int ld_row = tid >> 5;          // 0..7  (+8 for the second)
     const int ld_c4 = (tid & 31) * 4;     // column offset in floats
 
-    float best[2] = {-INFINITY, -INFINITY};
-    int bidx[2] = {0x7fffffff, 0x7fffffff};
-
     const int nstage = (C + BK - 1) / BK;
     const int kt_lo = ks * kt_per_wg, kt_hi = min(ktiles, kt_lo + kt_per_wg);
+    // start from the first row this lane will see (always < N: row 4h of a tile that exists), value -inf: a column whose
+    // correlations are all -inf (or that this lane never beats) still reports an in-range index
+    float best[2] = {-INFINITY, -INFINITY};
+    int bidx[2] = {kt_lo * BM + wm * 64 + 4 * h, kt_lo * BM + wm * 64 + 4 * h};
+    if (bidx[0] >= N) bidx[0] = bidx[1] = kt_lo * BM;
 
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         const int k0 = kt * BM;
@@ -156,7 +158,7 @@ corr_argmax_kernel(const float* __restrict__ xn, const float* __restrict__ ref, 
                     const int k = k0 + wm * 64 + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     const float v = acc[im][jn][e];
                     if (FAST || k < N) {
-                        if (v > best[jn]) { best[jn] = v; bidx[jn] = k; }
+                        if (takes_over(v, best[jn])) { best[jn] = v; bidx[jn] = k; }
                         if (WRITE_S) { if (FAST || q < N) S_out[((size_t)b * N + k) * N + q] = v; }
                     }
                 }
@@ -238,11 +240,12 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
     const float* A = xn + (size_t)b * C * ld;
     const float* R = ref + (size_t)b * C * ld;
 
-    float best[2] = {-INFINITY, -INFINITY};
-    int bidx[2] = {0x7fffffff, 0x7fffffff};
-
     const int nstage = C / FBK;
     const int kt_lo = ks * kt_per_wg, kt_hi = min(ktiles, kt_lo + kt_per_wg);
+    // start from the first row this lane will see, value -inf (see the generic kernel)
+    float best[2] = {-INFINITY, -INFINITY};
+    int bidx[2] = {kt_lo * BM + wm * 32 + 4 * h, kt_lo * BM + wm * 32 + 4 * h};
+    if (RAGGED && bidx[0] >= N) bidx[0] = bidx[1] = kt_lo * BM;
 
     // LDS-DMA: a stage = 2 operands x FBK rows x 512 B = 2*FBK/2 = 16 pieces of 1 KiB (2 rows); wave w owns row
     // pairs w and w+4 of A and of B -> NP = 4 pieces per wave per stage.  Lane -> (row parity, 16-byte column).
@@ -335,7 +338,7 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
                     const int k = k0 + wm * 32 + im * 64 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     const float v = acc[im][jn][e];
                     if (!RAGGED || k < N) {
-                        if (v > best[jn]) { best[jn] = v; bidx[jn] = k; }
+                        if (takes_over(v, best[jn])) { best[jn] = v; bidx[jn] = k; }
                         if (WRITE_S) { if (!RAGGED || q < N) S_out[((size_t)b * N + k) * N + q] = v; }
                     }
                 }
@@ -368,6 +371,143 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
             const int oi = red_i[(wn * 2 + jn) * 32 + r];
             if (better(ov, oi, best[jn], bidx[jn])) { best[jn] = ov; bidx[jn] = oi; }
             const int q = q0 + wn * 32 + jn * 64 + r;
+            if (!RAGGED || q < N) {
+                pval[((size_t)b * ksplit + ks) * N + q] = best[jn];
+                pidx[((size_t)b * ksplit + ks) * N + q] = bidx[jn];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 variant (BASELINE config 5: "CDNA4 bf16 MFMA for patch-corr"): the same contraction, arg-max and k-split merge
+// on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate).  Opt-in only (ipsr_forward_bf16corr /
+// ipsr_corr_argmax_bf16): the operands are ROUNDED to bf16, so an arg-max can move where the two best patches are
+// closer than the rounding error — the measured agreement with the fp32 kernel is reported by bench.py and asserted in
+// tests/test_gpu_parity.py; the fp32 kernel stays the default and the only one the parity contract is stated on.
+//
+// Operand layout.  The instruction wants, per lane, 8 CONSECUTIVE reduction elements of one row (A[i][8g..8g+7],
+// lane = i + 32g).  Channel-major [C][N] has them N apart, so both operands are first re-packed (pack_bf16_k8_kernel)
+// into [C/8][ld][8] bf16: the 8 channels of a group interleaved per position.  A lane's fragment is then ONE 16-byte
+// load, a half-wave reads 512 contiguous bytes, and the data is half the size of the fp32 operands.
+//
+// The MFMA part is 16x shorter than in fp32 (C=512: 128 instructions of 32 cycles per 128x128 tile and wave), so the
+// kernel is bound by operand delivery, not by the matrix pipe.  It therefore skips LDS altogether: every wave streams
+// its own A and B fragments from L2 straight into registers through a PF-deep software pipeline (no barrier, no LDS
+// image, no DMA bookkeeping); the 2x re-read of a tile by the two waves that share it is served by L1/L2.
+constexpr int PF = 4;     // k-steps (16 channels each) of fragment loads in flight per wave
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ void __launch_bounds__(256) pack_bf16_k8_kernel(const float* __restrict__ src, int C, int ld, int C8, uint4* __restrict__ dst)
+{
+    // one thread per (channel group, position): 8 strided fp32 reads (coalesced across positions), one 16-byte store
+    const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, b = blockIdx.z;
+    if (n >= ld) return;
+    const float* s = src + ((size_t)b * C + (size_t)g * 8) * ld + n;
+    unsigned short h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = (g * 8 + e < C) ? s[(size_t)e * ld] : 0.0f;
+        h[e] = __builtin_bit_cast(unsigned short, (__bf16)v);          // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    }
+    uint4 o;
+    o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
+    o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+    dst[((size_t)b * C8 + g) * ld + n] = o;
+}
+
+template <bool RAGGED>
+__global__ void __launch_bounds__(NTHREADS, 2)
+corr_argmax_bf16_kernel(const uint4* __restrict__ xnp, const uint4* __restrict__ refp, int C8, int N, int ld,
+                        int qtiles, int ksplit, int ktiles, int kt_per_wg, float* __restrict__ pval, int32_t* __restrict__ pidx)
+{
+    __shared__ float red_v[2 * 2 * 32];
+    __shared__ int red_i[2 * 2 * 32];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = L % ksplit;
+    const int qt = (L / ksplit) % qtiles;
+    const int b = L / (ksplit * qtiles);
+    const int q0 = qt * BN;
+
+    const uint4* A = xnp + (size_t)b * C8 * ld;
+    const uint4* R = refp + (size_t)b * C8 * ld;
+    const int nks = C8 / 2;                                  // k-steps of 16 channels; a multiple of PF (host-checked)
+    const int kt_lo = ks * kt_per_wg, kt_hi = min(ktiles, kt_lo + kt_per_wg);
+    float best[2] = {-INFINITY, -INFINITY};
+    int bidx[2] = {kt_lo * BM + wm * 64 + 4 * h, kt_lo * BM + wm * 64 + 4 * h};
+    if (RAGGED && bidx[0] >= N) bidx[0] = bidx[1] = kt_lo * BM;
+
+    // B fragments do not depend on the k-tile: positions q0 + wn*64 + {0,32} + r, channel group 2s + h
+    const uint4* rb = R + (size_t)h * ld + q0 + wn * 64 + r;
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int k0 = kt * BM;
+        const uint4* ra = A + (size_t)h * ld + k0 + wm * 64 + r;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        uint4 fa[PF][2], fb[PF][2];
+        auto load = [&](int d, int s) {
+            const size_t o = (size_t)2 * s * ld;
+            fa[d][0] = ra[o]; fa[d][1] = ra[o + 32];
+            fb[d][0] = rb[o]; fb[d][1] = rb[o + 32];
+        };
+#pragma unroll
+        for (int d = 0; d < PF; ++d) load(d, d);
+        for (int s0 = 0; s0 < nks; s0 += PF) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[d][0]), a1 = __builtin_bit_cast(bf16x8, fa[d][1]);
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[d][0]), b1 = __builtin_bit_cast(bf16x8, fb[d][1]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+                load(d, min(s0 + d + PF, nks - 1));          // branch-free refill (the tail re-reads the last step, unused)
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+            for (int im = 0; im < 2; ++im) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = k0 + wm * 64 + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = acc[im][jn][e];
+                    if (!RAGGED || k < N) {
+                        if (takes_over(v, best[jn])) { best[jn] = v; bidx[jn] = k; }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const float ov = __shfl_xor(best[jn], 32);
+        const int oi = __shfl_xor(bidx[jn], 32);
+        if (better(ov, oi, best[jn], bidx[jn])) { best[jn] = ov; bidx[jn] = oi; }
+    }
+    if (wm == 1 && h == 0) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) { red_v[(wn * 2 + jn) * 32 + r] = best[jn]; red_i[(wn * 2 + jn) * 32 + r] = bidx[jn]; }
+    }
+    __syncthreads();
+    if (wm == 0 && h == 0) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const float ov = red_v[(wn * 2 + jn) * 32 + r];
+            const int oi = red_i[(wn * 2 + jn) * 32 + r];
+            if (better(ov, oi, best[jn], bidx[jn])) { best[jn] = ov; bidx[jn] = oi; }
+            const int q = q0 + wn * 64 + jn * 32 + r;
             if (!RAGGED || q < N) {
                 pval[((size_t)b * ksplit + ks) * N + q] = best[jn];
                 pidx[((size_t)b * ksplit + ks) * N + q] = bidx[jn];
@@ -417,6 +557,17 @@ static void plan(int B, int N, int* qtiles, int* ktiles, int* ksplit, int* kt_pe
     *ksplit = cdiv(*ktiles, best);
 }
 
+// bf16 path: the packed operands ([C/8][ld][8] bf16 each) live in the workspace behind the partials
+static size_t bf16_pack_bytes(int B, int C, int ld) { return align_up((size_t)B * ((C + 7) / 8) * ld * 16, 256); }
+
+bool corr_bf16_supported(int C, int ld) { return C % (16 * PF) == 0 && ld % BM == 0; }
+
+size_t corr_argmax_bf16_ws_bytes(int B, int C, int N, int ld)
+{
+    if (ld <= 0) ld = N;
+    return corr_argmax_ws_bytes(B, C, N) + 2 * bf16_pack_bytes(B, C, ld);
+}
+
 size_t corr_argmax_ws_bytes(int B, int C, int N)
 {
     (void)C;
@@ -453,6 +604,45 @@ int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, i
     }
     profile_mark_stop(st);
     if (int rc = check_launch("corr_argmax_kernel")) return rc;
+    if (partials) {
+        partials->pval = pval;
+        partials->pidx = pidx;
+        partials->ksplit = ks;
+        return IPSR_OK;
+    }
+    argmax_merge_kernel<<<cdiv(B * N, 256), 256, 0, st>>>(pval, pidx, B, N, ks, ind, vmax);
+    return check_launch("argmax_merge_kernel");
+}
+
+// bf16 MFMA variant of launch_corr_argmax: xn / ref are the SAME fp32 operands; they are packed to bf16 here.
+int launch_corr_argmax_bf16(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
+                            void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials, int ld)
+{
+    if (ld <= 0) ld = N;
+    if (!corr_bf16_supported(C, ld))
+        return fail(IPSR_ERR_UNSUPPORTED, "bf16 correlation: needs C %% %d == 0 and a row stride that is a multiple of %d (got C=%d, ld=%d)",
+                    16 * PF, BM, C, ld);
+    int qt, kt, ks, kpw;
+    plan(B, N, &qt, &kt, &ks, &kpw);
+    if (ld < qt * BN) return fail(IPSR_ERR_UNSUPPORTED, "bf16 correlation: row stride %d < %d", ld, qt * BN);
+    if (ws_bytes < corr_argmax_bf16_ws_bytes(B, C, N, ld))
+        return fail(IPSR_ERR_WORKSPACE, "ipsr_corr_argmax_bf16: workspace %zu < %zu", ws_bytes, corr_argmax_bf16_ws_bytes(B, C, N, ld));
+    Carver cv(ws, ws_bytes);
+    float* pval = cv.take<float>((size_t)B * ks * N);
+    int32_t* pidx = cv.take<int32_t>((size_t)B * ks * N);
+    const int C8 = C / 8;
+    uint4* xp = cv.take<uint4>((size_t)B * C8 * ld);
+    uint4* rp = cv.take<uint4>((size_t)B * C8 * ld);
+    const dim3 pg(cdiv(ld, 256), C8, B);
+    pack_bf16_k8_kernel<<<pg, 256, 0, st>>>(xn, C, ld, C8, xp);
+    pack_bf16_k8_kernel<<<pg, 256, 0, st>>>(ref, C, ld, C8, rp);
+    if (int rc = check_launch("pack_bf16_k8_kernel")) return rc;
+    const int grid = B * qt * ks;
+    profile_mark_start(st);
+    if (ld == N) corr_argmax_bf16_kernel<false><<<grid, NTHREADS, 0, st>>>(xp, rp, C8, N, ld, qt, ks, kt, kpw, pval, pidx);
+    else corr_argmax_bf16_kernel<true><<<grid, NTHREADS, 0, st>>>(xp, rp, C8, N, ld, qt, ks, kt, kpw, pval, pidx);
+    profile_mark_stop(st);
+    if (int rc = check_launch("corr_argmax_bf16_kernel")) return rc;
     if (partials) {
         partials->pval = pval;
         partials->pidx = pidx;

@@ -33,8 +33,9 @@ __device__ __forceinline__ float block_sum(float v, float* red)
 
 __device__ __forceinline__ float act_fwd(float v, int act, float slope)
 {
-    if (act == 1) return v > 0.0f ? v : 0.0f;
-    if (act == 2) return v > 0.0f ? v : v * slope;
+    // NaN-propagating like torch's relu / leaky_relu (a diverged net must show, not read as 0)
+    if (act == 1) return v < 0.0f ? 0.0f : v;
+    if (act == 2) return v < 0.0f ? v * slope : v;
     return v;
 }
 // derivative from the OUTPUT (slope > 0 keeps the sign, ReLU maps negatives to 0)

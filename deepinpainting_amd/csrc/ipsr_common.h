@@ -15,8 +15,8 @@ int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
 
 // opt-in event bracketing of the dominant kernel (see ipsr_profile_enable in ipsr_hip.h)
-void profile_mark_start(hipStream_t st);
-void profile_mark_stop(hipStream_t st);
+void profile_mark_start(hipStream_t st, int region = 0);
+void profile_mark_stop(hipStream_t st, int region = 0);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -55,10 +55,16 @@ struct CorrPartials {
     int ksplit;
 };
 
+// Total order of (value, patch index) candidates, torch.max semantics (util/MaxCoord.py:23): the larger value wins, a NaN
+// counts as larger than every number, equal values (or two NaNs) resolve to the lower index.  Total = the arg-max is an
+// in-range index for EVERY input (all -inf, all NaN ...), never the 0x7fffffff start value.
 __device__ __forceinline__ bool better(float v1, int i1, float v0, int i0)
 {
-    return (v1 > v0) || (v1 == v0 && i1 < i0);
+    const bool n1 = v1 != v1, n0 = v0 != v0;
+    return (v1 > v0) || (n1 && !n0) || ((v1 == v0 || (n1 && n0)) && i1 < i0);
 }
+// running form for candidates visited in ASCENDING index: only a strictly better value replaces (first max / first NaN wins)
+__device__ __forceinline__ bool takes_over(float v, float best) { return (v > best) || (v != v && best == best); }
 
 // arg-max over k of column q of sample b: fold the k-split partials in ascending k (lowest k on ties)
 __device__ __forceinline__ void merged_argmax(const CorrPartials& cp, int b, int N, int q, float& v, int& i)
@@ -71,6 +77,7 @@ __device__ __forceinline__ void merged_argmax(const CorrPartials& cp, int b, int
         const int is = cp.pidx[base + (size_t)s * N];
         if (better(vs, is, v, i)) { v = vs; i = is; }
     }
+    i = min(max(i, 0), N - 1);      // consumers index patch rows and LDS with it: in range whatever the correlation produced
 }
 
 // I/O element types: fp32, or bf16 (BASELINE config 5: activations under bf16 autocast) with all arithmetic in fp32.
@@ -134,6 +141,12 @@ size_t corr_argmax_ws_bytes(int B, int C, int N);
 // consumer that merges them: the attention stage kernel)
 int launch_corr_argmax(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
                        float* S_out, void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials = nullptr, int ld = 0);
+
+// bf16-MFMA variant (opt-in): same fp32 operands, packed to bf16 inside; needs corr_bf16_supported(C, ld)
+bool corr_bf16_supported(int C, int ld);
+size_t corr_argmax_bf16_ws_bytes(int B, int C, int N, int ld = 0);
+int launch_corr_argmax_bf16(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
+                            void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials = nullptr, int ld = 0);
 
 struct AttnArgs {
     const float* xT;       // [B,N,Cp] patch-major raw copy, zero padded to Cp = roundup(C,8)

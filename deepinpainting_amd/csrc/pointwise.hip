@@ -12,11 +12,15 @@
 
 namespace ipsr {
 
+// torch semantics: relu and max_pool2d propagate NaN (fmaxf would swallow it)
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.0f ? 0.0f : v; }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a > b || a != a) ? a : b; }
+
 template <int ACT>   // 0 none, 1 relu, 2 leaky relu
 __device__ __forceinline__ float act_apply(float v, float slope)
 {
-    if (ACT == 1) return v > 0.0f ? v : 0.0f;
-    if (ACT == 2) return v > 0.0f ? v : v * slope;
+    if (ACT == 1) return v < 0.0f ? 0.0f : v;             // NaN stays NaN, as in torch
+    if (ACT == 2) return v < 0.0f ? v * slope : v;
     return v;
 }
 
@@ -57,19 +61,19 @@ __global__ void __launch_bounds__(256) bias_relu_pool2_kernel(const IO* __restri
             const float4 a = ld4(p + (size_t)(2 * i) * W, jp);
             const float4 b = ld4(p + (size_t)(2 * i + 1) * W, jp);
             // relu(v + bias) per element, then the window max in torch's order (row-major over the window)
-            const float a0 = fmaxf(a.x + bv, 0.0f), a1 = fmaxf(a.y + bv, 0.0f), a2 = fmaxf(a.z + bv, 0.0f), a3 = fmaxf(a.w + bv, 0.0f);
-            const float b0 = fmaxf(b.x + bv, 0.0f), b1 = fmaxf(b.y + bv, 0.0f), b2 = fmaxf(b.z + bv, 0.0f), b3 = fmaxf(b.w + bv, 0.0f);
-            st1(q, (size_t)i * Wo + 2 * jp, fmaxf(fmaxf(a0, a1), fmaxf(b0, b1)));
-            st1(q, (size_t)i * Wo + 2 * jp + 1, fmaxf(fmaxf(a2, a3), fmaxf(b2, b3)));
+            const float a0 = relu_nan(a.x + bv), a1 = relu_nan(a.y + bv), a2 = relu_nan(a.z + bv), a3 = relu_nan(a.w + bv);
+            const float b0 = relu_nan(b.x + bv), b1 = relu_nan(b.y + bv), b2 = relu_nan(b.z + bv), b3 = relu_nan(b.w + bv);
+            st1(q, (size_t)i * Wo + 2 * jp, max_nan(max_nan(a0, a1), max_nan(b0, b1)));
+            st1(q, (size_t)i * Wo + 2 * jp + 1, max_nan(max_nan(a2, a3), max_nan(b2, b3)));
         }
     } else {
         const int n = Ho * Wo;
         for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
             const int i = t / Wo, j = t - i * Wo;
             const size_t r0 = (size_t)(2 * i) * W + 2 * j, r1 = r0 + W;
-            const float v0 = fmaxf(ld1(p, r0) + bv, 0.0f), v1 = fmaxf(ld1(p, r0 + 1) + bv, 0.0f);
-            const float v2 = fmaxf(ld1(p, r1) + bv, 0.0f), v3 = fmaxf(ld1(p, r1 + 1) + bv, 0.0f);
-            st1(q, t, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+            const float v0 = relu_nan(ld1(p, r0) + bv), v1 = relu_nan(ld1(p, r0 + 1) + bv);
+            const float v2 = relu_nan(ld1(p, r1) + bv), v3 = relu_nan(ld1(p, r1 + 1) + bv);
+            st1(q, t, max_nan(max_nan(v0, v1), max_nan(v2, v3)));
         }
     }
 }
@@ -91,12 +95,12 @@ __global__ void __launch_bounds__(256) cat_relu_fwd_kernel(const IO* __restrict_
         const size_t n4 = n >> 2, n14 = n1 >> 2;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
             float4 v = i < n14 ? ld4(yb, i) : ld4(xb, i - n14);
-            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
             st4(ob, i, v);
         }
     } else {
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-            st1(ob, i, fmaxf(i < n1 ? ld1(yb, i) : ld1(xb, i - n1), 0.0f));
+            st1(ob, i, relu_nan(i < n1 ? ld1(yb, i) : ld1(xb, i - n1)));
     }
 }
 

@@ -15,6 +15,18 @@ Design for the MI355X node (8 GPUs, full xGMI mesh, 7 links x ~153 GB/s per GPU)
   * the 1/world scaling is applied to the bucket before its collective (under the backward); `finish()` only waits and
     points every .grad at its slice of the reduced bucket (no copy back).
 Works with any torch.distributed backend ("nccl" == RCCL on ROCm; "gloo" for the CPU tests).
+
+RCCL algorithm / protocol.  An MI355X node is a full mesh of point-to-point xGMI links (7 x ~153 GB/s per GPU), not a
+switch: a ring all-reduce moves every byte over ONE link per hop and is bound by that single link, while the
+mesh-aware forms (RCCL's direct reduce-scatter + all-gather, one chunk per peer over all 7 links at once) use the whole
+fabric.  RCCL picks per message size; `init_distributed(..., rccl_algo=..., rccl_proto=..., rccl_channels=...)` (bench.py:
+`--rccl-algo`, `--rccl-proto`, `--rccl-min-channels`) pins the choice through NCCL_ALGO / NCCL_PROTO /
+NCCL_MIN_NCHANNELS before the communicator is created — they are read once, at creation.  Intended setting for the
+64 MiB gradient buckets on the 8-GPU mesh: leave NCCL_ALGO unset (RCCL's tuner already prefers its direct/mesh kernels
+intra-node), NCCL_PROTO=Simple (the LL protocols halve payload per flit and only pay off below ~1 MiB), and
+NCCL_MIN_NCHANNELS >= 28 (4 channels per link) so that every link carries traffic.  None of this has been measured on
+an 8-GPU node by this repo (the builder has one GPU; the driver runs the scaling bench) — the knobs exist so that the
+measurement can be made without code changes.
 """
 import os
 
@@ -22,9 +34,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, rccl_algo=None, rccl_proto=None, rccl_channels=None):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK /
-    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank); a no-op for single-process runs."""
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank); a no-op for single-process runs.
+    rccl_algo / rccl_proto / rccl_channels: see the module docstring (explicit environment settings win)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -33,6 +46,10 @@ def init_distributed(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # this pool's driver only supports dmabuf IPC
+            for var, val in (("NCCL_ALGO", rccl_algo), ("NCCL_PROTO", rccl_proto), ("NCCL_MIN_NCHANNELS", rccl_channels)):
+                if val not in (None, ""):
+                    os.environ.setdefault(var, str(val))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
@@ -91,17 +108,29 @@ class GradBucketReducer(object):
         """Call right before the backward whose gradients should be exchanged."""
         self.armed = self.world > 1
         self._pending = [len(b["params"]) for b in self.buckets]
+        self._seen = set()
+        self._launched = set()
         self._work = []
 
     def _on_grad(self, p):
         if not self.armed:
             return
         bi = self._bucket_of[p]
+        if bi in self._launched:
+            # the bucket already went out with this parameter's gradient in it: a second accumulation (two backward passes
+            # through the same parameter while armed, e.g. an extra InnerCos.backward(retain_graph=True)) would be lost
+            raise RuntimeError("GradBucketReducer: a gradient arrived for a bucket that is already being all-reduced — "
+                               "run every backward of the exchanged nets between ONE arm() / finish() pair, or arm() again")
+        if id(p) in self._seen:          # accumulated twice before its bucket was complete: counted once
+            return
+        self._seen.add(id(p))
         self._pending[bi] -= 1
+        assert self._pending[bi] >= 0
         if self._pending[bi] == 0:
             self._launch(bi)
 
     def _launch(self, bi):
+        self._launched.add(bi)
         b = self.buckets[bi]
         dev = b["params"][0].device
         if b["flat"] is None or b["flat"].device != dev:
@@ -112,8 +141,18 @@ class GradBucketReducer(object):
             n = p.numel()
             views.append(flat[off:off + n].view_as(p))
             off += n
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b["params"]]
-        torch._foreach_copy_(views, grads)
+        # a parameter whose gradient already LIVES in its bucket slice (a kernel that wrote it there, or .grad left as
+        # the view by the previous finish() and accumulated in place) needs no copy; a parameter without a gradient on
+        # this rank contributes zeros (another rank may have one: every rank must issue the same collective)
+        src, dst = [], []
+        for p, v in zip(b["params"], views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
         flat.mul_(1.0 / self.world)          # the mean's scaling happens here, under the backward, not after the wait
         self._work.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), views))
 
@@ -131,6 +170,9 @@ class GradBucketReducer(object):
             work.wait()
             # the rank-averaged gradients stay where the collective left them: .grad becomes a view of the bucket (no copy
             # back).  The bucket is rewritten only by the next armed backward, after the optimizer has consumed these.
+            # NB a parameter that had no gradient on ANY rank ends up with a zero gradient (not None): Adam then still
+            # applies its momentum to it, where a single-process run would skip it.  No parameter of the four nets is
+            # ever without a gradient in optimize_parameters(), so the trainer is unaffected.
             for p, v in zip(self.buckets[bi]["params"], views):
                 p.grad = v
         self._work = []

@@ -24,6 +24,7 @@ What is new (none of it changes results):
   * data parallelism: with torch.distributed initialised (one process per GPU, RCCL) the gradients are
     bucket-all-reduced by deepinpainting_amd.dist.GradBucketReducer, overlapped with the backward.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -50,8 +51,22 @@ class IPSR(BaseModel):
         # conv-bias + InstanceNorm + activation in one HIP kernel each way (models/fused.py); False = plain torch modules
         networks.FusedSequential.enabled = bool(getattr(opt, 'fused_norm_act', True))
 
-        self.vgg = Vgg16(requires_grad=False, weights_path=getattr(opt, 'vgg16_weights', None)).to(self.device)
+        # The reference always runs ImageNet-pretrained VGG16 features (models/vgg16.py:9 downloads them).  There is no
+        # network here, so the weights come from a local file (opt.vgg16_weights / IPSR_VGG16_WEIGHTS); a seeded-random
+        # VGG — patch matching, both InnerCos targets and netF would all run on random features — is only built when the
+        # caller says so explicitly (opt.allow_random_vgg, or IPSR_ALLOW_RANDOM_VGG=1: bench.py and the tests do).
+        weights = getattr(opt, 'vgg16_weights', None) or os.environ.get('IPSR_VGG16_WEIGHTS')
+        allow_random = bool(getattr(opt, 'allow_random_vgg', False)) or os.environ.get('IPSR_ALLOW_RANDOM_VGG', '0') == '1'
+        if not weights and not allow_random:
+            raise RuntimeError(
+                "IPSR: no VGG16 weights given.  The reference uses torchvision's ImageNet-pretrained vgg16 "
+                "(models/vgg16.py:9); pass a local copy of that state_dict as opt.vgg16_weights or IPSR_VGG16_WEIGHTS=/path/to/vgg16.pth. "
+                "For synthetic benchmarks / tests set opt.allow_random_vgg = True (or IPSR_ALLOW_RANDOM_VGG=1) to build a "
+                "seeded-random VGG16 instead.")
+        self.vgg = Vgg16(requires_grad=False, weights_path=weights).to(self.device)
         self.vgg.eval()
+        if not self.vgg.pretrained and not getattr(opt, 'quiet', False):
+            print('WARNING: VGG16 feature extractor is seeded-random (allow_random_vgg) — not the pretrained net the reference uses')
 
         fs = opt.fineSize
         self.input_A = self.Tensor(opt.batchSize, opt.input_nc, fs, fs)
@@ -72,6 +87,9 @@ class IPSR(BaseModel):
         self.netP, _, _, _ = networks.define_G(
             opt.input_nc, opt.output_nc, opt.ngf, opt.which_model_netP, opt, self.mask_global, opt.norm,
             opt.use_dropout, opt.init_type, self.gpu_ids, opt.init_gain)
+        # BASELINE config 5 names "bf16 MFMA for patch-corr + convs": with amp_bf16 the layer's correlation runs on the bf16
+        # MFMA kernel too (opt.bf16_corr = False keeps it fp32); every other part of the layer stays fp32
+        self.CSA_model[0].corr_bf16 = self.amp_bf16 and bool(getattr(opt, 'bf16_corr', True)) and self.device.type == 'cuda'
         if self.isTrain:
             use_sigmoid = opt.gan_type == 'vanilla'
             self.netD = networks.define_D(opt.input_nc, opt.ndf, opt.which_model_netD, opt.n_layers_D, opt.norm,

@@ -33,6 +33,7 @@ class IPSR_model(nn.Module):
         self.mask_thred = mask_thred
         self.triple_weight = triple_weight
         self.cal_fixed_flag = True      # reference name; True = index tensors must be (re)computed
+        self.corr_bf16 = False          # opt-in (BASELINE config 5): correlation on the bf16 MFMA kernel; fp32 = the reference
         self.sp_x = None
         self.sp_y = None
         self.mask = None
@@ -93,6 +94,13 @@ class IPSR_model(nn.Module):
         return torch.cat(outs, 0)
 
     def forward(self, input):
+        if self.corr_bf16 and input.is_cuda:
+            from .. import ops
+            with ops.corr_precision("bf16"):
+                return self._forward(input)
+        return self._forward(input)
+
+    def _forward(self, input):
         _, self.c, self.h, self.w = input.size()
         if self.mask is not None and self.mask.dim() == 3:
             return self._forward_per_sample(input)

@@ -48,7 +48,7 @@ class BaseModel():
         torch.save(cpu_state, self._checkpoint_path(network_label, epoch_label))
 
     def load_network(self, network, network_label, epoch_label):
-        state = torch.load(self._checkpoint_path(network_label, epoch_label), map_location=self.device)
+        state = torch.load(self._checkpoint_path(network_label, epoch_label), map_location=self.device, weights_only=True)
         network.load_state_dict(state)
 
     def update_learning_rate(self):

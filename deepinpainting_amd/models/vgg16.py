@@ -46,7 +46,7 @@ class Vgg16(torch.nn.Module):
             setattr(self, 'slice%d' % si, seq)
         weights_path = weights_path or os.environ.get('IPSR_VGG16_WEIGHTS')
         if weights_path:
-            self.load_torchvision_state_dict(torch.load(weights_path, map_location='cpu'))
+            self.load_torchvision_state_dict(torch.load(weights_path, map_location='cpu', weights_only=True))
             self.pretrained = True
         else:
             gen = torch.Generator().manual_seed(seed)

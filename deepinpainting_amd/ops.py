@@ -3,6 +3,8 @@
 torch is used here for device memory and streams only; every computation is a HIP kernel of
 libipsr_hip.so.  All functions require CUDA(HIP) tensors and raise otherwise — no fallback.
 """
+import contextlib
+import threading
 from collections import namedtuple
 
 import torch
@@ -88,13 +90,24 @@ def patch_normalize(x_bcn):
     return xn, inv
 
 
-def corr_argmax(xn_bcn, ref_bcn, want_S=False):
-    """K4+K5.  -> (ind [B,N] i32, vmax [B,N], S [B,N,N] or None)."""
+def corr_argmax(xn_bcn, ref_bcn, want_S=False, corr="fp32"):
+    """K4+K5.  -> (ind [B,N] i32, vmax [B,N], S [B,N,N] or None).
+    corr="bf16": the opt-in bf16-MFMA kernel (operands rounded to bf16, fp32 accumulate); S is not available there."""
     xn = _req(xn_bcn, torch.float32, "xn")
     ref = _req(ref_bcn, torch.float32, "ref")
     B, C, N = xn.shape
     ind = torch.empty((B, N), dtype=torch.int32, device=xn.device)
     vmax = torch.empty((B, N), dtype=torch.float32, device=xn.device)
+    if corr == "bf16":
+        if want_S:
+            raise ValueError("corr_argmax: the bf16 kernel does not materialise S")
+        L = _lib.lib()
+        ws = _workspace(L.ipsr_corr_argmax_bf16_workspace_bytes(B, C, N), xn.device)
+        _lib.check(L.ipsr_corr_argmax_bf16(xn.data_ptr(), ref.data_ptr(), B, C, N, ind.data_ptr(), vmax.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _stream()), "ipsr_corr_argmax_bf16")
+        return ind, vmax, None
+    if corr != "fp32":
+        raise ValueError("corr must be 'fp32' or 'bf16'")
     S = torch.empty((B, N, N), dtype=torch.float32, device=xn.device) if want_S else None
     L = _lib.lib()
     ws = _workspace(L.ipsr_corr_argmax_workspace_bytes(B, C, N), xn.device)
@@ -107,11 +120,35 @@ def corr_argmax(xn_bcn, ref_bcn, want_S=False):
 Forward = namedtuple("Forward", ["out", "ind", "vmax", "attn_rows", "bwd_index"])
 
 
-def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want_index=True):
+_precision = threading.local()
+
+
+@contextlib.contextmanager
+def corr_precision(corr):
+    """`with ops.corr_precision("bf16"):` — layer forwards issued by this thread inside the block run their correlation on
+    the bf16 MFMA kernel (BASELINE config 5).  The autograd surface IPSRFunction.apply has the reference's fixed 12
+    arguments, so the choice travels this way (IPSR_model sets it from its `corr_bf16` attribute)."""
+    if corr not in ("fp32", "bf16"):
+        raise ValueError("corr must be 'fp32' or 'bf16'")
+    prev = getattr(_precision, "corr", "fp32")
+    _precision.corr = corr
+    try:
+        yield
+    finally:
+        _precision.corr = prev
+
+
+def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want_index=True, corr=None):
     """Whole layer forward.  x, ref [B,C,h,w] fp32; mask_point_idx_i32 [M] i32 -> Forward.
     want_attn:  also materialise the dense attention rows [B,M,N] (the reference's `in_attention`; tests and
                 inspection only — the layer itself works on the compressed form);
-    want_index: build the sparse trunc(kbar) the backward needs (skip under no_grad)."""
+    want_index: build the sparse trunc(kbar) the backward needs (skip under no_grad);
+    corr:       "fp32" (the reference's arithmetic, default) or "bf16" (opt-in bf16-MFMA correlation); None = what the
+                enclosing `corr_precision` block says."""
+    if corr is None:
+        corr = getattr(_precision, "corr", "fp32")
+    if corr not in ("fp32", "bf16"):
+        raise ValueError("corr must be 'fp32' or 'bf16'")
     x = _req(x, torch.float32, "input")
     ref = _req(ref, torch.float32, "ref.relu4_3")
     B, C, h, w = x.shape
@@ -131,13 +168,15 @@ def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want
     vmax = torch.empty((B, N), dtype=torch.float32, device=dev)
     attn = torch.empty((B, M, N), dtype=torch.float32, device=dev) if (want_attn and M > 0) else None
     bidx = torch.empty((B, L.ipsr_bwd_index_ints(N, M)), dtype=torch.int32, device=dev) if want_index else None
-    nbytes = L.ipsr_forward_workspace_bytes(B, C, h, w, M, patch, stride)
+    bf = corr == "bf16"
+    nbytes = (L.ipsr_forward_bf16corr_workspace_bytes if bf else L.ipsr_forward_workspace_bytes)(B, C, h, w, M, patch, stride)
     ws = _workspace(nbytes, dev)
-    _lib.check(L.ipsr_forward(x.data_ptr(), ref.data_ptr(), mpi.data_ptr() if M else None, M, B, C, h, w,
-                              patch, stride, out.data_ptr(), ind.data_ptr(), vmax.data_ptr(),
-                              attn.data_ptr() if attn is not None else None,
-                              bidx.data_ptr() if bidx is not None else None, ws.data_ptr(), ws.numel(), _stream()),
-               "ipsr_forward")
+    _lib.check((L.ipsr_forward_bf16corr if bf else L.ipsr_forward)(
+        x.data_ptr(), ref.data_ptr(), mpi.data_ptr() if M else None, M, B, C, h, w,
+        patch, stride, out.data_ptr(), ind.data_ptr(), vmax.data_ptr(),
+        attn.data_ptr() if attn is not None else None,
+        bidx.data_ptr() if bidx is not None else None, ws.data_ptr(), ws.numel(), _stream()),
+        "ipsr_forward_bf16corr" if bf else "ipsr_forward")
     if want_attn and attn is None:
         attn = torch.empty((B, 0, N), dtype=torch.float32, device=dev)
     return Forward(out, ind, vmax, attn, bidx)

@@ -12,8 +12,8 @@
  *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless marked [host].
  *   - all tensors are dense, row-major, NCHW:  x[b][c][y][x]  ->  ((b*C + c)*h + y)*w + x.
  *     N = number of patches = nH*nW with nH = (h-patch)/stride+1 (reference util/util.py:95-98).
- *     Only patch == 1, stride == 1 is implemented in this round (the reference itself raises for
- *     shift_sz != 1, models/IPSRFunction.py:134); other values return IPSR_ERR_UNSUPPORTED.
+ *     patch (the reference's shift_sz) >= 1 with stride == 1 is implemented (the reference itself raises for
+ *     shift_sz != 1 at models/IPSRFunction.py:134, see ipsr_forward below); stride != 1 returns IPSR_ERR_UNSUPPORTED.
  *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.  No entry point
  *     allocates, frees or synchronises: the caller owns every buffer incl. the workspace whose size
  *     the matching *_workspace_bytes() query returns.  All entry points are re-entrant per stream.
@@ -107,6 +107,23 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
                  float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* ---- bf16 MFMA correlation (BASELINE.json config 5: "CDNA4 bf16 MFMA for patch-corr") — OPT-IN ----------------------
+ * The same layer with the cross-correlation of models/IPSRFunction.py:59 computed on v_mfma_f32_32x32x16_bf16: both
+ * operands (the normalised patches and ref.relu4_3) are rounded to bf16, products are exact, accumulation is fp32.
+ * Everything else — normalisation, arg-max rule, recurrence, reconstruction, backward index — is the fp32 path above.
+ * Not the reference's arithmetic: an arg-max moves wherever the two best patches are closer than bf16 rounding; the
+ * agreement rate with ipsr_forward is measured by bench.py and tests/test_gpu_parity.py.  Same arguments as
+ * ipsr_forward / ipsr_corr_argmax (fp32 tensors in and out; the bf16 copies live in the workspace).  Shapes: C*patch^2
+ * a multiple of 64 and, for patch == 1, N a multiple of 128; anything else -> IPSR_ERR_UNSUPPORTED (no silent fp32 run). */
+size_t ipsr_forward_bf16corr_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride);
+int ipsr_forward_bf16corr(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
+                          int B, int C, int h, int w, int patch, int stride,
+                          float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
+                          void* ws, size_t ws_bytes, void* stream);
+size_t ipsr_corr_argmax_bf16_workspace_bytes(int B, int C, int N);
+int ipsr_corr_argmax_bf16(const float* xn, const float* ref, int B, int C, int N,
+                          int32_t* ind /*[B,N]*/, float* vmax /*[B,N]*/, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K8  backward -----------------------------------------------------------------------------
  * replaces IPSRFunction.backward (models/IPSRFunction.py:144-178):
  * grad_in[b,:,k] = g[b,:,k] + triple_w * sum_q trunc(A[b])[q][k] * g[b,:,q].
@@ -176,14 +193,20 @@ int innercos_loss_backward(const float* x, int B, int Cx, int Cuse, int N, const
                            float* grad_x /*[B,Cx,N]*/, void* stream);
 
 /* ---- measurement hook (bench.py) -----------------------------------------------------------------
- * Opt-in: when enabled, every launch of the correlation+arg-max kernel (the layer's dominant kernel,
- * inside ipsr_forward / ipsr_corr_argmax) is bracketed by a pair of HIP events recorded on the SAME
- * stream the kernel is launched on.  ipsr_profile_read synchronises the recorded pairs, writes their
- * elapsed times (ms) to the HOST array `ms` and resets the ring; it returns the number written.
- * ipsr_profile_enable(0) disables and frees.  This is the only global state in the library and it is
- * off by default; enable/read are not re-entrant (call them from one thread, outside a timed step). */
+ * Opt-in: when enabled, three kinds of regions are bracketed by a pair of HIP events recorded on the SAME stream the
+ * work is launched on:
+ *   region 0  every launch of the correlation + arg-max kernel (the layer's dominant kernel, inside ipsr_forward /
+ *             ipsr_corr_argmax)
+ *   region 1  every whole ipsr_forward call (all its kernels)
+ *   region 2  every whole ipsr_backward / ipsr_backward_patch call
+ * so that a training step can report the layer's time ON ITS REAL INPUTS.  ipsr_profile_read_region synchronises the
+ * recorded pairs of one region, writes their elapsed times (ms) to the HOST array `ms` and resets that ring; it returns
+ * the number written.  ipsr_profile_read(ms, n) == ipsr_profile_read_region(0, ms, n).  ipsr_profile_enable(capacity)
+ * sizes every ring for `capacity` regions; ipsr_profile_enable(0) disables and frees.  This is the only global state in
+ * the library and it is off by default; enable/read are not re-entrant (call them from one thread, outside a timed step). */
 int ipsr_profile_enable(int capacity);
 int ipsr_profile_read(float* ms /*[host]*/, int max_n);
+int ipsr_profile_read_region(int region, float* ms /*[host]*/, int max_n);
 
 #ifdef __cplusplus
 }

@@ -157,7 +157,11 @@ HOT int ipsr_corr_argmax_cpu(const float* xn, const float* ref, int B, int C, in
             }
             if (S_out) memcpy(S_out + ((size_t)b * N + k) * N + q0, acc, sizeof(float) * nq);
             if (k == 0) for (int q = 0; q < nq; ++q) { best[q] = acc[q]; bi[q] = 0; }
-            else for (int q = 0; q < nq; ++q) if (acc[q] > best[q]) { best[q] = acc[q]; bi[q] = k; }  /* first max wins */
+            else for (int q = 0; q < nq; ++q) {
+                /* torch.max semantics (MaxCoord.py:23): first max wins; a NaN counts as the maximum and the FIRST NaN wins */
+                const float v = acc[q], cur = best[q];
+                if (v > cur || (v != v && cur == cur)) { best[q] = v; bi[q] = k; }
+            }
         }
     }
     return IPSR_OK;

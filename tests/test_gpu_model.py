@@ -117,6 +117,79 @@ def test_ipsr_function_12_arg_surface():
         IPSRFunction.apply(x, feat, Vgg(None, None, None, cu(d["ref"])), 1, 2, 1.0, flag, nonmask, midx, fo, sx, sy)
 
 
+@pytest.mark.parametrize("name", ["layer_c16_8x8_center", "layer_c32_16x16_stroke", "layer_c512_8x8_cfg1", "layer_c8_8x8_ties"])
+def test_nonparametric_shift_and_maxcoord_mirrors_replay_the_reference_flow(name):
+    """A foreign caller's use of util.NonparametricShift + util.MaxCoord — the exact sequence of models/IPSRFunction.py:54-66
+    and :130-131 (conv_enc(ref) -> MaxCoord.update_output -> ... -> conv_new_dec(kbar)) — against the reference's own
+    numbers: arg-max indices exact, the decoded output within 1e-4."""
+    from deepinpainting_amd.util.NonparametricShift import NonparametricShift
+    from deepinpainting_amd.util.MaxCoord import MaxCoord
+    from deepinpainting_amd.util import util
+    from oracle import ipsr_oracle as orc
+    d = load(name)
+    x, ref = cu(d["x"]), cu(d["ref"])
+    B, C, h, w = x.shape
+    N = h * w
+    flag, nonmask, fo, midx = util.cal_mask_given_mask_thred(x[0], cu(d["feat_mask"]), 1, 1, 1)
+    sx, sy = util.cal_sps_for_Advanced_Indexing(h, w)
+    fo_o = orc.forward(d["x"], d["ref"], d["mask_point_idx"])
+    for b in range(B):
+        ret = NonparametricShift().buildAutoencoder(x[b], False, False, nonmask, midx, 1, 1)
+        _, conv_enc, conv_new_dec, _, known_patch, unknown_patch = ret
+        # what the reference returns (util/NonparametricShift.py:43-55): bias-free conv modules holding the patches
+        assert isinstance(conv_enc, torch.nn.Conv2d) and isinstance(conv_new_dec, torch.nn.ConvTranspose2d)
+        assert conv_enc.bias is None and conv_new_dec.bias is None
+        assert tuple(conv_enc.weight.shape) == (N, C, 1, 1) and tuple(conv_new_dec.weight.shape) == (N, C, 1, 1)
+        assert tuple(known_patch.shape) == (N, C, 1, 1) and tuple(unknown_patch.shape) == (len(d["mask_point_idx"]), C, 1, 1)
+        np.testing.assert_array_equal(known_patch[:, :, 0, 0].cpu().numpy(), d["x"][b].reshape(C, N).T)
+        np.testing.assert_array_equal(unknown_patch[:, :, 0, 0].cpu().numpy(), d["x"][b].reshape(C, N).T[d["mask_point_idx"]])
+        tmp1 = conv_enc(ref[b:b + 1])                                              # HIP correlation kernel, S materialised
+        assert tuple(tmp1.shape) == (1, N, h, w)
+        # the same map from the module's ordinary forward (MIOpen), fp32 tolerance
+        assert (tmp1 - torch.nn.Conv2d.forward(conv_enc, ref[b:b + 1])).abs().max().item() <= 1e-4
+        kbar0, ind, vmax = MaxCoord().update_output(tmp1.data, sx, sy)
+        assert kbar0.shape == tmp1.shape and not kbar0.any() and ind.dtype == torch.int64
+        np.testing.assert_array_equal(ind.cpu().numpy(), d["ind"][b])
+        np.testing.assert_array_equal(vmax.cpu().numpy(), fo_o.vmax[b])            # same fmaf chain as the oracle
+        # kbar as the reference fills it (:73-129): attention rows in the masked columns, one-hot elsewhere
+        kbar = torch.zeros(N, N, device="cuda")
+        q_all = torch.arange(N, device="cuda")
+        kbar[ind, q_all] = 1.0
+        mp = torch.from_numpy(d["mask_point_idx"]).cuda()
+        kbar[:, mp] = torch.from_numpy(fo_o.attn_rows[b]).cuda().t()
+        out = conv_new_dec(kbar.view(1, N, h, w)).detach().cpu().numpy()[0]
+        want = d["out"][b] if "out_channels" not in d else None
+        if want is not None:
+            assert np.abs(out - want).max() <= ATOL
+        assert np.abs(out - fo_o.out[b]).max() <= ATOL
+    with pytest.raises(AssertionError, match="target image must be of dimension 3"):
+        NonparametricShift().buildAutoencoder(x, False, False, nonmask, midx, 1, 1)
+    with pytest.raises(NotImplementedError):
+        NonparametricShift().buildAutoencoder(x[0], True, False, nonmask, midx, 1, 1)
+    with pytest.raises(AssertionError, match="first dimension"):
+        MaxCoord().update_output(torch.zeros(2, 4, 2, 2, device="cuda"), sx, sy)
+
+
+def test_nonparametric_shift_3x3_windows_match_the_patch_layer_fixture():
+    """shift_sz = 3: the windows buildAutoencoder extracts (:59-73) are the ones the patch layer correlates — the
+    encoder's arg-max over its correlation map equals the reference's `ind` of the p=3 fixture."""
+    from deepinpainting_amd.util.NonparametricShift import NonparametricShift
+    from deepinpainting_amd.util.MaxCoord import MaxCoord
+    d = dict(np.load(os.path.join(GOLDEN, "patch_layer_p3_c16_12x12_center.npz")))
+    x, ref = cu(d["x"]), cu(d["ref"])
+    B, C, h, w = x.shape
+    nW = h - 2
+    midx = torch.from_numpy(d["mask_point_idx"]).cuda()
+    nonmask = torch.arange(nW * nW, device="cuda")
+    for b in range(B):
+        _, conv_enc, conv_dec, _, known, unknown = NonparametricShift().buildAutoencoder(x[b], False, False, nonmask, midx, 3, 1)
+        assert tuple(conv_enc.weight.shape) == (nW * nW, C, 3, 3) and tuple(unknown.shape) == (len(d["mask_point_idx"]), C, 3, 3)
+        tmp1 = conv_enc(ref[b:b + 1])
+        assert tuple(tmp1.shape) == (1, nW * nW, nW, nW)
+        _, ind, _ = MaxCoord().update_output(tmp1.data, None, None)
+        np.testing.assert_array_equal(ind.cpu().numpy(), d["ind"][b])
+
+
 @pytest.mark.parametrize("name", ["layer_c16_8x8_center", "layer_c32_16x16_stroke", "layer_c512_8x8_cfg1"])
 def test_innercos_module_vs_reference(name):
     from deepinpainting_amd.models.InnerCos import InnerCos
@@ -196,6 +269,58 @@ def test_trainer_step_on_gpu_vs_reference(gpu_trainer):
     m.update_learning_rate()
 
 
+# per-tensor tolerance (relative to the fixture tensor's max |value|) of the gradients the reference's own step leaves, on the
+# GPU.  netP and the part of netG downstream of the IPSR layer see only fp32 summation-order differences (MIOpen Winograd /
+# implicit-GEMM vs the reference's CPU convolutions); everything UPSTREAM of the layer inherits the reference's LongTensor
+# truncation discontinuity (one ulp in a 512-long dot switches a whole gradient column), netD / netF see
+# it through fake_B.  Same table as the CPU twin's (tests/test_host_model.py) with MIOpen's rounding on top.
+GPU_GRAD_TOL = {("P", 0): 2e-3, ("P", 1): 2e-3, ("P", 2): 2e-3, ("G", 2): 2e-3, ("G", 1): 3e-2, ("G", 0): 0.2,
+                ("D", 0): 3e-2, ("D", 1): 3e-2, ("D", 2): 3e-2, ("F", 0): 3e-2, ("F", 1): 3e-2, ("F", 2): 3e-2}
+
+
+def test_trainer_step_on_gpu_all_gradients_and_weights_vs_reference(tmp_path):
+    """Everything tests/golden/trainer_step.npz holds from the reference's own optimize_parameters(), on the MI355X: the
+    gradient slices of ALL FOUR nets, the weights after the Adam step and the next iteration's errors.  strict_reference
+    = the reference's exact sequence (the fixture's netD / netF gradients are the ones backward_G leaves there, which the
+    default mode skips as dead work)."""
+    from deepinpainting_amd.options import Option
+    from deepinpainting_amd.models.models import create_model
+    d = np.load(os.path.join(GOLDEN, "trainer_step.npz"))
+    opt = Option(gpu_ids=[0], batchSize=1, use_dropout=False, quiet=True, strict_reference=True, checkpoints_dir=str(tmp_path))
+    m = quiet(create_model, opt)
+    for i, net in enumerate((m.netG, m.netP, m.netD, m.netF, m.vgg)):
+        golden_cases.reinit_deterministic(net, 500 + i)
+    img, mask, ref = golden_cases.trainer_inputs()
+    m.set_input(img.cuda(), mask.cuda(), ref.cuda())
+    m.set_ref_latent()
+    m.set_gt_latent()
+    m.optimize_parameters()
+    e = m.get_current_errors()
+    np.testing.assert_allclose([e['G_GAN'], e['G_L1'], e['D'], e['F']], d["errors"], rtol=2e-3)
+    np.testing.assert_allclose(m.loss_G.item(), d["loss_G"], rtol=2e-3)
+    np.testing.assert_allclose(m.loss_D.item(), d["loss_D"], rtol=2e-3)
+    report = []
+    for tag, net in (("G", m.netG), ("P", m.netP), ("D", m.netD), ("F", m.netF)):
+        named = dict(net.named_parameters())
+        sd = net.state_dict()
+        for j, k in enumerate(d["post_keys_" + tag]):
+            g, r = named[str(k)].grad.cpu().numpy().reshape(-1)[:256], d["grad_%s_%d" % (tag, j)]
+            rel = float(np.abs(g - r).max() / np.abs(r).max())
+            report.append("grad net%s %-40s rel %.2e (tol %.0e)" % (tag, k, rel, GPU_GRAD_TOL[(tag, j)]))
+            assert rel <= GPU_GRAD_TOL[(tag, j)], report[-1]
+            # Adam's first step is -lr*sign(grad): an element whose gradient is ~0 may flip sign and land 2*lr = 4e-4 away
+            diff = np.abs(sd[str(k)].cpu().numpy().reshape(-1)[:256] - d["post_%s_%d" % (tag, j)])
+            assert diff.max() <= 4.1e-4 and (diff > 1e-6).mean() < 0.15, "net%s %s after one Adam step" % (tag, k)
+    print("\n".join(report))
+    m.set_input(img.cuda(), mask.cuda(), ref.cuda())
+    m.set_ref_latent()
+    m.set_gt_latent()
+    m.optimize_parameters()
+    e2 = m.get_current_errors()
+    # second iteration: every weight moved by +-lr, sign flips of ~zero gradients make it chaotic at the percent level
+    np.testing.assert_allclose([e2['G_GAN'], e2['G_L1'], e2['D'], e2['F']], d["errors_iter2"], rtol=0.1)
+
+
 def test_trainer_batch8_dropout_runs(tmp_path):
     """BASELINE config 2 shape: batch 8, dropout on (train.ipynb default): losses finite, weights move."""
     from deepinpainting_amd.options import Option
@@ -221,19 +346,20 @@ def test_trainer_batch8_dropout_runs(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------ data parallel
-def _ddp_worker(rank, world, port, out_dir):
+def _ddp_worker(rank, world, port, out_dir, backend="gloo", steps=1):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    # gloo: both ranks share GPU 0 (the box has one) and gloo carries the CUDA tensors; nccl (= RCCL): one GPU per rank
+    dev = rank if backend == "nccl" else 0
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev))
     from deepinpainting_amd import dist as idist
     from deepinpainting_amd.options import Option
     from deepinpainting_amd.models.models import create_model
-    # both ranks share GPU 0 (the box has one): gloo carries the CUDA tensors; on the 8-GPU node the same code runs over RCCL
-    idist.init_distributed(backend="gloo")
-    torch.cuda.set_device(0)
+    idist.init_distributed(backend=backend)
+    torch.cuda.set_device(dev)
     torch.manual_seed(100 + rank)                     # DIFFERENT init per rank: the trainer must broadcast rank 0's
-    opt = Option(gpu_ids=[0], batchSize=1, use_dropout=False, quiet=True, ddp_bucket_mb=32,
+    opt = Option(gpu_ids=[dev], batchSize=1, use_dropout=False, quiet=True, ddp_bucket_mb=32,
                  checkpoints_dir=os.path.join(out_dir, "ck%d" % rank))
     m = quiet(create_model, opt)
     assert m._reducer_G is not None and m._reducer_D is not None and len(m._reducer_G.buckets) > 4
@@ -242,10 +368,11 @@ def _ddp_worker(rank, world, port, out_dir):
     ref = torch.rand(1, 3, 256, 256, device="cuda", generator=g) * 2 - 1
     mask = torch.zeros(1, 1, 256, 256, dtype=torch.bool, device="cuda")
     mask[:, :, 64:192, 64:192] = 1
-    m.set_input(img, mask, ref)
-    m.set_ref_latent()
-    m.set_gt_latent()
-    m.optimize_parameters()
+    for _ in range(steps):
+        m.set_input(img, mask, ref)
+        m.set_ref_latent()
+        m.set_gt_latent()
+        m.optimize_parameters()
     torch.cuda.synchronize()
     sig = {}
     for tag, net in (("G", m.netG), ("P", m.netP), ("D", m.netD), ("F", m.netF)):
@@ -272,6 +399,23 @@ def test_trainer_data_parallel_two_ranks(tmp_path):
         assert torch.equal(a[tag]["g"], b[tag]["g"]) if tag in "GP" else True
         assert torch.equal(a[tag]["w"], b[tag]["w"]), "net%s weights diverged across ranks" % tag
     # the losses differ (different data) — proves the ranks really saw different batches
+    assert a["errors"]["G_L1"] != b["errors"]["G_L1"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs two GPUs (the builder's box has one; the "
+                                                            "driver's 8-GPU node runs it)")
+def test_trainer_data_parallel_two_ranks_rccl_multi_step(tmp_path):
+    """The same exchange over RCCL (backend "nccl"), one GPU per rank, THREE steps: the async all-reduce on the collective
+    stream with .grad aliasing the bucket must keep both ranks' weights identical step after step."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path), "nccl", 3), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), "ddp_rank0.pt"))
+    b = torch.load(os.path.join(str(tmp_path), "ddp_rank1.pt"))
+    for tag in "GPDF":
+        assert torch.equal(a[tag]["w"], b[tag]["w"]), "net%s weights diverged across ranks" % tag
+        assert torch.isfinite(a[tag]["w"]).all()
     assert a["errors"]["G_L1"] != b["errors"]["G_L1"]
 
 
@@ -357,6 +501,42 @@ def test_trainer_bf16_autocast_config5(tmp_path):
         assert m.fake_B.dtype == torch.float32 and m.netG.model.model[0].weight.dtype == torch.float32
         assert all(np.isfinite(v) for v in losses[amp])
     np.testing.assert_allclose(losses[True], losses[False], rtol=0.08)
+
+
+def test_trainer_bf16_config5_at_batch16(tmp_path):
+    """BASELINE config 5 at ITS batch size (16 per GPU): convolutions under bf16 autocast AND the IPSR correlation on the bf16
+    MFMA kernel (the layer's module says so), two training steps, dropout on as in train.ipynb: losses finite, close to the
+    fp32 trainer's first step on the same weights and data, weights move, masters stay fp32."""
+    from deepinpainting_amd.options import Option
+    from deepinpainting_amd.models.models import create_model
+    g = torch.Generator(device="cuda").manual_seed(11)
+    img = torch.rand(16, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    ref = torch.rand(16, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    mask = torch.zeros(1, 1, 256, 256, dtype=torch.bool, device="cuda")
+    mask[:, :, 64:192, 64:192] = 1
+    first = {}
+    for amp in (False, True):
+        opt = Option(gpu_ids=[0], batchSize=16, use_dropout=False, quiet=True, amp_bf16=amp, checkpoints_dir=str(tmp_path / str(amp)))
+        m = quiet(create_model, opt)
+        for i, net in enumerate((m.netG, m.netP, m.netD, m.netF, m.vgg)):
+            golden_cases.reinit_deterministic(net, 900 + i)
+        assert m.CSA_model[0].corr_bf16 == amp
+        w0 = m.netG.model.model[0].weight.detach().clone()
+        for step in range(2 if amp else 1):
+            m.set_input(img, mask, ref)
+            m.set_ref_latent()
+            m.set_gt_latent()
+            m.optimize_parameters()
+            e = m.get_current_errors()
+            vals = [e['G_GAN'], e['G_L1'], e['D'], e['F'], float(m.ng_loss_value), float(m.ng_loss_value2)]
+            assert all(np.isfinite(v) for v in vals), vals
+            if step == 0:
+                first[amp] = vals
+        assert m.fake_B.dtype == torch.float32 and tuple(m.fake_B.shape) == (16, 3, 256, 256)
+        assert m.netG.model.model[0].weight.dtype == torch.float32 and not torch.equal(m.netG.model.model[0].weight, w0)
+        del m
+        torch.cuda.empty_cache()
+    np.testing.assert_allclose(first[True], first[False], rtol=0.08)
 
 
 PATCH_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "patch_layer_*.npz")))

@@ -91,6 +91,16 @@ def test_factories_error_behaviour():
         quiet(create_model, Option(model='other'))
 
 
+def test_trainer_refuses_a_silently_random_vgg(monkeypatch):
+    """The reference always runs on ImageNet-pretrained VGG16 features (models/vgg16.py:9).  Without a weights file the
+    trainer must refuse rather than train on a random feature extractor, unless the caller opts in explicitly."""
+    from deepinpainting_amd.models.models import create_model
+    monkeypatch.delenv("IPSR_ALLOW_RANDOM_VGG", raising=False)
+    monkeypatch.delenv("IPSR_VGG16_WEIGHTS", raising=False)
+    with pytest.raises(RuntimeError, match="no VGG16 weights"):
+        quiet(create_model, Option(gpu_ids=[], quiet=True))
+
+
 def test_scheduler_lambda_rule():
     opt = Option(niter=2, niter_decay=3, epoch_count=1)
     p = torch.nn.Parameter(torch.zeros(1))

@@ -17,7 +17,7 @@ ap.add_argument("--batch", type=int, default=8)
 args = ap.parse_args()
 B = args.batch
 
-opt = Option(gpu_ids=[0], batchSize=B, quiet=True, checkpoints_dir="/tmp/ipsr_ck")
+opt = Option(gpu_ids=[0], batchSize=B, quiet=True, allow_random_vgg=True, checkpoints_dir="/tmp/ipsr_ck")
 import contextlib, io
 with contextlib.redirect_stdout(io.StringIO()):
     m = create_model(opt)

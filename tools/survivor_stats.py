@@ -8,7 +8,7 @@ from deepinpainting_amd import ops  # noqa: E402
 from deepinpainting_amd.models.models import create_model  # noqa: E402
 from deepinpainting_amd.options import Option  # noqa: E402
 
-opt = Option(gpu_ids=[0], batchSize=8, use_dropout=True, quiet=True, checkpoints_dir="/tmp/ipsr_surv_ck")
+opt = Option(gpu_ids=[0], batchSize=8, use_dropout=True, quiet=True, allow_random_vgg=True, checkpoints_dir="/tmp/ipsr_surv_ck")
 torch.manual_seed(1234)
 with contextlib.redirect_stdout(io.StringIO()):
     model = create_model(opt)
