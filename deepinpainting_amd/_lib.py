@@ -48,6 +48,11 @@ SIGNATURES = {
     "ipsr_instnorm_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                            c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ipsr_bias_act_backward": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ipsr_conv2d_workspace_bytes": (c_size_t, [c_int] * 10),
+    "ipsr_conv2d": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                            c_void_p, c_size_t, c_void_p]),
+    "ipsr_conv3x3_winograd_workspace_bytes": (c_size_t, [c_int] * 6),
+    "ipsr_conv3x3_winograd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "innercos_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "innercos_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                               c_void_p, c_size_t, c_void_p]),

@@ -48,9 +48,16 @@ struct ConvLaunch {
     int nstage;           // total reduction stages
     int ksplit, stages_per_split;
     int m_tiles, n_tiles;
-    int dy[16], dx[16];
-    int toff[16];         // dy*Win + dx - min_t(dy*Win + dx)  (>= 0), in elements
+    // tap t = a*NSX + b (NSX = sqrt(NT) taps per kernel row):  dy = dy0 + a*dys,  dx = dx0 + b*dxs.  Scalars, not tables:
+    // an indexed array inside the kernel-argument struct made the compiler fetch it per lane with waterfall loops.
+    int dy0, dys, dx0, dxs;
     int minoff;           // min_t(dy*Win + dx)  (<= 0): the gather's buffer base is x + minoff
+};
+
+template <int NT> struct CgTap {
+    static constexpr int NSX = NT == 4 ? 2 : (NT == 9 ? 3 : 4);
+    static __device__ __forceinline__ int dy(const ConvLaunch& p, int t) { return p.dy0 + (t / NSX) * p.dys; }
+    static __device__ __forceinline__ int dx(const ConvLaunch& p, int t) { return p.dx0 + (t % NSX) * p.dxs; }
 };
 
 template <int NT> struct CgCfg {
@@ -61,23 +68,30 @@ template <int NT> struct CgCfg {
     static constexpr int SLOT = 2 * BK * CG_BM;          // floats per ring slot (A then B)
 };
 
-// One stage of the im2col gather for the thread's pixel column: rows PAR, PAR+2, ...  ->  registers.
+// One stage of the im2col gather for the thread's pixel column: the NB rows  jj + NB*gpar  (gpar = 0 | 1, wave-uniform)
+// -> registers.  Row -> (channel within the stage, tap):
+//      NT = 16 (BK 16, 1 channel):  cc = 0,             t = jj + 8*gpar
+//      NT =  9 (BK 18, 2 channels): cc = gpar,          t = jj
+//      NT =  4 (BK 16, 4 channels): cc = jj/4 + 2*gpar, t = jj % 4
 // Branch-free: raw buffer loads whose per-lane offset is the pixel's byte offset, or an offset with bit 31 set where the
 // tap falls outside the input (hardware range check against num_records = 2^31 -> the load returns 0).  The channel /
 // tap part of the address is wave-uniform and rides in the scalar offset, so an element costs two VALU operations and
-// the compiler keeps counted vmcnt waits (a predicated load per element made it fall back to vmcnt(0) at every join).
-template <int NT, int PAR>
+// straight-line code (a predicated load per element, or one code path per gpar, made the compiler drain vmcnt — and with
+// it the weight DMA in flight — in the middle of every stage).
+template <int NT>
 __device__ __forceinline__ void cg_gather(float (&reg)[CgCfg<NT>::NB], __amdgpu_buffer_rsrc_t rsrc, const ConvLaunch& p,
-                                          unsigned pixoff, unsigned inv_mask, int s, int hw_in)
+                                          unsigned pixoff, unsigned invm, int s, int hw_in, int gpar)
 {
-    constexpr int NB = CgCfg<NT>::NB, CPS = CgCfg<NT>::CPS;
+    constexpr int NB = CgCfg<NT>::NB, CPS = CgCfg<NT>::CPS, NSX = CgTap<NT>::NSX;
 #pragma unroll
     for (int jj = 0; jj < NB; ++jj) {
-        const int row = PAR + 2 * jj;
-        const int cc = row / NT, t = row % NT;           // compile-time after unrolling
+        int cc, a, b, tl;                                // a, b: tap row / column; tl: bit of the (pre-shifted) mask
+        if (NT == 16) { cc = 0; a = jj / NSX + 2 * gpar; b = jj % NSX; tl = jj; }
+        else if (NT == 9) { cc = gpar; a = jj / NSX; b = jj % NSX; tl = jj; }
+        else { cc = jj / 4 + 2 * gpar; a = (jj % 4) / NSX; b = jj % NSX; tl = jj % 4; }
         const int ci = s * CPS + cc;                     // uniform
-        const unsigned voff = ((inv_mask << (31 - t)) & 0x80000000u) | pixoff;
-        const int soff = (ci * hw_in + p.toff[t]) * 4;   // uniform, >= 0
+        const unsigned voff = ((invm << (31 - tl)) & 0x80000000u) | pixoff;
+        const int soff = (ci * hw_in + (p.dy0 + a * p.dys) * p.Win + p.dx0 + b * p.dxs - p.minoff) * 4;   // uniform, >= 0
         reg[jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
     }
 }
@@ -90,7 +104,7 @@ __global__ void __launch_bounds__(CG_THREADS, 2) conv_gemm_kernel(const ConvLaun
     __shared__ __attribute__((aligned(16))) float lds[CG_NBUF * SLOT];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in an SGPR: branches on it are scalar
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
 
@@ -104,7 +118,7 @@ __global__ void __launch_bounds__(CG_THREADS, 2) conv_gemm_kernel(const ConvLaun
     const int ntot = p.B * hw_o;
 
     // ---- gather role: this thread's pixel column and the validity of each tap there
-    const int gpar = tid >> 7;                           // rows gpar, gpar+2, ...  (wave-uniform)
+    const int gpar = wave >> 1;                          // this half of the block gathers rows jj + NB*gpar (wave-uniform)
     const int gn = n0 + (tid & 127);
     unsigned inv_mask = 0;                               // bit t set = tap t of this pixel reads outside the input
     unsigned pixoff = 0;                                 // byte offset of (b, channel 0, iy0, ix0) from the tensor start
@@ -116,11 +130,12 @@ __global__ void __launch_bounds__(CG_THREADS, 2) conv_gemm_kernel(const ConvLaun
         const int iy0 = oy * p.in_mul, ix0 = ox * p.in_mul;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int iy = iy0 + p.dy[t], ix = ix0 + p.dx[t];
+            const int iy = iy0 + CgTap<NT>::dy(p, t), ix = ix0 + CgTap<NT>::dx(p, t);
             if (!(nv && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)) inv_mask |= 1u << t;
         }
         pixoff = (unsigned)((b * p.Cred * hw_in + iy0 * p.Win + ix0) * 4);      // host checks the tensor is < 2 GiB
     }
+    const unsigned invm = NT == 16 ? inv_mask >> (8 * gpar) : inv_mask;      // NT = 16: this half's taps are 8*gpar .. 8*gpar+7
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + p.minoff), 0, 0x80000000, 0x00020000);
 
     const int s_lo = ks * p.stages_per_split;
@@ -150,17 +165,15 @@ __global__ void __launch_bounds__(CG_THREADS, 2) conv_gemm_kernel(const ConvLaun
             if (q < PAIRS) dma_piece(s, q);
         }
     };
-    const int my_pieces = (PAIRS - wave + 3) / 4;        // pieces THIS wave issues per stage (wave-uniform)
 
     float breg[NB];
     auto gather = [&](int s) {
-        if (gpar == 0) cg_gather<NT, 0>(breg, rsrc, p, pixoff, inv_mask, s_lo + s, hw_in);
-        else cg_gather<NT, 1>(breg, rsrc, p, pixoff, inv_mask, s_lo + s, hw_in);
+        cg_gather<NT>(breg, rsrc, p, pixoff, invm, s_lo + s, hw_in, gpar);
     };
     auto store_b = [&](int s) {
         float* bt = lds + (s & (CG_NBUF - 1)) * SLOT + BK * CG_BM + (tid & 127);
 #pragma unroll
-        for (int jj = 0; jj < NB; ++jj) bt[(gpar + 2 * jj) * CG_BM] = breg[jj];
+        for (int jj = 0; jj < NB; ++jj) bt[(jj + NB * gpar) * CG_BM] = breg[jj];
     };
 
     // ---- prologue: A stages 0..2 in flight, B stage 0 in LDS
@@ -201,16 +214,10 @@ __global__ void __launch_bounds__(CG_THREADS, 2) conv_gemm_kernel(const ConvLaun
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cs], fb1[cs], acc[1][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // Stage s+1 must be complete in LDS before anyone crosses the barrier: its A pieces (issued two stages ago) and this
-        // thread's gathered registers (issued at the top of this stage) are all OLDER than the pieces of stage s+3 issued
-        // above, so "all but my youngest pieces" covers both.
-        if (prefetch) {
-            if (my_pieces >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // Stage s+1 must be complete in LDS before anyone crosses the barrier: this thread's gathered registers (issued at the
+        // top of this stage) and the A pieces in flight.  The pieces of stage s+3 were issued in the first k-steps above, a
+        // whole stage of MFMAs ago, so draining them here costs nothing measurable and keeps the wait a plain vmcnt(0).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (more) store_b(s + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -263,7 +270,7 @@ __global__ void __launch_bounds__(256) conv_reduce_kernel(const float* __restric
 
 // Wp[(ci, t)][m] = W[ci*sc + m*sm + src[t]]   (zero for ci >= Cred, m >= M); 32x32 tiles transposed through LDS so that
 // both the reads (along the source's contiguous taps) and the writes (along m) are coalesced.
-struct TapSrc { int src[16]; };
+struct TapSrc { int nsx, r0, rs, s0, ss, k; };       // source tap of t = a*nsx + b:  (r0 + a*rs)*k + (s0 + b*ss)
 
 __global__ void __launch_bounds__(256) conv_pack_weights_kernel(const float* __restrict__ W, float* __restrict__ Wp, int M, int Mp,
                                                                 int Cred, int red_rows, int NT, long sc, long sm, TapSrc taps)
@@ -275,7 +282,8 @@ __global__ void __launch_bounds__(256) conv_pack_weights_kernel(const float* __r
         const int red = r0 + tx;
         const int ci = red / NT, t = red - ci * NT;
         const bool rok = red < red_rows && ci < Cred;
-        const long roff = (long)ci * sc + taps.src[t];
+        const int ta = t / taps.nsx, tb = t - ta * taps.nsx;
+        const long roff = (long)ci * sc + (taps.r0 + ta * taps.rs) * taps.k + (taps.s0 + tb * taps.ss);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + ty + 8 * i;
@@ -406,25 +414,35 @@ int launch_conv_gemm(bool transposed, bool w_cred_major, const float* x, const f
         if (P.nstage[c] == 0) continue;
         ConvLaunch L;
         TapSrc ts;
-        for (int t = 0; t < 16; ++t) { L.dy[t] = L.dx[t] = 0; ts.src[t] = 0; }
+        ts.k = k;
         if (!transposed) {
-            for (int r = 0; r < k; ++r)
-                for (int s = 0; s < k; ++s) { L.dy[r * k + s] = r * dil - pad; L.dx[r * k + s] = s * dil - pad; ts.src[r * k + s] = r * k + s; }
+            L.dy0 = L.dx0 = -pad; L.dys = L.dxs = dil;
+            ts.nsx = k; ts.r0 = ts.s0 = 0; ts.rs = ts.ss = 1;
             L.in_mul = stride; L.oy_mul = L.ox_mul = 1; L.oy_add = L.ox_add = 0;
         } else if (stride == 1) {
-            for (int r = 0; r < k; ++r)
-                for (int s = 0; s < k; ++s) { L.dy[r * k + s] = pad - r * dil; L.dx[r * k + s] = pad - s * dil; ts.src[r * k + s] = r * k + s; }
+            L.dy0 = L.dx0 = pad; L.dys = L.dxs = -dil;
+            ts.nsx = k; ts.r0 = ts.s0 = 0; ts.rs = ts.ss = 1;
             L.in_mul = 1; L.oy_mul = L.ox_mul = 1; L.oy_add = L.ox_add = 0;
         } else {
             int rr[4], ro[4], sr[4], so[4];
             const int nr = axis_taps(k, stride, pad, dil, P.py[c], rr, ro), nsx = axis_taps(k, stride, pad, dil, P.px[c], sr, so);
-            for (int a = 0; a < nr; ++a)
-                for (int b2 = 0; b2 < nsx; ++b2) { L.dy[a * nsx + b2] = ro[a]; L.dx[a * nsx + b2] = so[b2]; ts.src[a * nsx + b2] = rr[a] * k + sr[b2]; }
+            // the valid taps of an axis form an arithmetic progression in r, and so do their offsets
+            for (int a = 2; a < nr; ++a)
+                if (rr[a] - rr[a - 1] != rr[1] - rr[0] || ro[a] - ro[a - 1] != ro[1] - ro[0]) return fail(IPSR_ERR_UNSUPPORTED, "conv: irregular tap set");
+            for (int a = 2; a < nsx; ++a)
+                if (sr[a] - sr[a - 1] != sr[1] - sr[0] || so[a] - so[a - 1] != so[1] - so[0]) return fail(IPSR_ERR_UNSUPPORTED, "conv: irregular tap set");
+            if (nr != nsx) return fail(IPSR_ERR_UNSUPPORTED, "conv: %d x %d taps in a parity class", nr, nsx);
+            L.dy0 = ro[0]; L.dys = nr > 1 ? ro[1] - ro[0] : 0;
+            L.dx0 = so[0]; L.dxs = nsx > 1 ? so[1] - so[0] : 0;
+            ts.nsx = nsx; ts.r0 = rr[0]; ts.rs = nr > 1 ? rr[1] - rr[0] : 0; ts.s0 = sr[0]; ts.ss = nsx > 1 ? sr[1] - sr[0] : 0;
             L.in_mul = 1; L.oy_mul = L.ox_mul = 2; L.oy_add = P.py[c]; L.ox_add = P.px[c];
         }
-        L.minoff = 0;
-        for (int t = 0; t < P.NT[c]; ++t) L.minoff = min(L.minoff, L.dy[t] * Win + L.dx[t]);
-        for (int t = 0; t < 16; ++t) L.toff[t] = t < P.NT[c] ? L.dy[t] * Win + L.dx[t] - L.minoff : 0;
+        {
+            const int nsx = ts.nsx, na = P.NT[c] / nsx;
+            L.minoff = 0;
+            for (int a = 0; a < na; ++a)
+                for (int b2 = 0; b2 < nsx; ++b2) L.minoff = min(L.minoff, (L.dy0 + a * L.dys) * Win + L.dx0 + b2 * L.dxs);
+        }
         float* wp = wsf + P.wp_off[c];
         const int red_rows = P.nstage[c] * P.BK[c];
         conv_pack_weights_kernel<<<dim3(cdiv(red_rows, 32), cdiv(P.Mp, 32)), 256, 0, st>>>(w, wp, M, P.Mp, Cred, red_rows, P.NT[c], sc, sm, ts);
@@ -452,3 +470,57 @@ int launch_conv_gemm(bool transposed, bool w_cred_major, const float* x, const f
 }
 
 }  // namespace ipsr
+
+using namespace ipsr;
+
+extern "C" {
+
+static int conv_out_dim(int op, int n, int k, int stride, int pad, int dil)
+{
+    if (op == 0 || op == 1) return (n + 2 * pad - dil * (k - 1) - 1) / stride + 1;     // Conv2d
+    return (n - 1) * stride - 2 * pad + dil * (k - 1) + 1;                              // ConvTranspose2d, output_padding 0
+}
+
+static int conv_args_ok(const char* who, int op, int B, int Cin, int H, int W, int Cout, int k, int stride, int pad, int dil)
+{
+    if (op < 0 || op > 3) return fail(IPSR_ERR_INVALID, "%s: op %d", who, op);
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || k < 1 || k > 4 || stride < 1 || pad < 0 || dil < 1)
+        return fail(IPSR_ERR_INVALID, "%s: bad geometry B=%d Cin=%d H=%d W=%d Cout=%d k=%d stride=%d pad=%d dil=%d", who, B, Cin, H, W, Cout, k, stride, pad, dil);
+    if (conv_out_dim(op, H, k, stride, pad, dil) < 1 || conv_out_dim(op, W, k, stride, pad, dil) < 1)
+        return fail(IPSR_ERR_INVALID, "%s: empty output", who);
+    return IPSR_OK;
+}
+
+size_t ipsr_conv2d_workspace_bytes(int op, int B, int Cin, int H, int W, int Cout, int k, int stride, int pad, int dil)
+{
+    if (conv_args_ok("ipsr_conv2d_workspace_bytes", op, B, Cin, H, W, Cout, k, stride, pad, dil)) return 0;
+    const int Ho = conv_out_dim(op, H, k, stride, pad, dil), Wo = conv_out_dim(op, W, k, stride, pad, dil);
+    switch (op) {
+        case 0: return conv_gemm_ws_bytes(0, B, Cin, Cout, H, W, Ho, Wo, k, stride, pad, dil);
+        case 1: return conv_gemm_ws_bytes(1, B, Cout, Cin, Ho, Wo, H, W, k, stride, pad, dil);
+        case 2: return conv_gemm_ws_bytes(1, B, Cin, Cout, H, W, Ho, Wo, k, stride, pad, dil);
+        default: return conv_gemm_ws_bytes(0, B, Cout, Cin, Ho, Wo, H, W, k, stride, pad, dil);
+    }
+}
+
+int ipsr_conv2d(int op, const float* in, const float* weight, float* out, int B, int Cin, int H, int W, int Cout,
+                int k, int stride, int pad, int dil, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!in || !weight || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv2d: null pointer");
+    if (int rc = conv_args_ok("ipsr_conv2d", op, B, Cin, H, W, Cout, k, stride, pad, dil)) return rc;
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) != 0) return fail(IPSR_ERR_INVALID, "ipsr_conv2d: workspace must be 16-byte aligned");
+    const int Ho = conv_out_dim(op, H, k, stride, pad, dil), Wo = conv_out_dim(op, W, k, stride, pad, dil);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (op) {
+        case 0:      // y[B,Cout,Ho,Wo] = conv(x[B,Cin,H,W], w[Cout,Cin,k,k])
+            return launch_conv_gemm(false, false, in, weight, out, B, Cin, Cout, H, W, Ho, Wo, k, stride, pad, dil, ws, ws_bytes, st);
+        case 1:      // dx[B,Cin,H,W] from dy[B,Cout,Ho,Wo], w[Cout,Cin,k,k]  (reduction over Cout: weight is [Cred][M])
+            return launch_conv_gemm(true, true, in, weight, out, B, Cout, Cin, Ho, Wo, H, W, k, stride, pad, dil, ws, ws_bytes, st);
+        case 2:      // y[B,Cout,Ho,Wo] = conv_transpose(x[B,Cin,H,W], w[Cin,Cout,k,k])  (weight is [Cred][M])
+            return launch_conv_gemm(true, true, in, weight, out, B, Cin, Cout, H, W, Ho, Wo, k, stride, pad, dil, ws, ws_bytes, st);
+        default:     // dx[B,Cin,H,W] from dy[B,Cout,Ho,Wo], w[Cin,Cout,k,k]  (a direct gather over dy; weight is [M][Cred])
+            return launch_conv_gemm(false, false, in, weight, out, B, Cout, Cin, Ho, Wo, H, W, k, stride, pad, dil, ws, ws_bytes, st);
+    }
+}
+
+}  // extern "C"

@@ -148,6 +148,11 @@ size_t corr_argmax_bf16_ws_bytes(int B, int C, int N, int ld = 0);
 int launch_corr_argmax_bf16(const float* xn, const float* ref, int B, int C, int N, int32_t* ind, float* vmax,
                             void* ws, size_t ws_bytes, hipStream_t st, CorrPartials* partials = nullptr, int ld = 0);
 
+// conv_gemm.hip — implicit-GEMM convolutions on the fp32 matrix cores (see the file header)
+size_t conv_gemm_ws_bytes(int transposed, int B, int Cred, int M, int Hin, int Win, int Hout, int Wout, int k, int stride, int pad, int dil);
+int launch_conv_gemm(bool transposed, bool w_cred_major, const float* x, const float* w, float* y, int B, int Cred, int M,
+                     int Hin, int Win, int Hout, int Wout, int k, int stride, int pad, int dil, void* ws, size_t ws_bytes, hipStream_t st);
+
 struct AttnArgs {
     const float* xT;       // [B,N,Cp] patch-major raw copy, zero padded to Cp = roundup(C,8)
     const float* inv;      // [B,N]

@@ -1,0 +1,362 @@
+// winograd.hip — 3x3 stride-1 pad-1 convolutions (and their input gradients / the transposed twins) by Winograd
+// F(4x4, 3x3) on the fp32 matrix cores.
+//
+// Reference layers (models/vgg16.py:9-21 — all thirteen VGG convolutions; models/networks.py:220-243 — `downconv_3`
+// Conv2d(k3 s1 p1) and `upconv_3` ConvTranspose2d(k3 s1 p1) of every netG level): together the largest share of the
+// training step's time.  A direct fp32 implicit GEMM (conv_gemm.hip, ~100 TF) can at best tie MIOpen's F(2x2,3x3)
+// Winograd assembly there (100-120 TF direct-equivalent); the way past it is the larger tile: F(4x4,3x3) needs 36
+// multiplies per 16 outputs and channel pair instead of 144 — 4x fewer MFMA flops than the direct form.
+//
+//      Y = A^T [ (G g G^T) (.) (B^T d B) ] A          per 4x4 output tile, summed over input channels
+//
+// Non-fused, four launches (all operands of the multiply stage are then plain reduction-major matrices):
+//   wino_filter_kernel   U[xi][c][k] = (G g G^T)[xi]                 from the weight tensor in any of the four roles
+//                        (Conv2d / ConvTranspose2d, forward / backward-data: index strides + tap flip, as in conv_gemm.hip)
+//   wino_input_kernel    V[xi][c][t] = (B^T d B)[xi]                 d = 6x6 input window of tile t = (b, ty, tx), zero padded
+//   wino_gemm_kernel     M[xi][k][t] = sum_c U[xi][c][k] * V[xi][c][t]   36 independent GEMMs; both operands are [C][*]
+//                        with the reduction outermost — exactly the layout the correlation kernel streams by LDS-DMA, so
+//                        this is that kernel's pipeline (128x128 tile, 4-slot DMA ring, 32x32x2 fp32 MFMA) without the arg-max
+//   wino_output_kernel   y[b][k][4ty+i][4tx+j] = (A^T M A)[i][j]
+// HBM traffic is 2.25x the activations each way (36 numbers per 16 pixels) — worth it from 128 channels up, where the
+// 4x smaller GEMM dominates; below that the direct kernels / MIOpen stay in charge (the Python dispatcher decides per shape).
+//
+// Numerics: the standard interpolation points (0, +-1, +-2, inf); fp32 error ~4e-6 of the output scale at 512 channels
+// (tests/test_gpu_conv.py measures it per shape against an fp64 convolution).
+#include "ipsr_common.h"
+
+namespace ipsr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int WG_BM = 128, WG_BN = 128, WG_BK = 16, WG_NBUF = 4, WG_THREADS = 256;
+
+// ---- 1-D transforms --------------------------------------------------------------------------------
+__device__ __forceinline__ void wino_bt(const float d[6], float v[6])        // B^T d
+{
+    v[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+    v[1] = -4.0f * d[1] - 4.0f * d[2] + d[3] + d[4];
+    v[2] = 4.0f * d[1] - 4.0f * d[2] - d[3] + d[4];
+    v[3] = -2.0f * d[1] - d[2] + 2.0f * d[3] + d[4];
+    v[4] = 2.0f * d[1] - d[2] - 2.0f * d[3] + d[4];
+    v[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+}
+__device__ __forceinline__ void wino_g(const float g[3], float u[6])         // G g
+{
+    u[0] = 0.25f * g[0];
+    u[1] = (-1.0f / 6.0f) * (g[0] + g[1] + g[2]);
+    u[2] = (-1.0f / 6.0f) * (g[0] - g[1] + g[2]);
+    u[3] = (1.0f / 24.0f) * g[0] + (1.0f / 12.0f) * g[1] + (1.0f / 6.0f) * g[2];
+    u[4] = (1.0f / 24.0f) * g[0] - (1.0f / 12.0f) * g[1] + (1.0f / 6.0f) * g[2];
+    u[5] = g[2];
+}
+__device__ __forceinline__ void wino_at(const float m[6], float y[4])        // A^T m
+{
+    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    y[1] = m[1] - m[2] + 2.0f * m[3] - 2.0f * m[4];
+    y[2] = m[1] + m[2] + 4.0f * m[3] + 4.0f * m[4];
+    y[3] = m[1] - m[2] + 8.0f * m[3] - 8.0f * m[4] + m[5];
+}
+
+// U[xi][c][k], k < Kp (zero beyond K), from W[c*sc + k*sm + r*3 + s] (flip: r -> 2-r, s -> 2-s)
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ W, int C, int K, int Kp, long sc, long sm, int flip,
+                                                          float* __restrict__ U)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (k >= Kp) return;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
+            g[r][s] = k < K ? W[(long)c * sc + (long)k * sm + rr * 3 + ss] : 0.0f;
+        }
+    float t[6][3], u[6][6];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {                 // columns: t[:,s] = G g[:,s]
+        const float col[3] = {g[0][s], g[1][s], g[2][s]};
+        float o[6];
+        wino_g(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t[i][s] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino_g(t[i], u[i]);          // rows: u[i,:] = G t[i,:]
+    const size_t plane = (size_t)C * Kp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) U[(size_t)(i * 6 + j) * plane + (size_t)c * Kp + k] = u[i][j];
+}
+
+// V[xi][c][t], t < Tp (zero beyond T = B*TY*TX)
+__global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, int B, int C, int H, int Wd, int TY, int TX, int Tp,
+                                                         float* __restrict__ V)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (t >= Tp) return;
+    const int T = B * TY * TX;
+    float d[6][6];
+    if (t < T) {
+        const int b = t / (TY * TX), rem = t - b * TY * TX;
+        const int ty = rem / TX, tx = rem - ty * TX;
+        const float* xp = x + ((size_t)b * C + c) * H * Wd;
+        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int yy = y0 + i;
+            const bool yok = (unsigned)yy < (unsigned)H;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int xx = x0 + j;
+                d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d[i][j] = 0.0f;
+    }
+    float w[6][6], v[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                 // columns: w[:,j] = B^T d[:,j]
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float o[6];
+        wino_bt(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino_bt(w[i], v[i]);         // rows
+    const size_t plane = (size_t)C * Tp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) V[(size_t)(i * 6 + j) * plane + (size_t)c * Tp + t] = v[i][j];
+}
+
+// y[b][k][4ty+i][4tx+j] = (A^T M A)[i][j]
+__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mo, int B, int K, int Kp, int H, int Wd, int TY, int TX,
+                                                          int Tp, float* __restrict__ y)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    const int T = B * TY * TX;
+    if (t >= T) return;
+    float m[6][6];
+    const size_t plane = (size_t)Kp * Tp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[i][j] = Mo[(size_t)(i * 6 + j) * plane + (size_t)k * Tp + t];
+    float w[4][6], o[4][4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                 // columns: w[:,j] = A^T m[:,j]
+        const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
+        float r4[4];
+        wino_at(col, r4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i][j] = r4[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wino_at(w[i], o[i]);
+    const int b = t / (TY * TX), rem = t - b * TY * TX;
+    const int ty = rem / TX, tx = rem - ty * TX;
+    float* yp = y + ((size_t)b * K + k) * H * Wd;
+    const int y0 = 4 * ty, x0 = 4 * tx;
+    if ((Wd & 3) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (y0 + i < H) *reinterpret_cast<float4*>(yp + (size_t)(y0 + i) * Wd + x0) = make_float4(o[i][0], o[i][1], o[i][2], o[i][3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (y0 + i < H && x0 + j < Wd) yp[(size_t)(y0 + i) * Wd + x0 + j] = o[i][j];
+    }
+}
+
+// ---- the 36 GEMMs ----------------------------------------------------------------------------------
+// M[xi][k][t] = sum_c U[xi][c][k] * V[xi][c][t];  C % 16 == 0, Kp % 128 == 0, Tp % 128 == 0.
+// corr_argmax_fast_kernel's pipeline (see there for the measurements behind each choice): operand tiles HBM/L2 -> LDS by
+// global_load_lds_dwordx4 three stages ahead in a 4-slot ring, counted vmcnt + raw s_barrier per stage, a wave owns the
+// 32x32 sub-tiles {wm*32, +64} x {wn*32, +64} so that its two A (B) fragments of a k-step are ONE ds_read2st64_b32.
+__global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* __restrict__ U, const float* __restrict__ V, int C, int Kp, int Tp,
+                                                                  int ktiles, int ttiles, float* __restrict__ Mo)
+{
+    __shared__ __attribute__((aligned(16))) float lds[WG_NBUF * 2 * WG_BK * WG_BM];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // all tiles of one xi (they share U[xi] and V[xi]) get consecutive logical ids -> one XCD's L2
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_xi = ktiles * ttiles;
+    const int xi = L / per_xi, rem = L - xi * per_xi;
+    const int kt = rem % ktiles, tt = rem / ktiles;
+    const int k0 = kt * WG_BM, t0 = tt * WG_BN;
+    const float* A = U + (size_t)xi * C * Kp;
+    const float* Bm = V + (size_t)xi * C * Tp;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nstage = C / WG_BK;
+    constexpr int NP = WG_BK / 4;                         // DMA pieces (1 KiB = 2 rows) per wave per stage: 2 of A, 2 of B
+    const int dma_row = lane >> 5, dma_col = (lane & 31) * 4;
+    auto dma_piece = [&](int s, int p) {
+        const bool isA = p < NP / 2;
+        const int pair = wave + 4 * (isA ? p : p - NP / 2);
+        const int slot = (s & (WG_NBUF - 1)) * (2 * WG_BK * WG_BM) + (isA ? 0 : WG_BK * WG_BM) + pair * 2 * WG_BM;
+        const size_t row = (size_t)s * WG_BK + 2 * pair + dma_row;
+        const float* g = isA ? (A + row * Kp + k0 + dma_col) : (Bm + row * Tp + t0 + dma_col);
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)&lds[slot], 16, 0, 0);
+    };
+    auto wait_stage = [&](int younger) {
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dma_piece(0, p);
+    if (nstage > 1) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dma_piece(1, p);
+    }
+    if (nstage > 2) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dma_piece(2, p);
+    }
+    wait_stage(min(2, nstage - 1));
+    __builtin_amdgcn_s_barrier();
+
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & (WG_NBUF - 1);
+        const bool prefetch = s + 3 < nstage;
+        const float* ta = lds + (size_t)cur * (2 * WG_BK * WG_BM) + h * WG_BM + wm * 32 + r;
+        const float* tb = lds + (size_t)cur * (2 * WG_BK * WG_BM) + WG_BK * WG_BM + h * WG_BM + wn * 32 + r;
+        float fa0[3], fa1[3], fb0[3], fb1[3];
+        fa0[0] = ta[0]; fa1[0] = ta[64]; fb0[0] = tb[0]; fb1[0] = tb[64];
+#pragma unroll
+        for (int kk = 0; kk < WG_BK / 2; ++kk) {
+            const int cs = kk % 3, nx = (kk + 1) % 3;
+            if (kk + 1 < WG_BK / 2) {
+                const int ro = (kk + 1) * 2 * WG_BM;
+                fa0[nx] = ta[ro]; fa1[nx] = ta[ro + 64]; fb0[nx] = tb[ro]; fb1[nx] = tb[ro + 64];
+            }
+            if (prefetch && (kk % ((WG_BK / 2) / NP)) == 0) dma_piece(s + 3, kk / ((WG_BK / 2) / NP));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb0[cs], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb1[cs], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cs], fb0[cs], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cs], fb1[cs], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wait_stage(min(s + 3, nstage - 1) - (s + 1));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    float* out = Mo + (size_t)xi * Kp * Tp;
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int t = t0 + wn * 32 + jn * 64 + r;
+#pragma unroll
+        for (int im = 0; im < 2; ++im)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * 32 + im * 64 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                out[(size_t)k * Tp + t] = acc[im][jn][e];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct WinoPlan { int TY, TX, T, Tp, Kp; size_t u_floats, v_floats, m_floats, total_bytes; };
+
+static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p)
+{
+    if (C % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "winograd: %d reduction channels are not a multiple of %d", C, WG_BK);
+    p->TY = (H + 3) / 4; p->TX = (W + 3) / 4;
+    p->T = B * p->TY * p->TX;
+    p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;
+    p->Kp = (K + WG_BM - 1) / WG_BM * WG_BM;
+    p->u_floats = (size_t)36 * C * p->Kp;
+    p->v_floats = (size_t)36 * C * p->Tp;
+    p->m_floats = (size_t)36 * p->Kp * p->Tp;
+    p->total_bytes = align_up(p->u_floats * 4, 256) + align_up(p->v_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
+    return IPSR_OK;
+}
+
+size_t winograd_ws_bytes(int B, int C, int K, int H, int W)
+{
+    WinoPlan p;
+    if (wino_plan(B, C, K, H, W, &p) != IPSR_OK) return 0;
+    return p.total_bytes;
+}
+
+// y[B,K,H,W] = conv3x3(x[B,C,H,W]) with weight element (c, k, r, s) at w[c*sc + k*sm + r*3 + s], taps flipped when `flip`.
+int launch_winograd(const float* x, const float* w, float* y, int B, int C, int K, int H, int W, long sc, long sm, int flip,
+                    void* ws, size_t ws_bytes, hipStream_t st)
+{
+    WinoPlan p;
+    if (int rc = wino_plan(B, C, K, H, W, &p)) return rc;
+    if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    Carver cv(ws, ws_bytes);
+    float* U = cv.take<float>(p.u_floats);
+    float* V = cv.take<float>(p.v_floats);
+    float* Mo = cv.take<float>(p.m_floats);
+    wino_filter_kernel<<<dim3(cdiv(p.Kp, 256), C), 256, 0, st>>>(w, C, K, p.Kp, sc, sm, flip, U);
+    wino_input_kernel<<<dim3(cdiv(p.Tp, 256), C), 256, 0, st>>>(x, B, C, H, W, p.TY, p.TX, p.Tp, V);
+    if (int rc = check_launch("wino_input_kernel")) return rc;
+    const int ktiles = p.Kp / WG_BM, ttiles = p.Tp / WG_BN;
+    wino_gemm_kernel<<<36 * ktiles * ttiles, WG_THREADS, 0, st>>>(U, V, C, p.Kp, p.Tp, ktiles, ttiles, Mo);
+    if (int rc = check_launch("wino_gemm_kernel")) return rc;
+    wino_output_kernel<<<dim3(cdiv(p.T, 256), K), 256, 0, st>>>(Mo, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
+    return check_launch("wino_output_kernel");
+}
+
+}  // namespace ipsr
+
+using namespace ipsr;
+
+extern "C" {
+
+size_t ipsr_conv3x3_winograd_workspace_bytes(int op, int B, int Cin, int H, int W, int Cout)
+{
+    if (op < 0 || op > 3 || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
+    const bool fwd = op == 0 || op == 2;
+    return winograd_ws_bytes(B, fwd ? Cin : Cout, fwd ? Cout : Cin, H, W);
+}
+
+int ipsr_conv3x3_winograd(int op, const float* in, const float* weight, float* out, int B, int Cin, int H, int W, int Cout,
+                          void* ws, size_t ws_bytes, void* stream)
+{
+    if (!in || !weight || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd: null pointer");
+    if (op < 0 || op > 3 || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd: bad argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd: out / workspace must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // k3 s1 p1: input and output have the same extent.  C = reduction channels, K = produced channels.
+    switch (op) {
+        case 0:      // Conv2d forward: weight [Cout][Cin][3][3]: (c, k) at c*9 + k*Cin*9
+            return launch_winograd(in, weight, out, B, Cin, Cout, H, W, 9, (long)Cin * 9, 0, ws, ws_bytes, st);
+        case 1:      // Conv2d backward-data: dx = conv(dy, flipped w), reduction over Cout: (c=co, k=ci) at co*Cin*9 + ci*9
+            return launch_winograd(in, weight, out, B, Cout, Cin, H, W, (long)Cin * 9, 9, 1, ws, ws_bytes, st);
+        case 2:      // ConvTranspose2d forward: weight [Cin][Cout][3][3], flipped: (c=ci, k=co) at ci*Cout*9 + co*9
+            return launch_winograd(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, ws, ws_bytes, st);
+        default:     // ConvTranspose2d backward-data: dx = conv(dy, w as [ci][co]), reduction over Cout: (c=co, k=ci) at co*9 + ci*Cout*9
+            return launch_winograd(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, ws, ws_bytes, st);
+    }
+}
+
+}  // extern "C"

@@ -96,9 +96,8 @@ def _act_of(m):
 
 
 def _conv_no_bias(m, x):
-    if isinstance(m, nn.ConvTranspose2d):
-        return F.conv_transpose2d(x, m.weight, None, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
-    return F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+    from .hipconv import conv_nobias
+    return conv_nobias(m, x)
 
 
 def _plain_conv(m):

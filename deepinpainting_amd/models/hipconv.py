@@ -1,0 +1,134 @@
+"""Convolutions of the four nets and of VGG16 on the hand-written HIP kernels, behind nn.Conv2d /
+nn.ConvTranspose2d modules whose parameters, names and state_dict keys are untouched (models/networks.py:220-259,
+404-432, 470-495, 510-515; models/vgg16.py:9-21).
+
+Three engines per (operation, geometry), chosen by `select()` from measurements on MI355X at the step's shapes
+(tools/bench_hipconv.py -> profiles/r02_hipconv_*.txt):
+
+  "winograd"  csrc/winograd.hip   k3 s1 p1 forward / backward-data of Conv2d and ConvTranspose2d, F(4x4,3x3) on fp32 MFMA:
+                                  2.0-2.4x MIOpen's F(2x2,3x3) assembly from 16x16 maps and 128 channels up
+  "direct"    csrc/conv_gemm.hip  one-launch implicit GEMM, NCHW in/out (every k3/k4, stride 1/2, dilated and transposed
+                                  geometry of the nets, forward and backward-data): at parity with MIOpen (~100 TF), used
+                                  where it measured >= 7 % faster
+  "miopen"    torch               everything else, and every weight gradient
+
+`IPSR_CONV_ENGINE=miopen|direct|winograd|auto` (default auto) forces one engine wherever it is implemented — for the
+per-engine parity tests and for A/B timing.  bf16 autocast and non-contiguous / non-fp32 inputs always take MIOpen.
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+_FORCE = None          # test hook: overrides the environment
+
+
+def _mode():
+    return _FORCE or os.environ.get("IPSR_CONV_ENGINE", "auto")
+
+
+def select(op, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """-> "winograd" | "direct" | "miopen" for one convolution call.  (Cin, H, W) = the module's input, as in ipsr_conv2d."""
+    mode = _mode()
+    fwd = op in (ops.CONV_FWD, ops.CONVT_FWD)
+    cred, kout = (Cin, Cout) if fwd else (Cout, Cin)            # reduction / produced channels of this operation
+    wino_ok = k == 3 and stride == 1 and pad == 1 and dil == 1 and cred % 16 == 0
+    if mode == "miopen":
+        return "miopen"
+    if mode == "winograd":
+        return "winograd" if wino_ok else "miopen"
+    if mode == "direct":
+        return "direct" if ops.conv2d_supported(op, B, Cin, H, W, Cout, k, stride, pad, dil) else "miopen"
+    # auto: measured rules (MI355X, batch 8; profiles/r02_hipconv_k3.txt, r02_hipconv_all.txt)
+    if wino_ok and H * W >= 256 and max(cred, kout) >= 128 and min(cred, kout) >= 64:
+        return "winograd"
+    if k == 4 and stride == 2 and dil == 2 and op == ops.CONV_BWD_DATA and Cin >= 128 and 16 <= H <= 128:
+        return "direct"          # dilated 4x4 stride-2 input gradient: 8-12 % faster than MIOpen's f3x2_dilation2 + transposes
+    if k == 4 and stride == 2 and dil == 1 and op == ops.CONVT_BWD_DATA and Cin == 256 and Cout == 64:
+        return "direct"
+    return "miopen"
+
+
+class _HipConv(torch.autograd.Function):
+    """Bias-free Conv2d / ConvTranspose2d: forward and input gradient on the selected HIP engine, weight gradient on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, w, transposed, k, stride, pad, dil, eng_fwd):
+        B, Cin, H, W = x.shape
+        Cout = w.shape[1] if transposed else w.shape[0]
+        op = ops.CONVT_FWD if transposed else ops.CONV_FWD
+        xc = x.contiguous()
+        if eng_fwd == "winograd":
+            y = ops.conv3x3_winograd(op, xc, w, (B, Cin, H, W), Cout)
+        elif eng_fwd == "direct":
+            y = ops.conv2d(op, xc, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
+        else:
+            y = (F.conv_transpose2d(xc, w, None, stride, pad, 0, 1, dil) if transposed else F.conv2d(xc, w, None, stride, pad, dil))
+        ctx.save_for_backward(xc, w)
+        ctx.geom = (transposed, k, stride, pad, dil, Cout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        transposed, k, stride, pad, dil, Cout = ctx.geom
+        B, Cin, H, W = x.shape
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            op = ops.CONVT_BWD_DATA if transposed else ops.CONV_BWD_DATA
+            eng = select(op, B, Cin, H, W, Cout, k, stride, pad, dil)
+            if eng == "winograd":
+                dx = ops.conv3x3_winograd(op, dy, w, (B, Cin, H, W), Cout)
+            elif eng == "direct":
+                dx = ops.conv2d(op, dy, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
+                                                         [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return dx, dw, None, None, None, None, None, None
+
+
+def _geometry(m):
+    """(k, stride, pad, dil) of a module the kernels can express (square, symmetric, groups 1, no output padding) or None."""
+    ks, st, pd, dl = m.kernel_size, m.stride, m.padding, m.dilation
+    if m.groups != 1 or ks[0] != ks[1] or st[0] != st[1] or pd[0] != pd[1] or dl[0] != dl[1] or isinstance(pd, str):
+        return None
+    if isinstance(m, nn.ConvTranspose2d) and tuple(m.output_padding) != (0, 0):
+        return None
+    if getattr(m, "padding_mode", "zeros") != "zeros":
+        return None
+    return ks[0], st[0], pd[0], dl[0]
+
+
+def conv_nobias(m, x, weight=None):
+    """m(x) without the bias (the fused epilogue kernels add it): HIP engine where `select` says so, else MIOpen."""
+    w = m.weight if weight is None else weight
+    transposed = isinstance(m, nn.ConvTranspose2d)
+    g = _geometry(m)
+    if g is not None and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 \
+            and not torch.is_autocast_enabled():
+        k, stride, pad, dil = g
+        B, Cin, H, W = x.shape
+        Cout = w.shape[1] if transposed else w.shape[0]
+        op = ops.CONVT_FWD if transposed else ops.CONV_FWD
+        eng = select(op, B, Cin, H, W, Cout, k, stride, pad, dil)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+        if needs_grad:
+            # the backward may use a HIP engine even where the forward stays on MIOpen
+            bop = ops.CONVT_BWD_DATA if transposed else ops.CONV_BWD_DATA
+            beng = select(bop, B, Cin, H, W, Cout, k, stride, pad, dil) if x.requires_grad else "miopen"
+            if eng != "miopen" or beng != "miopen":
+                return _HipConv.apply(x, w, transposed, k, stride, pad, dil, eng)
+        elif eng == "winograd":
+            return ops.conv3x3_winograd(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout)
+        elif eng == "direct":
+            return ops.conv2d(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, k, stride, pad, dil)
+    if transposed:
+        return F.conv_transpose2d(x, w, None, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
+    return F.conv2d(x, w, None, m.stride, m.padding, m.dilation, m.groups)

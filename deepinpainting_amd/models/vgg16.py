@@ -83,12 +83,13 @@ class Vgg16(torch.nn.Module):
         separate pass), then ONE pass for bias + ReLU (+ the 2x2 max-pool when it follows) — ops.bias_act_ /
         ops.bias_relu_pool2, bit-identical to Conv2d(bias) -> ReLU(inplace) -> MaxPool2d."""
         from .. import ops
+        from .hipconv import conv_nobias
         mods = list(seq)
         i = 0
         while i < len(mods):
             m = mods[i]
             if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
-                y = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+                y = conv_nobias(m, x)                      # Winograd F(4x4,3x3) / MIOpen per shape (models/hipconv.py)
                 if i + 2 < len(mods) and isinstance(mods[i + 2], nn.MaxPool2d) and y.size(2) % 2 == 0 and y.size(3) % 2 == 0:
                     x = ops.bias_relu_pool2(y, m.bias)
                     i += 3

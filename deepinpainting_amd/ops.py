@@ -310,6 +310,69 @@ def bias_relu_pool2(x, bias):
     return y
 
 
+CONV_FWD, CONV_BWD_DATA, CONVT_FWD, CONVT_BWD_DATA = 0, 1, 2, 3
+
+
+def conv_out_dim(op, n, k, stride, pad, dil):
+    if op in (CONV_FWD, CONV_BWD_DATA):
+        return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    return (n - 1) * stride - 2 * pad + dil * (k - 1) + 1
+
+
+def conv2d_supported(op, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """True when ipsr_conv2d implements this geometry (its workspace query answers 0 otherwise)."""
+    return _lib.lib().ipsr_conv2d_workspace_bytes(op, B, Cin, H, W, Cout, k, stride, pad, dil) > 0
+
+
+def conv2d(op, inp, weight, in_shape, Cout, k, stride, pad, dil):
+    """The bias-free convolution kernels (include/ipsr_hip.h, ipsr_conv2d).  `in_shape` = (B, Cin, H, W) of the MODULE's input
+    whatever the op; `inp` is x for the forward ops and dy for the backward-data ops.  Returns y / dx (fp32, contiguous)."""
+    B, Cin, H, W = in_shape
+    Ho, Wo = conv_out_dim(op, H, k, stride, pad, dil), conv_out_dim(op, W, k, stride, pad, dil)
+    inp = _req(inp, torch.float32, "conv input")
+    weight = _req(weight, torch.float32, "conv weight")
+    fwd = op in (CONV_FWD, CONVT_FWD)
+    want_in = (B, Cin, H, W) if fwd else (B, Cout, Ho, Wo)
+    want_w = (Cout, Cin, k, k) if op in (CONV_FWD, CONV_BWD_DATA) else (Cin, Cout, k, k)
+    if tuple(inp.shape) != want_in or tuple(weight.shape) != want_w:
+        raise RuntimeError("conv2d op %d: input %s / weight %s do not match %s / %s" % (op, tuple(inp.shape), tuple(weight.shape), want_in, want_w))
+    out = torch.empty((B, Cout, Ho, Wo) if fwd else (B, Cin, H, W), dtype=torch.float32, device=inp.device)
+    L = _lib.lib()
+    nbytes = L.ipsr_conv2d_workspace_bytes(op, B, Cin, H, W, Cout, k, stride, pad, dil)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv2d: op %d with k=%d stride=%d pad=%d dil=%d, Cin=%d Cout=%d is not implemented: %s"
+                                  % (op, k, stride, pad, dil, Cin, Cout, L.ipsr_last_error().decode("utf-8", "replace")))
+    ws = _workspace(nbytes, inp.device)
+    _lib.check(L.ipsr_conv2d(op, inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout, k, stride, pad, dil,
+                             ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv2d")
+    return out
+
+
+def winograd_supported(op, B, Cin, H, W, Cout):
+    return _lib.lib().ipsr_conv3x3_winograd_workspace_bytes(op, B, Cin, H, W, Cout) > 0
+
+
+def conv3x3_winograd(op, inp, weight, in_shape, Cout):
+    """k3 s1 p1 convolution / transposed convolution / their input gradients by Winograd F(4x4,3x3) (ipsr_conv3x3_winograd)."""
+    B, Cin, H, W = in_shape
+    inp = _req(inp, torch.float32, "conv input")
+    weight = _req(weight, torch.float32, "conv weight")
+    fwd = op in (CONV_FWD, CONVT_FWD)
+    want_in = (B, Cin, H, W) if fwd else (B, Cout, H, W)
+    want_w = (Cout, Cin, 3, 3) if op in (CONV_FWD, CONV_BWD_DATA) else (Cin, Cout, 3, 3)
+    if tuple(inp.shape) != want_in or tuple(weight.shape) != want_w:
+        raise RuntimeError("conv3x3_winograd op %d: input %s / weight %s do not match %s / %s" % (op, tuple(inp.shape), tuple(weight.shape), want_in, want_w))
+    out = torch.empty((B, Cout, H, W) if fwd else (B, Cin, H, W), dtype=torch.float32, device=inp.device)
+    L = _lib.lib()
+    nbytes = L.ipsr_conv3x3_winograd_workspace_bytes(op, B, Cin, H, W, Cout)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv3x3_winograd: op %d Cin=%d Cout=%d is not implemented" % (op, Cin, Cout))
+    ws = _workspace(nbytes, inp.device)
+    _lib.check(L.ipsr_conv3x3_winograd(op, inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout,
+                                       ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv3x3_winograd")
+    return out
+
+
 def innercos_loss(x, cuse, mask_f32, target, strength):
     """K9.  x [B,Cx,h,w] (only the first `cuse` channels are read), target [B,cuse,h,w] -> loss [] fp32."""
     x = _req(x, torch.float32, "in_data")

@@ -178,6 +178,32 @@ int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, con
 int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16,
                            void* dx, float* dbias_p, void* stream);
 
+/* ---- convolutions of the surrounding nets ---------------------------------------------------------------
+ * replaces nn.Conv2d / nn.ConvTranspose2d (bias-free part; the bias rides in the fused epilogues above) of the U-Nets,
+ * the PatchGAN discriminators and the VGG16 feature net — models/networks.py:220-259, 404-432, 470-495, 510-515,
+ * models/vgg16.py:9-21 — and their input gradients, as one implicit GEMM per call on the fp32 matrix cores, NCHW in and out.
+ *   op 0  Conv2d forward           in = x  [B,Cin,H,W]      weight [Cout,Cin,k,k]   out = y  [B,Cout,Ho,Wo]
+ *   op 1  Conv2d backward-data     in = dy [B,Cout,Ho,Wo]   weight [Cout,Cin,k,k]   out = dx [B,Cin,H,W]
+ *   op 2  ConvTranspose2d forward  in = x  [B,Cin,H,W]      weight [Cin,Cout,k,k]   out = y  [B,Cout,Ho,Wo]
+ *   op 3  ConvTranspose2d bwd-data in = dy [B,Cout,Ho,Wo]   weight [Cin,Cout,k,k]   out = dx [B,Cin,H,W]
+ * (Cin, H, W) always describe the module's INPUT; Ho = (H + 2*pad - dil*(k-1) - 1)/stride + 1 for Conv2d and
+ * (H-1)*stride - 2*pad + dil*(k-1) + 1 for ConvTranspose2d (output_padding 0, groups 1, square kernels k <= 4).
+ * Supported tap sets: 9 or 16 taps (k = 3, 4) with any stride for the direct forms (op 0, 3) and stride 1 or 2 for the
+ * transposed forms (op 1, 2); the reduction channel count must be even for k = 3.  Anything else -> IPSR_ERR_UNSUPPORTED
+ * (the Python wrapper then leaves that layer on MIOpen).  fp32, summation order fixed (deterministic, no atomics). */
+size_t ipsr_conv2d_workspace_bytes(int op, int B, int Cin, int H, int W, int Cout, int k, int stride, int pad, int dil);
+int ipsr_conv2d(int op, const float* in, const float* weight, float* out, int B, int Cin, int H, int W, int Cout,
+                int k, int stride, int pad, int dil, void* ws, size_t ws_bytes, void* stream);
+
+/* The 3x3 / stride 1 / pad 1 members of that family (every VGG16 convolution, `downconv_3` / `upconv_3` of every netG level)
+ * by Winograd F(4x4,3x3): 4x fewer matrix-core flops than the direct form at 2.25x the activation traffic; pays from ~128
+ * channels up.  Same `op` codes and tensor roles as ipsr_conv2d (k = 3, stride = 1, pad = 1, dil = 1 implied).  The
+ * reduction channel count (Cin for op 0/2, Cout for op 1/3) must be a multiple of 16.  fp32; the transforms use the
+ * standard points (0, +-1, +-2, inf): error ~4e-6 of the output scale at 512 channels. */
+size_t ipsr_conv3x3_winograd_workspace_bytes(int op, int B, int Cin, int H, int W, int Cout);
+int ipsr_conv3x3_winograd(int op, const float* in, const float* weight, float* out, int B, int Cin, int H, int W, int Cout,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
  * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.

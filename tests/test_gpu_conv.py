@@ -1,0 +1,178 @@
+"""SURVEY §8 (f)1 — the hand-written convolution kernels (csrc/conv_gemm.hip implicit GEMM, csrc/winograd.hip F(4x4,3x3))
+against an fp64 torch convolution, per geometry of the reference's nets (models/networks.py:220-259, 404-432, 470-495,
+510-515; models/vgg16.py:9-21), through the C-ABI (ops.conv2d / ops.conv3x3_winograd) and through the module path
+(models/hipconv.py: forward, input gradient, weight gradient)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (kind, Cin, H, W, Cout, k, stride, pad, dil): every geometry of the four nets + VGG, at sizes an fp64 CPU convolution
+# finishes in well under a second; odd extents, channel counts that are not tile multiples, 1x1 maps, batch tails
+GEOMS = [
+    ("conv", 32, 16, 16, 48, 3, 1, 1, 1),          # downconv_3 / VGG
+    ("conv", 130, 9, 13, 70, 3, 1, 1, 1),          # ragged: Cin not a multiple of 16 (direct only), odd map
+    ("conv", 16, 20, 20, 24, 4, 2, 1, 1),          # netP / netD / netF down convolution
+    ("conv", 16, 21, 19, 24, 4, 2, 1, 1),          # odd input extents
+    ("conv", 24, 16, 16, 24, 4, 2, 3, 2),          # netG dilated down convolution
+    ("conv", 24, 6, 6, 24, 4, 2, 3, 2),
+    ("conv", 24, 2, 2, 24, 4, 2, 3, 2),            # innermost level
+    ("conv", 40, 12, 12, 36, 4, 1, 1, 1),          # netD stride-1 4x4 (32 -> 31)
+    ("conv", 256, 9, 9, 1, 4, 1, 1, 1),            # netD's last convolution: one output channel
+    ("conv", 512, 2, 2, 512, 4, 2, 1, 1),          # netP innermost: 2x2 -> 1x1, long reduction (split-K)
+    ("convT", 32, 16, 16, 48, 3, 1, 1, 1),         # upconv_3
+    ("convT", 64, 5, 7, 20, 3, 1, 1, 1),
+    ("convT", 16, 10, 10, 24, 4, 2, 1, 1),         # netP / netG up convolution
+    ("convT", 16, 7, 9, 24, 4, 2, 1, 1),
+    ("convT", 512, 1, 1, 64, 4, 2, 1, 1),          # innermost: 1x1 -> 2x2
+]
+
+
+def _ref64(kind, x, w, dy, st, pad, dil):
+    """fp64 CPU forward and input gradient."""
+    xd = x.double().cpu().requires_grad_(True)
+    wd = w.double().cpu().requires_grad_(True)
+    y = F.conv_transpose2d(xd, wd, None, st, pad, 0, 1, dil) if kind == "convT" else F.conv2d(xd, wd, None, st, pad, dil)
+    dx, dw = torch.autograd.grad(y, (xd, wd), dy.double().cpu())
+    return y.detach(), dx, dw
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("geom", GEOMS, ids=lambda g: "%s_c%d_%dx%d_k%d_%ds%dp%dd%d" % (g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8]))
+def test_direct_implicit_gemm_vs_fp64(geom):
+    """conv_gemm.hip: forward and backward-data of every geometry within 2e-5 of fp64 (fp32 accumulation of <= 8192 terms)."""
+    from deepinpainting_amd import ops
+    kind, Cin, H, W, Cout, k, st, pad, dil = geom
+    tr = kind == "convT"
+    B = 3
+    g = torch.Generator().manual_seed(Cin * 1000 + H)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), generator=g) * 0.1).cuda()
+    Ho, Wo = ops.conv_out_dim(ops.CONVT_FWD if tr else ops.CONV_FWD, H, k, st, pad, dil), ops.conv_out_dim(ops.CONVT_FWD if tr else ops.CONV_FWD, W, k, st, pad, dil)
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g).cuda()
+    y64, dx64, _ = _ref64(kind, x, w, dy, st, pad, dil)
+    fop, bop = (ops.CONVT_FWD, ops.CONVT_BWD_DATA) if tr else (ops.CONV_FWD, ops.CONV_BWD_DATA)
+    assert ops.conv2d_supported(fop, B, Cin, H, W, Cout, k, st, pad, dil) and ops.conv2d_supported(bop, B, Cin, H, W, Cout, k, st, pad, dil)
+    y = ops.conv2d(fop, x, w, (B, Cin, H, W), Cout, k, st, pad, dil)
+    dx = ops.conv2d(bop, dy, w, (B, Cin, H, W), Cout, k, st, pad, dil)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(y64.shape) and tuple(dx.shape) == tuple(dx64.shape)
+    assert _rel(y, y64) <= 2e-5
+    assert _rel(dx, dx64) <= 2e-5
+    # deterministic: the same call gives the same bits (fixed summation order, split-K reduced in order)
+    assert torch.equal(y, ops.conv2d(fop, x, w, (B, Cin, H, W), Cout, k, st, pad, dil))
+
+
+@pytest.mark.parametrize("kind,Cin,H,W,Cout", [("conv", 32, 16, 16, 48), ("conv", 128, 32, 32, 128), ("conv", 64, 9, 13, 48),
+                                               ("conv", 512, 16, 16, 256), ("convT", 32, 16, 16, 48), ("convT", 256, 12, 20, 64),
+                                               ("conv", 16, 4, 4, 16), ("conv", 48, 6, 10, 144)])
+def test_winograd_f4x4_3x3_vs_fp64(kind, Cin, H, W, Cout):
+    """winograd.hip: k3 s1 p1 forward and backward-data, Conv2d and ConvTranspose2d, within 1e-4 of fp64 — the transforms
+    amplify rounding (coefficients up to 8, 1/24): measured 1e-5..3e-5 of the output scale; extents that are not multiples
+    of 4 and tile counts that are not multiples of 128 included."""
+    from deepinpainting_amd import ops
+    tr = kind == "convT"
+    B = 2
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn((Cin, Cout, 3, 3) if tr else (Cout, Cin, 3, 3), generator=g) * 0.1).cuda()
+    dy = torch.randn(B, Cout, H, W, generator=g).cuda()
+    y64, dx64, _ = _ref64(kind, x, w, dy, 1, 1, 1)
+    fop, bop = (ops.CONVT_FWD, ops.CONVT_BWD_DATA) if tr else (ops.CONV_FWD, ops.CONV_BWD_DATA)
+    y = ops.conv3x3_winograd(fop, x, w, (B, Cin, H, W), Cout)
+    dx = ops.conv3x3_winograd(bop, dy, w, (B, Cin, H, W), Cout)
+    torch.cuda.synchronize()
+    assert _rel(y, y64) <= 1e-4
+    assert _rel(dx, dx64) <= 1e-4
+    assert not ops.winograd_supported(fop, B, 24, H, W, Cout)          # reduction channels must be a multiple of 16: refuses
+
+
+@pytest.mark.parametrize("engine", ["direct", "winograd", "auto"])
+def test_module_path_forward_and_gradients(engine):
+    """models/hipconv.py: Conv2d / ConvTranspose2d modules through the dispatcher with one engine forced — output, input
+    gradient and weight gradient against fp64, and against the plain torch module on the same weights."""
+    from deepinpainting_amd.models import hipconv
+    torch.manual_seed(3)
+    cases = [(nn.Conv2d(64, 128, 3, 1, 1), 16, 16), (nn.ConvTranspose2d(128, 64, 3, 1, 1), 16, 16),
+             (nn.Conv2d(32, 32, 4, 2, 3, dilation=2), 16, 16), (nn.ConvTranspose2d(32, 16, 4, 2, 1), 8, 8), (nn.Conv2d(16, 32, 4, 2, 1), 16, 16)]
+    hipconv._FORCE = engine
+    try:
+        for m, H, W in cases:
+            m = m.cuda()
+            x = torch.randn(2, m.in_channels, H, W, device="cuda", requires_grad=True)
+            y = hipconv.conv_nobias(m, x)
+            dy = torch.randn_like(y)
+            dx, dw = torch.autograd.grad(y, (x, m.weight), dy)
+            kind = "convT" if isinstance(m, nn.ConvTranspose2d) else "conv"
+            y64, dx64, dw64 = _ref64(kind, x.detach(), m.weight.detach(), dy, m.stride[0], m.padding[0], m.dilation[0])
+            assert _rel(y, y64) <= 1e-4 and _rel(dx, dx64) <= 1e-4 and _rel(dw, dw64) <= 1e-4, (engine, m)
+            with torch.no_grad():
+                y2 = hipconv.conv_nobias(m, x.detach())
+            assert torch.equal(y2, y.detach())
+    finally:
+        hipconv._FORCE = None
+
+
+def test_dispatcher_rules_and_refusals():
+    from deepinpainting_amd import ops
+    from deepinpainting_amd.models import hipconv
+    sel = hipconv.select
+    assert sel(ops.CONV_FWD, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd"          # VGG conv4_x / netG level 32x32
+    assert sel(ops.CONVT_BWD_DATA, 8, 1024, 32, 32, 256, 3, 1, 1, 1) == "winograd"
+    assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 3, 1, 1, 1) == "miopen"            # 64 -> 64 at 256x256: traffic-bound, MIOpen wins
+    assert sel(ops.CONV_FWD, 8, 3, 256, 256, 64, 3, 1, 1, 1) == "miopen"             # 3 input channels
+    assert sel(ops.CONV_FWD, 8, 512, 4, 4, 512, 3, 1, 1, 1) == "miopen"              # tiny maps
+    assert sel(ops.CONV_BWD_DATA, 8, 512, 32, 32, 512, 4, 2, 3, 2) == "direct"
+    assert sel(ops.CONV_FWD, 8, 256, 32, 32, 512, 4, 2, 1, 1) == "miopen"
+    with pytest.raises(NotImplementedError):
+        ops.conv2d(ops.CONV_FWD, torch.zeros(1, 3, 8, 8, device="cuda"), torch.zeros(4, 3, 3, 3, device="cuda"), (1, 3, 8, 8), 4, 3, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(ops.CONV_FWD, torch.zeros(1, 4, 8, 8, device="cuda"), torch.zeros(4, 8, 3, 3, device="cuda"), (1, 4, 8, 8), 4, 3, 1, 1, 1)
+
+
+def test_vgg_and_unet_outputs_unchanged_by_the_engines():
+    """The whole VGG16 feature pass and a netG forward/backward with the HIP engines against the same nets on MIOpen only:
+    features within 1e-4 of their scale, parameter gradients within 1e-3 (fp32 summation-order noise through ~30 layers)."""
+    import contextlib
+    import io
+    from deepinpainting_amd.models import hipconv, networks
+    from deepinpainting_amd.models.vgg16 import Vgg16
+    from deepinpainting_amd.options import Option
+    vgg = Vgg16().cuda().eval()
+    x = torch.rand(2, 3, 128, 128, device="cuda") * 2 - 1
+    outs = {}
+    for eng in ("miopen", "auto"):
+        hipconv._FORCE = eng
+        try:
+            with torch.no_grad():
+                outs[eng] = vgg(x)
+        finally:
+            hipconv._FORCE = None
+    for a, b in zip(outs["auto"], outs["miopen"]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+    opt = Option(gpu_ids=[0], use_dropout=False)
+    mask = torch.zeros(1, 1, 256, 256, dtype=torch.bool, device="cuda")
+    mask[:, :, 64:192, 64:192] = 1
+    with contextlib.redirect_stdout(io.StringIO()):
+        netP = networks.define_G(3, 3, 64, 'unet_256', opt, mask, 'instance', False, 'normal', [0], 0.02)[0]
+    img = torch.rand(2, 3, 256, 256, device="cuda") * 2 - 1
+    grads = {}
+    for eng in ("miopen", "direct"):
+        hipconv._FORCE = eng
+        try:
+            netP.zero_grad()
+            netP(img).square().mean().backward()
+            grads[eng] = [p.grad.clone() for p in netP.parameters()]
+        finally:
+            hipconv._FORCE = None
+    # (a conv bias in front of an InstanceNorm has an exactly-zero true gradient: what is left there is rounding noise of the
+    # size of the largest gradients' last bits, hence the global term)
+    gmax = max(float(b.abs().max()) for b in grads["miopen"])
+    for a, b in zip(grads["direct"], grads["miopen"]):
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-6 * gmax

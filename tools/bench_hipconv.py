@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Per-shape check + timing of the hand-written implicit-GEMM convolutions (csrc/conv_gemm.hip) against MIOpen, for every
+distinct Conv2d / ConvTranspose2d geometry of the training step at BASELINE config 2 (batch 8, 256x256, fp32).
+
+    python tools/bench_hipconv.py [--batch 8] [--quick] > gpurun_out/hipconv.txt
+
+For each shape and op (forward, backward-data): max |err| of the HIP kernel and of MIOpen against an fp64 CPU convolution of
+sample 0, and the time of both (median of 10, HIP events).  `use` marks where the HIP kernel is the faster one.
+"""
+import argparse
+import os
+import statistics
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: F401  (private MIOpen db copy)
+from deepinpainting_amd import ops
+
+# (kind, Cin, H, Cout, k, stride, pad, dil) — the step's layers (profiles/r01_conv_layer_table.txt)
+SHAPES = [
+    ("conv", 512, 32, 512, 3, 1, 1, 1), ("conv", 256, 64, 256, 3, 1, 1, 1), ("conv", 64, 256, 64, 3, 1, 1, 1),
+    ("conv", 128, 128, 128, 3, 1, 1, 1), ("conv", 64, 128, 128, 3, 1, 1, 1), ("conv", 128, 64, 256, 3, 1, 1, 1),
+    ("conv", 256, 32, 512, 3, 1, 1, 1), ("conv", 256, 32, 512, 4, 1, 1, 1),
+    ("conv", 256, 32, 512, 4, 2, 1, 1), ("conv", 64, 128, 128, 4, 2, 1, 1), ("conv", 128, 64, 256, 4, 2, 1, 1),
+    ("conv", 512, 16, 512, 4, 2, 1, 1), ("conv", 512, 8, 512, 4, 2, 1, 1), ("conv", 512, 4, 512, 4, 2, 1, 1),
+    ("conv", 512, 2, 512, 4, 2, 1, 1),
+    ("conv", 64, 256, 64, 4, 2, 3, 2), ("conv", 128, 128, 128, 4, 2, 3, 2), ("conv", 256, 64, 256, 4, 2, 3, 2),
+    ("conv", 512, 32, 512, 4, 2, 3, 2), ("conv", 512, 16, 512, 4, 2, 3, 2), ("conv", 512, 8, 512, 4, 2, 3, 2),
+    ("conv", 512, 4, 512, 4, 2, 3, 2), ("conv", 512, 2, 512, 4, 2, 3, 2),
+    ("conv", 512, 16, 512, 3, 1, 1, 1), ("conv", 512, 8, 512, 3, 1, 1, 1), ("conv", 512, 4, 512, 3, 1, 1, 1),
+    ("conv", 512, 2, 512, 3, 1, 1, 1), ("conv", 6, 256, 64, 3, 1, 1, 1),
+    ("convT", 256, 128, 64, 3, 1, 1, 1), ("convT", 512, 64, 128, 3, 1, 1, 1), ("convT", 1024, 32, 256, 3, 1, 1, 1),
+    ("convT", 1024, 16, 512, 3, 1, 1, 1), ("convT", 1024, 8, 512, 3, 1, 1, 1), ("convT", 1024, 4, 512, 3, 1, 1, 1),
+    ("convT", 1024, 2, 512, 3, 1, 1, 1),
+    ("convT", 64, 128, 64, 4, 2, 1, 1), ("convT", 1024, 16, 256, 4, 2, 1, 1), ("convT", 128, 64, 128, 4, 2, 1, 1),
+    ("convT", 512, 16, 512, 4, 2, 1, 1), ("convT", 256, 64, 64, 4, 2, 1, 1), ("convT", 512, 32, 128, 4, 2, 1, 1),
+    ("convT", 256, 32, 256, 4, 2, 1, 1), ("convT", 1024, 8, 512, 4, 2, 1, 1), ("convT", 512, 8, 512, 4, 2, 1, 1),
+    ("convT", 1024, 4, 512, 4, 2, 1, 1), ("convT", 512, 4, 512, 4, 2, 1, 1), ("convT", 1024, 2, 512, 4, 2, 1, 1),
+    ("convT", 512, 2, 512, 4, 2, 1, 1), ("convT", 512, 1, 512, 4, 2, 1, 1),
+]
+K3 = [s_ for s_ in SHAPES if s_[4] == 3]
+QUICK = [("conv", 512, 32, 512, 3, 1, 1, 1), ("conv", 256, 32, 512, 4, 2, 1, 1), ("conv", 512, 32, 512, 4, 2, 3, 2),
+         ("conv", 512, 8, 512, 4, 2, 1, 1), ("convT", 1024, 32, 256, 3, 1, 1, 1), ("convT", 512, 32, 128, 4, 2, 1, 1),
+         ("convT", 512, 4, 512, 4, 2, 1, 1)]
+
+
+def timed(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return statistics.median(ts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--k3", action="store_true", help="only the 3x3 stride-1 shapes (the Winograd candidates)")
+    args = ap.parse_args()
+    B = args.batch
+    torch.manual_seed(0)
+    print("%-5s %-16s %-14s %-7s | %-4s %9s %9s %7s %7s | %9s %9s  %s" % ("kind", "input", "weight", "s/p/d", "op", "hip ms", "miopen ms", "hip TF", "mio TF", "hip err", "mio err", "use"))
+    tot_h = tot_m = tot_best = 0.0
+    for kind, Cin, H, Cout, k, st, pad, dil in (QUICK if args.quick else (K3 if args.k3 else SHAPES)):
+        tr = kind == "convT"
+        x = torch.randn(B, Cin, H, H, device="cuda")
+        w = torch.randn((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device="cuda") * 0.05
+        f = (lambda a, ww: F.conv_transpose2d(a, ww, None, st, pad, 0, 1, dil)) if tr else (lambda a, ww: F.conv2d(a, ww, None, st, pad, dil))
+        with torch.no_grad():
+            y = f(x, w)
+        Ho = y.shape[2]
+        dy = torch.randn_like(y)
+        flops = 2.0 * B * Cin * Cout * k * k * (H * H if tr else Ho * Ho)
+        cb = torch.ops.aten.convolution_backward
+        cargs = (dy, x, w, None, [st, st], [pad, pad], [dil, dil], tr, [0, 0], 1)
+        for opname, op in (("fwd", ops.CONVT_FWD if tr else ops.CONV_FWD), ("bwdD", ops.CONVT_BWD_DATA if tr else ops.CONV_BWD_DATA)):
+            fwd = opname == "fwd"
+            mio = (lambda: f(x, w)) if fwd else (lambda: cb(*cargs, [True, False, False])[0])
+            if not ops.conv2d_supported(op, B, Cin, H, H, Cout, k, st, pad, dil):
+                with torch.no_grad():
+                    tm = timed(mio)
+                print("%-5s %-16s %-14s %-7s | %-4s %9s %9.4f %7s %7.1f | unsupported -> MIOpen" % (
+                    kind, "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), "%d/%d/%d" % (st, pad, dil), opname, "-", tm, "-", flops / tm / 1e9))
+                tot_m += tm; tot_best += tm; tot_h += tm
+                continue
+            hip = (lambda: ops.conv2d(op, x if fwd else dy, w, (B, Cin, H, H), Cout, k, st, pad, dil))
+            with torch.no_grad():
+                got, ref32 = hip(), mio()
+                eh = em = float("nan")
+                if not args.no_check:
+                    xd, wd, dyd = x[:1].double().cpu().requires_grad_(True), w.double().cpu(), dy[:1].double().cpu()
+                    with torch.enable_grad():
+                        yd = f(xd, wd)
+                        want = yd.detach() if fwd else torch.autograd.grad(yd, xd, dyd)[0]
+                    scale = float(want.abs().max())
+                    eh = float((got[:1].double().cpu() - want).abs().max()) / scale
+                    em = float((ref32[:1].double().cpu() - want).abs().max()) / scale
+                    rest = float((got - ref32).abs().max()) / scale           # the other samples against MIOpen
+                    eh = max(eh, rest if rest > 1e-4 else 0.0)
+                th, tm = timed(hip), timed(mio)
+            tw, ew = float("inf"), float("nan")
+            if k == 3 and st == 1 and pad == 1 and dil == 1 and ops.winograd_supported(op, B, Cin, H, H, Cout):
+                wino = (lambda: ops.conv3x3_winograd(op, x if fwd else dy, w, (B, Cin, H, H), Cout))
+                gw = wino()
+                if not args.no_check:
+                    ew = max(float((gw[:1].double().cpu() - want).abs().max()) / scale, float((gw - ref32).abs().max()) / scale)
+                tw = timed(wino)
+            best = min(th, tm, tw)
+            tot_h += min(th, tw); tot_m += tm; tot_best += best
+            print("%-5s %-16s %-14s %-7s | %-4s %9.4f %9.4f %7.1f %7.1f | %9.2e %9.2e  %-4s | wino %9.4f ms %7.1f TF err %9.2e" % (
+                kind, "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), "%d/%d/%d" % (st, pad, dil), opname, th, tm,
+                flops / th / 1e9, flops / tm / 1e9, eh, em, "WINO" if best == tw else ("HIP" if best == th else ""),
+                tw, flops / tw / 1e9 if tw < 1e9 else 0.0, ew), flush=True)
+    print("sum over shapes (one call each): hip %.3f ms, miopen %.3f ms, best-of %.3f ms" % (tot_h, tot_m, tot_best))
+
+
+if __name__ == "__main__":
+    main()
