@@ -44,25 +44,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def _private_miopen_db():
-    """Give every rank its own copy of the shipped MIOpen find-db (deepinpainting_amd/miopen_db): MIOpen takes file
-    locks on its user db, and 8 ranks sharing one directory would serialise on them.  Must run before the first conv."""
-    if "MIOPEN_USER_DB_PATH" in os.environ or os.environ.get("IPSR_NO_MIOPEN_DB", "0") == "1":
-        return
-    import shutil
-    src = os.path.join(ROOT, "deepinpainting_amd", "miopen_db")
-    dst = os.path.join("/tmp", "ipsr_miopen_db_%d_%s" % (os.getuid(), os.environ.get("LOCAL_RANK", "0")))
-    try:
-        os.makedirs(dst, exist_ok=True)
-        for f in os.listdir(src):
-            if f.endswith(".txt"):
-                shutil.copy(os.path.join(src, f), os.path.join(dst, f))
-        os.environ["MIOPEN_USER_DB_PATH"] = dst
-    except OSError:
-        pass      # fall back to the in-tree directory (deepinpainting_amd/__init__.py)
+from deepinpainting_amd import use_shipped_miopen_db  # noqa: E402
 
-
-_private_miopen_db()
+use_shipped_miopen_db()      # a private per-rank copy of the shipped MIOpen find-db; must precede the first convolution
 
 STEP_FLOPS_PER_IMAGE = 340.6e9     # conv/mm forward+backward of one training step at 256x256 AS EXECUTED here: torch
                                    # FlopCounterMode over the default trainer = 339.5, + 1.07 of the IPSR correlation.  The

@@ -53,6 +53,8 @@ SIGNATURES = {
                             c_void_p, c_size_t, c_void_p]),
     "ipsr_conv3x3_winograd_workspace_bytes": (c_size_t, [c_int] * 6),
     "ipsr_conv3x3_winograd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ipsr_conv3x3_winograd_wrw_workspace_bytes": (c_size_t, [c_int] * 6),
+    "ipsr_conv3x3_winograd_wrw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "innercos_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "innercos_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                               c_void_p, c_size_t, c_void_p]),

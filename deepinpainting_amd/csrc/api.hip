@@ -261,7 +261,7 @@ static int forward_impl(const float* x, const float* ref, const int32_t* mask_po
     } else {
         if (int rc = launch_patch_normalize(x, B, p.K, p.N, xn, xT, p.Cp, inv, st, p.ld, p.ld)) return rc;
     }
-    AttnArgs a;
+    AttnArgs a{};                      // every field defined (mcount = NULL, mpi_stride = 0: one shared mask)
     if (corr_bf16) {
         if (int rc = launch_corr_argmax_bf16(xn, rs, B, p.K, p.N, ind, vmax, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
     } else {

@@ -169,7 +169,7 @@ __device__ __forceinline__ RecLds recurrence_prologue(int* lds_raw, int b, const
 // Runs in a 256-thread block of the stage kernel: all four waves fill / drain the LDS arrays, wave 0 alone walks the chain.
 template <int NCH, bool FULL>
 __device__ __forceinline__ void recurrence_body(int* lds_raw, int b, const float* __restrict__ xT, const float* __restrict__ inv,
-                                                const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M,
+                                                const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M, int Ms,
                                                 float* __restrict__ wn_out, float* __restrict__ wo_out)
 {
     const RecLds rl = recurrence_prologue(lds_raw, b, inv, part, mpi, N, M);
@@ -248,7 +248,7 @@ __device__ __forceinline__ void recurrence_body(int* lds_raw, int b, const float
 #undef IPSR_TAIL
   }
     __syncthreads();
-    for (int l = tid; l < M; l += 256) { wn_out[(size_t)b * M + l] = wn_s[l]; wo_out[(size_t)b * M + l] = wo_s[l]; }
+    for (int l = tid; l < M; l += 256) { wn_out[(size_t)b * Ms + l] = wn_s[l]; wo_out[(size_t)b * Ms + l] = wo_s[l]; }
 }
 
 // Wide patches (Cp > 1536; shift_sz > 1 makes a patch C*p*p numbers): the RING-deep double register ring above
@@ -256,7 +256,7 @@ __device__ __forceinline__ void recurrence_body(int* lds_raw, int b, const float
 // (A serves even steps, B odd ones): 5 rows of NCH*8 registers, each load has one full step of compute to land in.
 template <int NCH>
 __device__ __forceinline__ void recurrence_wide_body(int* lds_raw, int b, const float* __restrict__ xT, const float* __restrict__ inv,
-                                                     const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M,
+                                                     const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M, int Ms,
                                                      float* __restrict__ wn_out, float* __restrict__ wo_out)
 {
     const RecLds rl = recurrence_prologue(lds_raw, b, inv, part, mpi, N, M);
@@ -291,7 +291,7 @@ __device__ __forceinline__ void recurrence_wide_body(int* lds_raw, int b, const 
         }
     }
     __syncthreads();
-    for (int l = tid; l < M; l += 256) { wn_out[(size_t)b * M + l] = rl.wn_s[l]; wo_out[(size_t)b * M + l] = rl.wo_s[l]; }
+    for (int l = tid; l < M; l += 256) { wn_out[(size_t)b * Ms + l] = rl.wn_s[l]; wo_out[(size_t)b * Ms + l] = rl.wo_s[l]; }
 }
 
 // Patches wider than 2048 numbers (shift_sz > 1: C*p*p, 4608 for the reference's 512 channels and 3x3 patches): one
@@ -318,7 +318,7 @@ __device__ __forceinline__ void load_row_quad(RowRegs<NW>& dst, const float* __r
 
 template <int NW>
 __device__ __forceinline__ void recurrence_quad_body(int* lds_raw, int b, const float* __restrict__ xT, const float* __restrict__ inv,
-                                                     const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M,
+                                                     const CorrPartials& part, const int32_t* __restrict__ mpi, int Cp, int N, int M, int Ms,
                                                      float* __restrict__ wn_out, float* __restrict__ wo_out)
 {
     const RecLds rl = recurrence_prologue(lds_raw, b, inv, part, mpi, N, M);
@@ -395,7 +395,7 @@ __device__ __forceinline__ void recurrence_quad_body(int* lds_raw, int b, const 
     for (int d = 0; d < QD - 1; ++d)
         if (t + d < nsteps) step(pu[d], pk[d], t + d, rl.iv_s[t + d], rl.vm_s[t + d]);   // uniform across the block: every wave reaches the barrier
     __syncthreads();
-    for (int l = J; l < M; l += 256) { wn_out[(size_t)b * M + l] = rl.wn_s[l]; wo_out[(size_t)b * M + l] = rl.wo_s[l]; }
+    for (int l = J; l < M; l += 256) { wn_out[(size_t)b * Ms + l] = rl.wn_s[l]; wo_out[(size_t)b * Ms + l] = rl.wo_s[l]; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -452,7 +452,7 @@ __device__ __forceinline__ void gather_body(float (*tile)[33], int tileid, const
 //   recon_masked_kernel     out[:,q_l] = sum_j Ac[l][j] * P[D_j,:]  on fp32 MFMA, j ascending == k ascending
 
 __device__ __forceinline__ void prepare_body(int* lds, int b, const CorrPartials& part, const int32_t* __restrict__ mpi,
-                                             int N, int M, int Mc, int nbits, int32_t* __restrict__ ind, float* __restrict__ vmax,
+                                             int N, int M, int Ms, int Mc, int nbits, int32_t* __restrict__ ind, float* __restrict__ vmax,
                                              int32_t* __restrict__ dlist, int32_t* __restrict__ mprime,
                                              int32_t* __restrict__ jq, int32_t* __restrict__ rankflag,
                                              int32_t* __restrict__ bwd_index, size_t ints_per_sample)
@@ -511,7 +511,7 @@ __device__ __forceinline__ void prepare_body(int* lds, int b, const CorrPartials
     __syncthreads();
     const int mp = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     for (int j = mp + tid; j < Mc; j += 256) dlist[(size_t)b * Mc + j] = 0;     // padding rows of the GEMM: any valid patch
-    for (int l = tid; l < M; l += 256) jq[(size_t)b * M + l] = flag[indm[mpi_at(mpi, l, N)]] - 1;
+    for (int l = tid; l < M; l += 256) jq[(size_t)b * Ms + l] = flag[indm[mpi_at(mpi, l, N)]] - 1;
 
     // ---- one-hot rows of trunc(kbar): non-masked q grouped by k = ind[q], ascending q inside a group.  One wave walks
     // the positions 64 at a time; lanes with equal keys find each other with one ballot per key bit.  Keys and cursors
@@ -539,6 +539,14 @@ __device__ __forceinline__ void prepare_body(int* lds, int b, const CorrPartials
     }
 }
 
+// masked positions of sample b: the shared count a.M, or its own (device array, clamped to the capacity a.M)
+__device__ __forceinline__ int sample_count(const AttnArgs& a, int b)
+{
+    if (!a.mcount) return a.M;
+    const int m = a.mcount[b];
+    return m < 0 ? 0 : (m > a.M ? a.M : m);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Stage kernel: ONE launch behind the correlation kernel runs three independent jobs side by side, because the
 // coherent-attention recurrence is a serial chain on one wave per sample and would otherwise leave 248 CUs idle:
@@ -553,12 +561,17 @@ __global__ void __launch_bounds__(256) attention_stage_kernel(AttnArgs a, int nr
     __shared__ float gtile[32][33];
     const int bid = blockIdx.x;
     if (bid < nrec) {
-        if constexpr (NCH > 4) recurrence_quad_body<(NCH + 3) / 4>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
-        else if constexpr (NCH > 3) recurrence_wide_body<NCH>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
-        else recurrence_body<NCH, FULL>(lds_dyn, bid, a.xT, a.inv, a.part, a.mpi, a.Cp, a.N, a.M, a.wn, a.wo);
+        // per-sample masks: every sample has its own index row and its own number of masked positions (a.M = the capacity)
+        const int M = sample_count(a, bid);
+        const int32_t* mpi = a.mpi + (size_t)bid * a.mpi_stride;
+        if (M <= 0) return;                                  // nothing masked in this sample: no recurrence
+        if constexpr (NCH > 4) recurrence_quad_body<(NCH + 3) / 4>(lds_dyn, bid, a.xT, a.inv, a.part, mpi, a.Cp, a.N, M, a.M, a.wn, a.wo);
+        else if constexpr (NCH > 3) recurrence_wide_body<NCH>(lds_dyn, bid, a.xT, a.inv, a.part, mpi, a.Cp, a.N, M, a.M, a.wn, a.wo);
+        else recurrence_body<NCH, FULL>(lds_dyn, bid, a.xT, a.inv, a.part, mpi, a.Cp, a.N, M, a.M, a.wn, a.wo);
     } else if (bid < nrec + a.B) {
-        prepare_body(lds_dyn, bid - nrec, a.part, a.mpi, a.N, a.M, a.Mc, nbits, a.ind, a.vmax, a.dlist, a.mprime, a.jq, a.rankflag,
-                     a.bwd_index, ints_per_sample);
+        const int b = bid - nrec;
+        prepare_body(lds_dyn, b, a.part, a.mpi + (size_t)b * a.mpi_stride, a.N, sample_count(a, b), a.M, a.Mc, nbits, a.ind, a.vmax, a.dlist,
+                     a.mprime, a.jq, a.rankflag, a.bwd_index, ints_per_sample);
     } else {
         gather_body(gtile, bid - nrec - a.B, a.xT, a.part, a.B, a.C, a.Cp, a.N, a.out);
     }
@@ -576,27 +589,35 @@ constexpr int AC_KEEP = 4;      // survivors per column remembered in registers 
 template <bool WITH_INDEX>
 __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __restrict__ wn, const float* __restrict__ wo,
                                                                 const int32_t* __restrict__ jq, const int32_t* __restrict__ mprime,
-                                                                const int32_t* __restrict__ rankflag, const int32_t* __restrict__ mpi,
-                                                                int N, int M, int Mc, float* __restrict__ ac,
+                                                                const int32_t* __restrict__ rankflag, const int32_t* __restrict__ mpi_all,
+                                                                int mpi_stride, const int32_t* __restrict__ mcount,
+                                                                int N, int Ms, int Mc, float* __restrict__ ac,
                                                                 int32_t* __restrict__ bwd_index, size_t ints_per_sample)
 {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     float4* step = reinterpret_cast<float4*>(lds);          // [M] {wn, wo, jq bits, 0}
-    int* offj = lds + 4 * M;                                 // [Mc + 1] survivor count, then offset, of active column j
+    int* offj = lds + 4 * Ms;                                // [Mc + 1] survivor count, then offset, of active column j
     __shared__ int wave_tot[AC_MAXT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
-    const float* wnb = wn + (size_t)b * M;
-    const float* wob = wo + (size_t)b * M;
-    const int32_t* jqb = jq + (size_t)b * M;
+    // Ms = capacity (row strides, LDS carve, CSR layout); M = this sample's masked positions
+    int M = Ms;
+    if (mcount) { M = mcount[b]; M = M < 0 ? 0 : (M > Ms ? Ms : M); }
+    const int32_t* mpi = mpi_all + (size_t)b * mpi_stride;
+    const float* wnb = wn + (size_t)b * Ms;
+    const float* wob = wo + (size_t)b * Ms;
+    const int32_t* jqb = jq + (size_t)b * Ms;
     for (int l = tid; l < M; l += nthr) step[l] = make_float4(wnb[l], wob[l], __int_as_float(jqb[l]), 0.0f);
     __syncthreads();
-    float* acb = ac + (size_t)b * M * Mc;
-    const size_t capB = (size_t)M * (M + 1) / 2;
+    float* acb = ac + (size_t)b * Ms * Mc;
+    const size_t capB = (size_t)Ms * (Ms + 1) / 2;
+    // columns that can be non-zero: the active ones, rounded up to the GEMM's 32-column stages (the rest of a row is never
+    // read by recon_masked_kernel) — with per-sample masks Mc is sized for the capacity, not for this sample
+    const int Mce = min(Mc, (mprime[b] + 31) & ~31);
     int32_t* offB = WITH_INDEX ? bwd_index + (size_t)b * ints_per_sample + (N + 1) + N : nullptr;
     int32_t* entB_q = WITH_INDEX ? offB + N + 1 : nullptr;
     float* entB_w = reinterpret_cast<float*>(entB_q + capB);
 
-    for (int j0 = 0; j0 < Mc; j0 += nthr) {                  // one pass for Mc <= 1024
+    for (int j0 = 0; j0 < Mce; j0 += nthr) {                 // one pass for Mc <= 1024
         const int j = j0 + tid;
         float a = 0.0f;
         int cnt = 0;
@@ -604,7 +625,7 @@ __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __r
         float keep_w[AC_KEEP];
 #pragma unroll
         for (int i = 0; i < AC_KEEP; ++i) { keep_l[i] = 0; keep_w[i] = 0.0f; }
-        if (j < Mc) {
+        if (j < Mce) {
 #pragma unroll 8
             for (int l = 0; l < M; ++l) {
                 const float4 s = step[l];
@@ -636,14 +657,14 @@ __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __r
         __syncthreads();
         int off = (j0 == 0 ? 0 : offj[Mc]) + incl - cnt;
         for (int w = 0; w < wv; ++w) off += wave_tot[w];
-        if (j < Mc) offj[j] = off;
+        if (j < Mce) offj[j] = off;
         __syncthreads();
         if (tid == nthr - 1) {
             int tot = j0 == 0 ? 0 : offj[Mc];
             for (int w = 0; w < nwave; ++w) tot += wave_tot[w];
             offj[Mc] = tot;
         }
-        if (j < Mc && cnt > 0) {
+        if (j < Mce && cnt > 0) {
             if (cnt <= AC_KEEP) {
 #pragma unroll
                 for (int i = 0; i < AC_KEEP; ++i)
@@ -663,6 +684,11 @@ __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __r
         __syncthreads();
     }
     if (!WITH_INDEX) return;
+    // the grand total also answers "all active columns are below k" (rank == mprime): when the replay stopped short of Mc that
+    // slot is offj[Mce] (mprime == Mce), and with no active column at all the total is 0
+    __syncthreads();
+    if (tid == 0 && Mce < Mc) offj[Mce] = Mce == 0 ? 0 : offj[Mc];
+    __syncthreads();
     // offB[k] = survivors in columns < k: active column -> offj[rank], inactive -> offj[#active columns below]
     for (int k = tid; k <= N; k += nthr) {
         int r;
@@ -674,13 +700,14 @@ __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __r
 
 // dense rows of `in_attention` (optional output): attn[l][k] = active(k) ? Ac[l][rank(k)] : 0
 __global__ void __launch_bounds__(256) attn_expand_kernel(const float* __restrict__ ac, const int32_t* __restrict__ rankflag,
-                                                          int N, int M, int Mc, float* __restrict__ attn)
+                                                          const int32_t* __restrict__ mcount, int N, int Ms, int Mc, float* __restrict__ attn)
 {
     const int b = blockIdx.z, l = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= N) return;
+    const int M = mcount ? min(max(mcount[b], 0), Ms) : Ms;           // rows past this sample's count are zero
     const int r = rankflag[(size_t)b * N + k];
-    attn[((size_t)b * M + l) * N + k] = r >= 0 ? ac[((size_t)b * M + l) * Mc + r] : 0.0f;
+    attn[((size_t)b * Ms + l) * N + k] = (l < M && r >= 0) ? ac[((size_t)b * Ms + l) * Mc + r] : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -692,7 +719,8 @@ constexpr int RM_BC = 64, RM_BL = 64, RM_BK = 32;
 
 __global__ void __launch_bounds__(256) recon_masked_kernel(const float* __restrict__ xT, const float* __restrict__ ac,
                                                            const int32_t* __restrict__ dlist, const int32_t* __restrict__ mprime,
-                                                           const int32_t* __restrict__ mpi, int C, int Cp, int N, int M, int Mc,
+                                                           const int32_t* __restrict__ mpi_all, int mpi_stride,
+                                                           const int32_t* __restrict__ mcount, int C, int Cp, int N, int Ms, int Mc,
                                                            float* __restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) float As[2][RM_BK][RM_BC];
@@ -701,8 +729,11 @@ __global__ void __launch_bounds__(256) recon_masked_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     const int l0 = blockIdx.x * RM_BL, c0 = blockIdx.y * RM_BC, b = blockIdx.z;
+    const int M = mcount ? min(max(mcount[b], 0), Ms) : Ms;           // this sample's masked positions (Ms = capacity / row stride)
+    if (l0 >= M) return;                                              // uniform for the block
+    const int32_t* mpi = mpi_all + (size_t)b * mpi_stride;
     const float* xTb = xT + (size_t)b * N * Cp;
-    const float* acb = ac + (size_t)b * M * Mc;
+    const float* acb = ac + (size_t)b * Ms * Mc;
     const int32_t* db = dlist + (size_t)b * Mc;
     const int mp = mprime[b];
 
@@ -822,13 +853,13 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_compress_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
         }
         const int nthr = Mc < AC_MAXT ? ((Mc + 63) & ~63) : AC_MAXT;
-        if (need_index) attn_compress_kernel<true><<<B, nthr, lds_c, st>>>(a.wn, a.wo, a.jq, a.mprime, a.rankflag, a.mpi, N, M, Mc, a.ac, a.bwd_index, ints);
-        else attn_compress_kernel<false><<<B, nthr, lds_c, st>>>(a.wn, a.wo, a.jq, a.mprime, a.rankflag, a.mpi, N, M, Mc, a.ac, nullptr, ints);
+        if (need_index) attn_compress_kernel<true><<<B, nthr, lds_c, st>>>(a.wn, a.wo, a.jq, a.mprime, a.rankflag, a.mpi, a.mpi_stride, a.mcount, N, M, Mc, a.ac, a.bwd_index, ints);
+        else attn_compress_kernel<false><<<B, nthr, lds_c, st>>>(a.wn, a.wo, a.jq, a.mprime, a.rankflag, a.mpi, a.mpi_stride, a.mcount, N, M, Mc, a.ac, nullptr, ints);
         if (int rc = check_launch("attn_compress_kernel")) return rc;
-        recon_masked_kernel<<<dim3(cdiv(M, RM_BL), cdiv(C, RM_BC), B), 256, 0, st>>>(a.xT, a.ac, a.dlist, a.mprime, a.mpi, C, Cp, N, M, Mc, a.out);
+        recon_masked_kernel<<<dim3(cdiv(M, RM_BL), cdiv(C, RM_BC), B), 256, 0, st>>>(a.xT, a.ac, a.dlist, a.mprime, a.mpi, a.mpi_stride, a.mcount, C, Cp, N, M, Mc, a.out);
         if (int rc = check_launch("recon_masked_kernel")) return rc;
         if (a.attn) {
-            attn_expand_kernel<<<dim3(cdiv(N, 256), M, B), 256, 0, st>>>(a.ac, a.rankflag, N, M, Mc, a.attn);
+            attn_expand_kernel<<<dim3(cdiv(N, 256), M, B), 256, 0, st>>>(a.ac, a.rankflag, a.mcount, N, M, Mc, a.attn);
             if (int rc = check_launch("attn_expand_kernel")) return rc;
         }
     } else if (need_index) {

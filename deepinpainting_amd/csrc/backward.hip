@@ -90,16 +90,55 @@ __global__ void __launch_bounds__(BW_THREADS) ipsr_backward_kernel(const float* 
             }
     }
     __syncthreads();
-    // phase 2: one lane per (long column, channel row); the chain itself stays sequential (same bits as phase 1)
+    // phase 2: one lane per (long column, channel row); the chain itself stays sequential (same bits as phase 1).
+    // In training the conv features are signed and the matches collapse: measured (tools/instep_layer.py, profiles/
+    // r02_instep_layer.txt) ~10 columns per sample hold ALL ~750 one-hot entries (190-600 each) and up to 6 columns
+    // 130-220 survivors, so this phase is the kernel.  What bounds a chain is the latency of fetching the next entry, not
+    // the add: entries are therefore fetched 8 at a time (independent loads, one L2 round trip per 8 steps, the next batch
+    // already in flight) and only the 8 dependent adds / fmas stay serial.
     const int nl = min(n_long, BW_MAXLONG);
     for (int idx = tid; idx < nl * R; idx += BW_THREADS) {
         const int k = long_k[idx / R], i = idx % R;
         if (i >= nrow) continue;
         const float* row = rows + (size_t)i * N;
         float acc = 0.0f;
-        for (int e = offA[k], e1 = offA[k + 1]; e < e1; ++e) acc = acc + row[entA[e]];
-#pragma unroll 4
-        for (int e = offB[k], e1 = offB[k + 1]; e < e1; ++e) acc = __builtin_fmaf(entB_w[e], row[entB_q[e]], acc);
+        {
+            const int e0 = offA[k], e1 = offA[k + 1];
+            if (e1 > e0) {
+                int qn[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qn[j] = entA[min(e0 + j, e1 - 1)];
+                for (int e = e0; e < e1; e += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = row[qn[j]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) qn[j] = entA[min(e + 8 + j, e1 - 1)];   // next batch (clamped: a valid, unused entry)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (e + j < e1) acc = acc + v[j];
+                }
+            }
+        }
+        {
+            const int e0 = offB[k], e1 = offB[k + 1];
+            if (e1 > e0) {
+                int qn[8];
+                float wn[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int ee = min(e0 + j, e1 - 1); qn[j] = entB_q[ee]; wn[j] = entB_w[ee]; }
+                for (int e = e0; e < e1; e += 8) {
+                    float v[8], wc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { v[j] = row[qn[j]]; wc[j] = wn[j]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const int ee = min(e + 8 + j, e1 - 1); qn[j] = entB_q[ee]; wn[j] = entB_w[ee]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (e + j < e1) acc = __builtin_fmaf(wc[j], v[j], acc);
+                }
+            }
+        }
         const float t = acc * triple_w;
         ob[(size_t)i * N + k] = identity ? row[k] + t : t;
     }

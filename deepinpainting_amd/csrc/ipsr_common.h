@@ -159,8 +159,10 @@ struct AttnArgs {
     int32_t* ind;          // [B,N]  written by the stage kernel (merged arg-max)
     float* vmax;           // [B,N]
     CorrPartials part;     // k-split partials of the correlation kernel
-    const int32_t* mpi;    // [M]
-    int B, C, Cp, N, M, Mc;   // Mc = roundup(M, 32): row stride of the compressed attention
+    const int32_t* mpi;    // [M] shared by the batch (mpi_stride 0), or [B][M] one row per sample (mpi_stride M)
+    int mpi_stride;
+    const int32_t* mcount; // NULL: every sample has M masked positions; else [B] device counts (per-sample masks), each <= M
+    int B, C, Cp, N, M, Mc;   // M = capacity (row strides / CSR layout); Mc = roundup(M, 32): row stride of the compressed attention
     // workspace
     float* wn;             // [B,M]
     float* wo;             // [B,M]

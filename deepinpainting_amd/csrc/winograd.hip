@@ -59,6 +59,23 @@ __device__ __forceinline__ void wino_at(const float m[6], float y[4])        // 
     y[3] = m[1] - m[2] + 8.0f * m[3] - 8.0f * m[4] + m[5];
 }
 
+// weight gradient, F(3x3, 4x4): dW(3x3) = A'^T [ (G' e G'^T) (.) (B^T d B) ] A'   (e = 4x4 tile of dy, d = 6x6 window of x)
+__device__ __forceinline__ void wino_g4(const float e[4], float u[6])        // G' e
+{
+    u[0] = 0.25f * e[0];
+    u[1] = (-1.0f / 6.0f) * (e[0] + e[1] + e[2] + e[3]);
+    u[2] = (-1.0f / 6.0f) * (e[0] - e[1] + e[2] - e[3]);
+    u[3] = (1.0f / 24.0f) * e[0] + (1.0f / 12.0f) * e[1] + (1.0f / 6.0f) * e[2] + (1.0f / 3.0f) * e[3];
+    u[4] = (1.0f / 24.0f) * e[0] - (1.0f / 12.0f) * e[1] + (1.0f / 6.0f) * e[2] - (1.0f / 3.0f) * e[3];
+    u[5] = e[3];
+}
+__device__ __forceinline__ void wino_at3(const float m[6], float y[3])       // A'^T m
+{
+    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    y[1] = m[1] - m[2] + 2.0f * m[3] - 2.0f * m[4];
+    y[2] = m[1] + m[2] + 4.0f * m[3] + 4.0f * m[4] + m[5];
+}
+
 // U[xi][c][k], k < Kp (zero beyond K), from W[c*sc + k*sm + r*3 + s] (flip: r -> 2-r, s -> 2-s)
 __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ W, int C, int K, int Kp, long sc, long sm, int flip,
                                                           float* __restrict__ U)
@@ -177,6 +194,124 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
             for (int j = 0; j < 4; ++j)
                 if (y0 + i < H && x0 + j < Wd) yp[(size_t)(y0 + i) * Wd + x0 + j] = o[i][j];
     }
+}
+
+// ---- weight-gradient transforms: outputs are TILE-major ([xi][t][channel]) because the GEMM then reduces over tiles ----
+// One workgroup = 16 tiles x 16 channels: a thread transforms one (tile, channel) with its lanes along the tiles (coalesced
+// reads of neighbouring windows), the 36 results cross LDS and leave with the lanes along the channels (64-byte runs).
+__device__ __forceinline__ void wino_store_tmajor(float (*stage)[16][17], const float v[6][6], int tl, int cl, float* __restrict__ dst,
+                                                  int t0, int c0, int Tp, int Cp)
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) stage[i * 6 + j][tl][cl] = v[i][j];
+    __syncthreads();
+    const int c = threadIdx.x & 15, t = threadIdx.x >> 4;
+    const size_t plane = (size_t)Tp * Cp;
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) dst[(size_t)xi * plane + (size_t)(t0 + t) * Cp + c0 + c] = stage[xi][t][c];
+}
+
+// window operand (x for Conv2d, dy for ConvTranspose2d):  Vt[xi][t][c] = (B^T d B)[xi], zero for t >= T or c >= C
+__global__ void __launch_bounds__(256) wino_wrw_window_kernel(const float* __restrict__ x, int B, int C, int H, int Wd, int TY, int TX,
+                                                              int Tp, int Cp, float* __restrict__ Vt)
+{
+    __shared__ float stage[36][16][17];
+    const int tl = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int t0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+    const int t = t0 + tl, c = c0 + cl, T = B * TY * TX;
+    float d[6][6];
+    const bool live = t < T && c < C;
+    int b = 0, ty = 0, tx = 0;
+    if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
+    const float* xp = x + ((size_t)b * C + (live ? c : 0)) * H * Wd;
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int yy = y0 + i;
+        const bool yok = live && (unsigned)yy < (unsigned)H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int xx = x0 + j;
+            d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+        }
+    }
+    float w[6][6], v[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float o[6];
+        wino_bt(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino_bt(w[i], v[i]);
+    wino_store_tmajor(stage, v, tl, cl, Vt, t0, c0, Tp, Cp);
+}
+
+// tile operand (dy for Conv2d, x for ConvTranspose2d):  Et[xi][t][k] = (G' e G'^T)[xi], e = the 4x4 tile, zero beyond T / K
+__global__ void __launch_bounds__(256) wino_wrw_tile_kernel(const float* __restrict__ dy, int B, int K, int H, int Wd, int TY, int TX,
+                                                            int Tp, int Kp, float* __restrict__ Et)
+{
+    __shared__ float stage[36][16][17];
+    const int tl = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int t0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
+    const int t = t0 + tl, k = k0 + cl, T = B * TY * TX;
+    const bool live = t < T && k < K;
+    int b = 0, ty = 0, tx = 0;
+    if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
+    const float* dp = dy + ((size_t)b * K + (live ? k : 0)) * H * Wd;
+    float e[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int yy = 4 * ty + i, xx = 4 * tx + j;
+            e[i][j] = (live && yy < H && xx < Wd) ? dp[(size_t)yy * Wd + xx] : 0.0f;
+        }
+    float w[6][4], v[6][6];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float col[4] = {e[0][j], e[1][j], e[2][j], e[3][j]};
+        float o[6];
+        wino_g4(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino_g4(w[i], v[i]);
+    wino_store_tmajor(stage, v, tl, cl, Et, t0, k0, Tp, Kp);
+}
+
+// dW[k][c][r][s] = (A'^T Mw[:][k][c] A')[r][s]
+__global__ void __launch_bounds__(256) wino_wrw_output_kernel(const float* __restrict__ Mw, int K, int C, int Kp, int Cp, float* __restrict__ dW)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    if (c >= C) return;
+    float m[6][6];
+    const size_t plane = (size_t)Kp * Cp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[i][j] = Mw[(size_t)(i * 6 + j) * plane + (size_t)k * Cp + c];
+    float w[3][6], o[3][3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
+        float r3[3];
+        wino_at3(col, r3);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i][j] = r3[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wino_at3(w[i], o[i]);
+    float* dst = dW + ((size_t)k * C + c) * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dst[i * 3 + j] = o[i][j];
 }
 
 // ---- the 36 GEMMs ----------------------------------------------------------------------------------
@@ -325,6 +460,50 @@ int launch_winograd(const float* x, const float* w, float* y, int B, int C, int 
     return check_launch("wino_output_kernel");
 }
 
+struct WinoWrwPlan { int TY, TX, T, Tp, Kp, Cp; size_t e_floats, v_floats, m_floats, total_bytes; };
+
+static int wino_wrw_plan(int B, int K, int C, int H, int W, WinoWrwPlan* p)
+{
+    p->TY = (H + 3) / 4; p->TX = (W + 3) / 4;
+    p->T = B * p->TY * p->TX;
+    p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;            // reduction of the GEMM: a multiple of 16 (and of the 16-tile blocks)
+    p->Kp = (K + WG_BM - 1) / WG_BM * WG_BM;
+    p->Cp = (C + WG_BN - 1) / WG_BN * WG_BN;
+    p->e_floats = (size_t)36 * p->Tp * p->Kp;
+    p->v_floats = (size_t)36 * p->Tp * p->Cp;
+    p->m_floats = (size_t)36 * p->Kp * p->Cp;
+    p->total_bytes = align_up(p->e_floats * 4, 256) + align_up(p->v_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
+    return IPSR_OK;
+}
+
+size_t winograd_wrw_ws_bytes(int B, int K, int C, int H, int W)
+{
+    WinoWrwPlan p;
+    wino_wrw_plan(B, K, C, H, W, &p);
+    return p.total_bytes;
+}
+
+// dW[K][C][3][3] = sum over tiles:  tile operand `et` [B,K,H,W] (4x4 tiles), window operand `dt` [B,C,H,W] (6x6 windows)
+int launch_winograd_wrw(const float* et, const float* dt, float* dW, int B, int K, int C, int H, int W, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    WinoWrwPlan p;
+    wino_wrw_plan(B, K, C, H, W, &p);
+    if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "winograd wrw: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    Carver cv(ws, ws_bytes);
+    float* Et = cv.take<float>(p.e_floats);
+    float* Vt = cv.take<float>(p.v_floats);
+    float* Mw = cv.take<float>(p.m_floats);
+    wino_wrw_tile_kernel<<<dim3(p.Tp / 16, p.Kp / 16), 256, 0, st>>>(et, B, K, H, W, p.TY, p.TX, p.Tp, p.Kp, Et);
+    wino_wrw_window_kernel<<<dim3(p.Tp / 16, p.Cp / 16), 256, 0, st>>>(dt, B, C, H, W, p.TY, p.TX, p.Tp, p.Cp, Vt);
+    if (int rc = check_launch("wino_wrw_window_kernel")) return rc;
+    const int ktiles = p.Kp / WG_BM, ctiles = p.Cp / WG_BN;
+    // M[xi][k][c] = sum_t Et[xi][t][k] * Vt[xi][t][c]: the same GEMM with the tiles as the reduction
+    wino_gemm_kernel<<<36 * ktiles * ctiles, WG_THREADS, 0, st>>>(Et, Vt, p.Tp, p.Kp, p.Cp, ktiles, ctiles, Mw);
+    if (int rc = check_launch("wino_gemm_kernel")) return rc;
+    wino_wrw_output_kernel<<<dim3(cdiv(C, 256), K), 256, 0, st>>>(Mw, K, C, p.Kp, p.Cp, dW);
+    return check_launch("wino_wrw_output_kernel");
+}
+
 }  // namespace ipsr
 
 using namespace ipsr;
@@ -357,6 +536,25 @@ int ipsr_conv3x3_winograd(int op, const float* in, const float* weight, float* o
         default:     // ConvTranspose2d backward-data: dx = conv(dy, w as [ci][co]), reduction over Cout: (c=co, k=ci) at co*9 + ci*Cout*9
             return launch_winograd(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, ws, ws_bytes, st);
     }
+}
+
+size_t ipsr_conv3x3_winograd_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout)
+{
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
+    return transposed ? winograd_wrw_ws_bytes(B, Cin, Cout, H, W) : winograd_wrw_ws_bytes(B, Cout, Cin, H, W);
+}
+
+int ipsr_conv3x3_winograd_wrw(int transposed, const float* x, const float* dy, float* dw, int B, int Cin, int H, int W, int Cout,
+                              void* ws, size_t ws_bytes, void* stream)
+{
+    if (!x || !dy || !dw || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_wrw: null pointer");
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_wrw: bad argument");
+    if (reinterpret_cast<uintptr_t>(ws) & 15u) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_wrw: workspace must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // Conv2d:          dW[co][ci][r][s] = sum dy[co][o] x[ci][o + r - 1]       tile operand dy, window operand x
+    // ConvTranspose2d: dW[ci][co][r][s] = sum x[ci][i] dy[co][i + r - 1]       tile operand x,  window operand dy
+    if (transposed) return launch_winograd_wrw(x, dy, dw, B, Cin, Cout, H, W, ws, ws_bytes, st);
+    return launch_winograd_wrw(dy, x, dw, B, Cout, Cin, H, W, ws, ws_bytes, st);
 }
 
 }  // extern "C"

@@ -18,7 +18,12 @@ class _InnerCosLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cuse, mask, target, strength):
         xf, tf = x.detach().float(), target.detach().float()       # fp32 whatever the surrounding autocast regime
-        ctx.save_for_backward(xf, mask, tf)
+        # The tap returns its INPUT (reference InnerCos.py:41), and the next module of the U-Net rewrites that tensor in place
+        # (uprelu_3 after InnerCos2, models/networks.py:229): the backward must see the values the loss was computed on, so a
+        # tensor that will take part in autograd is saved as a private copy (an alias would trip autograd's version check in
+        # `InnerCos.backward()`; the reference's mul/MSE graph copies implicitly).  Under no_grad nothing is kept.
+        keep = xf.clone() if (ctx.needs_input_grad[0] and xf.data_ptr() == x.data_ptr()) else xf
+        ctx.save_for_backward(keep, mask, tf)
         ctx.cuse, ctx.strength, ctx.in_dtype = cuse, strength, x.dtype
         return ops.innercos_loss(xf, cuse, mask, tf, strength)
 

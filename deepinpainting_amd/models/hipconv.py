@@ -10,7 +10,9 @@ Three engines per (operation, geometry), chosen by `select()` from measurements 
   "direct"    csrc/conv_gemm.hip  one-launch implicit GEMM, NCHW in/out (every k3/k4, stride 1/2, dilated and transposed
                                   geometry of the nets, forward and backward-data): at parity with MIOpen (~100 TF), used
                                   where it measured >= 7 % faster
-  "miopen"    torch               everything else, and every weight gradient
+  "miopen"    torch               everything else
+Weight gradients: Winograd F(3x3,4x4) (csrc/winograd.hip) for the 3x3 stride-1 layers with >= 256 channels on 16x16..64x64
+maps (2.0-2.4x MIOpen), MIOpen otherwise (`select_wrw`).
 
 `IPSR_CONV_ENGINE=miopen|direct|winograd|auto` (default auto) forces one engine wherever it is implemented — for the
 per-engine parity tests and for A/B timing.  bf16 autocast and non-contiguous / non-fp32 inputs always take MIOpen.
@@ -47,8 +49,20 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil):
         return "winograd"
     if k == 4 and stride == 2 and dil == 2 and op == ops.CONV_BWD_DATA and Cin >= 128 and 16 <= H <= 128:
         return "direct"          # dilated 4x4 stride-2 input gradient: 8-12 % faster than MIOpen's f3x2_dilation2 + transposes
-    if k == 4 and stride == 2 and dil == 1 and op == ops.CONVT_BWD_DATA and Cin == 256 and Cout == 64:
-        return "direct"
+    return "miopen"
+
+
+def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """-> "winograd" | "miopen" for the weight gradient of one layer (profiles/r02_hipconv_k3_wrw.txt: F(3x3,4x4) is 2.0-2.4x
+    MIOpen from 256 channels up on maps of 16x16..64x64; on larger maps its tile-major transforms lose to MIOpen)."""
+    mode = _mode()
+    ok = k == 3 and stride == 1 and pad == 1 and dil == 1
+    if mode in ("miopen", "direct") or not ok:
+        return "miopen"
+    if mode == "winograd":
+        return "winograd"
+    if 256 <= H * W <= 4096 and max(Cin, Cout) >= 256 and min(Cin, Cout) >= 128:
+        return "winograd"
     return "miopen"
 
 
@@ -88,7 +102,9 @@ class _HipConv(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
                                                          [True, False, False])[0]
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil) == "winograd":
+            dw = ops.conv3x3_winograd_wrw(transposed, x, dy, Cout)
+        elif ctx.needs_input_grad[1]:
             dw = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
                                                      [False, True, False])[1]
         return dx, dw, None, None, None, None, None, None
@@ -123,7 +139,8 @@ def conv_nobias(m, x, weight=None):
             # the backward may use a HIP engine even where the forward stays on MIOpen
             bop = ops.CONVT_BWD_DATA if transposed else ops.CONV_BWD_DATA
             beng = select(bop, B, Cin, H, W, Cout, k, stride, pad, dil) if x.requires_grad else "miopen"
-            if eng != "miopen" or beng != "miopen":
+            weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil) if w.requires_grad else "miopen"
+            if eng != "miopen" or beng != "miopen" or weng != "miopen":
                 return _HipConv.apply(x, w, transposed, k, stride, pad, dil, eng)
         elif eng == "winograd":
             return ops.conv3x3_winograd(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout)

@@ -13,6 +13,8 @@ _TRAINERS = {
 
 
 def create_model(opt):
+    from .. import use_shipped_miopen_db
+    use_shipped_miopen_db()          # before the first convolution of this process
     wanted = opt.model
     print(wanted)
     entry = _TRAINERS.get(wanted)

@@ -373,6 +373,21 @@ def conv3x3_winograd(op, inp, weight, in_shape, Cout):
     return out
 
 
+def conv3x3_winograd_wrw(transposed, x, dy, Cout):
+    """Weight gradient of a k3 s1 p1 Conv2d (transposed=False -> [Cout,Cin,3,3]) / ConvTranspose2d (True -> [Cin,Cout,3,3])."""
+    x = _req(x, torch.float32, "conv input")
+    dy = _req(dy, torch.float32, "grad_output")
+    B, Cin, H, W = x.shape
+    if tuple(dy.shape) != (B, Cout, H, W):
+        raise RuntimeError("conv3x3_winograd_wrw: grad_output %s does not match %s" % (tuple(dy.shape), (B, Cout, H, W)))
+    dw = torch.empty((Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = _workspace(L.ipsr_conv3x3_winograd_wrw_workspace_bytes(int(transposed), B, Cin, H, W, Cout), x.device)
+    _lib.check(L.ipsr_conv3x3_winograd_wrw(int(transposed), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,
+                                           ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv3x3_winograd_wrw")
+    return dw
+
+
 def innercos_loss(x, cuse, mask_f32, target, strength):
     """K9.  x [B,Cx,h,w] (only the first `cuse` channels are read), target [B,cuse,h,w] -> loss [] fp32."""
     x = _req(x, torch.float32, "in_data")

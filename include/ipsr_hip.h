@@ -204,6 +204,15 @@ size_t ipsr_conv3x3_winograd_workspace_bytes(int op, int B, int Cin, int H, int 
 int ipsr_conv3x3_winograd(int op, const float* in, const float* weight, float* out, int B, int Cin, int H, int W, int Cout,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* Weight gradient of the same 3x3 / stride 1 / pad 1 layers by Winograd F(3x3,4x4) (the transposed algorithm: 4x4 tiles of one
+ * operand against 6x6 windows of the other, reduced over all tiles of the batch on the matrix cores):
+ *   transposed = 0  Conv2d           dw [Cout,Cin,3,3] = sum dy[.,co,o] * x[.,ci,o+r-1]
+ *   transposed = 1  ConvTranspose2d  dw [Cin,Cout,3,3] = sum x[.,ci,i] * dy[.,co,i+r-1]
+ * x [B,Cin,H,W], dy [B,Cout,H,W]; any channel counts (tiles are zero padded to 128). */
+size_t ipsr_conv3x3_winograd_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout);
+int ipsr_conv3x3_winograd_wrw(int transposed, const float* x, const float* dy, float* dw, int B, int Cin, int H, int W, int Cout,
+                              void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
  * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.

@@ -123,6 +123,27 @@ def main():
                 kind, "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), "%d/%d/%d" % (st, pad, dil), opname, th, tm,
                 flops / th / 1e9, flops / tm / 1e9, eh, em, "WINO" if best == tw else ("HIP" if best == th else ""),
                 tw, flops / tw / 1e9 if tw < 1e9 else 0.0, ew), flush=True)
+    if args.k3:
+        print("\nweight gradient, Winograd F(3x3,4x4) vs MIOpen:")
+        for kind, Cin, H, Cout, k, st, pad, dil in K3:
+            tr = kind == "convT"
+            if min(Cin, Cout) < 16:
+                continue
+            x = torch.randn(B, Cin, H, H, device="cuda")
+            w = torch.randn((Cin, Cout, 3, 3) if tr else (Cout, Cin, 3, 3), device="cuda") * 0.05
+            dy = torch.randn(B, Cout, H, H, device="cuda")
+            cb = torch.ops.aten.convolution_backward
+            cargs = (dy, x, w, None, [1, 1], [1, 1], [1, 1], tr, [0, 0], 1)
+            with torch.no_grad():
+                mio = lambda: cb(*cargs, [False, True, False])[1]
+                hipw = lambda: ops.conv3x3_winograd_wrw(tr, x, dy, Cout)
+                a, b2 = hipw(), mio()
+                err = float((a - b2).abs().max() / b2.abs().max())
+                tw, tm = timed(hipw), timed(mio)
+            flops = 2.0 * B * Cin * Cout * 9 * H * H
+            print("%-5s %-16s %-14s | wrw wino %9.4f ms %7.1f TF   miopen %9.4f ms %7.1f TF   |wino - miopen| %9.2e  %s" % (
+                kind, "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), tw, flops / tw / 1e9, tm, flops / tm / 1e9, err,
+                "WINO" if tw < tm else ""), flush=True)
     print("sum over shapes (one call each): hip %.3f ms, miopen %.3f ms, best-of %.3f ms" % (tot_h, tot_m, tot_best))
 
 
