@@ -220,7 +220,8 @@ size_t ipsr_forward_workspace_bytes(int B, int C, int h, int w, int M, int patch
 static int forward_impl(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
                         int B, int C, int h, int w, int patch, int stride,
                         float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
-                        void* ws, size_t ws_bytes, void* stream, bool corr_bf16)
+                        void* ws, size_t ws_bytes, void* stream, bool corr_bf16,
+                        const int32_t* mcount = nullptr, int mpi_stride = 0)
 {
     if (!x || !ref || !out || !ind || !vmax || !ws) return fail(IPSR_ERR_INVALID, "ipsr_forward: null pointer");
     if (B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return fail(IPSR_ERR_INVALID, "ipsr_forward: bad size B=%d C=%d h=%d w=%d M=%d", B, C, h, w, M);
@@ -268,6 +269,7 @@ static int forward_impl(const float* x, const float* ref, const int32_t* mask_po
         if (int rc = launch_corr_argmax(xn, rs, B, p.K, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
     }
     a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
+    a.mcount = mcount; a.mpi_stride = mpi_stride;
     a.B = B; a.C = p.K; a.Cp = p.Cp; a.N = p.N; a.M = M; a.Mc = p.Mc;
     a.wn = reinterpret_cast<float*>(slice[WS_WN]);
     a.wo = reinterpret_cast<float*>(slice[WS_WO]);
@@ -289,6 +291,18 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
                  void* ws, size_t ws_bytes, void* stream)
 {
     return forward_impl(x, ref, mask_point_idx, M, B, C, h, w, patch, stride, out, ind, vmax, attn_rows, bwd_index, ws, ws_bytes, stream, false);
+}
+
+int ipsr_forward_masks(const float* x, const float* ref, const int32_t* mask_point_idx, int mpi_stride, const int32_t* counts, int Mcap,
+                       int B, int C, int h, int w, int patch, int stride,
+                       float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
+                       void* ws, size_t ws_bytes, void* stream, int corr_bf16)
+{
+    if (!counts) return fail(IPSR_ERR_INVALID, "ipsr_forward_masks: counts is NULL (use ipsr_forward for one host-known count)");
+    if (mpi_stride != 0 && mpi_stride != Mcap) return fail(IPSR_ERR_INVALID, "ipsr_forward_masks: mpi_stride must be 0 or Mcap (got %d, Mcap %d)", mpi_stride, Mcap);
+    if (Mcap < 1) return fail(IPSR_ERR_INVALID, "ipsr_forward_masks: Mcap must be >= 1");
+    return forward_impl(x, ref, mask_point_idx, Mcap, B, C, h, w, patch, stride, out, ind, vmax, attn_rows, bwd_index, ws, ws_bytes, stream,
+                        corr_bf16 != 0, counts, mpi_stride);
 }
 
 size_t ipsr_forward_bf16corr_workspace_bytes(int B, int C, int h, int w, int M, int patch, int stride)

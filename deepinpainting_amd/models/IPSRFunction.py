@@ -58,3 +58,26 @@ class IPSRFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         grad_input = ops.backward(grad_output.float(), ctx.bwd_index, ctx.triple_w, ctx.M, ctx.shift_sz).to(ctx.in_dtype)
         return grad_input, None, None, None, None, None, None, None, None, None, None, None
+
+
+class IPSRFunctionDeviceCounts(torch.autograd.Function):
+    """The same layer with the masked positions described ON THE DEVICE: `mpi32` [Mcap] (one index for the batch) or
+    [B,Mcap] (one row per sample) and `counts` [B] int32 — what IPSR_model uses internally (include/ipsr_hip.h,
+    ipsr_forward_masks).  Not part of the reference's surface (its IPSRFunction.apply above stays the foreign-caller entry);
+    it exists because the reference's 12 host-sized index tensors force a device->host round trip per mask, and because a
+    batch with one hole per sample cannot be described by them at all."""
+
+    @staticmethod
+    def forward(ctx, input, ref_feat, mpi32, counts, shift_sz, stride, triple_w):
+        assert input.dim() == 4, "Input Dim has to be 4"
+        ctx.in_dtype = input.dtype
+        f = ops.forward(input.detach().float(), ref_feat.detach().float(), mpi32, int(shift_sz), int(stride),
+                        want_index=ctx.needs_input_grad[0], counts=counts)
+        ctx.Mcap, ctx.shift_sz, ctx.triple_w = int(mpi32.size(-1)), int(shift_sz), triple_w
+        ctx.bwd_index, ctx.ind, ctx.vmax = f.bwd_index, f.ind, f.vmax
+        return f.out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        g = ops.backward(grad_output.float(), ctx.bwd_index, ctx.triple_w, ctx.Mcap, ctx.shift_sz).to(ctx.in_dtype)
+        return g, None, None, None, None, None, None

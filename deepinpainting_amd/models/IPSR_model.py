@@ -4,16 +4,20 @@ Same constructor, `set_mask`, `set_ref`, `forward` and repr.  The reference reco
 tensors with an O(N^2) Python loop on EVERY forward because `cal_fixed_flag` is never cleared
 (:45-53); they depend on the mask only, so here they are recomputed only after `set_mask`.
 
+The index (flag, mask_point_idx, count) stays ON THE DEVICE: the K2 kernel's outputs go straight into the layer
+(ipsr_forward_masks reads the count from device memory), so a forward costs no host round trip; the reference-surface
+attributes `flag`, `nonmask_point_idx`, `flatten_offsets`, `mask_point_idx` are materialised on first access only.
+
 Extension (not in the reference, whose notebook pins batchSize = 1 because it has ONE mask per batch): `set_mask` with a
-[B,1,H,W] mask gives every sample its own hole.  The layer then runs sample by sample — each sample has its own masked
-positions and its own recurrence length — which is exactly the reference's per-sample loop (models/IPSRFunction.py:46) with
-the mask inside it; per-sample results equal a batch-of-one call with that sample's mask.
+[B,1,H,W] mask gives every sample its own hole.  The batch still runs as ONE launch sequence — every sample with its own
+index row, count and recurrence length — which is exactly the reference's per-sample loop (models/IPSRFunction.py:46) with
+the mask inside it; per-sample results equal a batch-of-one call with that sample's mask bit for bit.
 """
 import torch
 import torch.nn as nn
 
 from ..util import util
-from .IPSRFunction import IPSRFunction
+from .IPSRFunction import IPSRFunction, IPSRFunctionDeviceCounts
 
 
 class _Ref(object):
@@ -57,41 +61,48 @@ class IPSR_model(nn.Module):
     def set_ref(self, latent_ref):
         self.ref = latent_ref
 
-    def _forward_per_sample(self, input):
-        B = input.size(0)
-        assert self.mask.size(0) == B, 'per-sample masks: %d masks for a batch of %d' % (self.mask.size(0), B)
+    # ---- device-side index: flag / mask_point_idx / count straight from the K2 kernel, never read back in the hot path ----
+    def _index_rows(self, masks):
+        """masks [h,w] or [B,h,w] byte -> (flag32 [R,N], mpi32 [R,N] (-1 padded), counts [R] int32), R = 1 or B."""
+        from .. import ops
+        rows = [masks] if masks.dim() == 2 else list(masks)
+        outs = [ops.index_prep(m if m.dtype == torch.uint8 else m.to(torch.uint8), int(self.shift_sz), int(self.stride), int(self.mask_thred))
+                for m in rows]
+        return (torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), torch.cat([o[2] for o in outs]))
+
+    def _ensure_index(self, input):
         if self.cal_fixed_flag or self._index_shape != (self.h, self.w):
-            self._per_sample_index = [util.cal_mask_given_mask_thred(input[0].detach(), self.mask[b], self.shift_sz, self.stride,
-                                                                     self.mask_thred) for b in range(B)]
+            assert self.mask is not None, 'set_mask() must be called before forward()'
+            self._flag32, self._mpi32, self._counts = self._index_rows(self.mask)
+            n_win = (self.h - int(self.shift_sz) + 1) * (self.w - int(self.shift_sz) + 1)
+            assert self._flag32.size(1) == n_win, 'mask %s does not match a %dx%d feature' % (tuple(self.mask.shape), self.h, self.w)
+            self._host_index = None                 # the reference-surface tensors are rebuilt lazily
             self.cal_fixed_flag = False
             self._index_shape = (self.h, self.w)
-        if not (torch.is_tensor(self.sp_x) or torch.is_tensor(self.sp_y)):
-            self.sp_x, self.sp_y = util.cal_sps_for_Advanced_Indexing(self.h, self.w)
-        feat = self.ref.relu4_3
 
-        def one(b):
-            flag, nonmask, offsets, mpi = self._per_sample_index[b]
-            ref_b = self.ref._replace(relu4_3=feat[b:b + 1]) if hasattr(self.ref, '_replace') else _Ref(feat[b:b + 1])
-            return IPSRFunction.apply(input[b:b + 1], self.mask[b], ref_b, self.shift_sz, self.stride, self.triple_weight,
-                                      flag, nonmask, mpi, offsets, self.sp_x, self.sp_y)
+    def _host_tensors(self):
+        """flag / nonmask_point_idx / flatten_offsets / mask_point_idx as the reference exposes them (int64, exact sizes): built on
+        first access (one host sync), for tests and foreign callers — the layer itself never needs them."""
+        if getattr(self, '_host_index', None) is None:
+            assert getattr(self, '_flag32', None) is not None, 'flag must have been figured out and has to be a tensor!'
+            rows = []
+            for r in range(self._flag32.size(0)):
+                M = int(self._counts[r].item())
+                flag = self._flag32[r].to(torch.int64)
+                mpi = self._mpi32[r, :M].to(torch.int64)
+                mpi._ipsr_i32 = self._mpi32[r, :M].contiguous()
+                rows.append((flag, torch.arange(flag.numel(), dtype=torch.int64, device=flag.device), util.flatten_offsets_from_flag(flag), mpi))
+            self._host_index = rows
+        return self._host_index
 
-        if not input.is_cuda or B == 1:
-            return torch.cat([one(b) for b in range(B)], 0)
-        # A single sample fills an eighth of the chip (64 correlation workgroups, one recurrence wave): run the samples
-        # side by side on their own HIP streams.  Autograd replays each sample's backward on the stream of its forward.
-        cur = torch.cuda.current_stream(input.device)
-        if getattr(self, '_streams', None) is None or len(self._streams) < B or self._streams[0].device != input.device:
-            self._streams = [torch.cuda.Stream(device=input.device) for _ in range(B)]
-        outs = [None] * B
-        for b in range(B):
-            st = self._streams[b]
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                outs[b] = one(b)
-        for b in range(B):
-            cur.wait_stream(self._streams[b])
-            outs[b].record_stream(cur)
-        return torch.cat(outs, 0)
+    flag = property(lambda self: self._host_tensors()[0][0])
+    nonmask_point_idx = property(lambda self: self._host_tensors()[0][1])
+    flatten_offsets = property(lambda self: self._host_tensors()[0][2])
+    mask_point_idx = property(lambda self: self._host_tensors()[0][3])
+
+    @property
+    def _per_sample_index(self):
+        return self._host_tensors()
 
     def forward(self, input):
         if self.corr_bf16 and input.is_cuda:
@@ -101,22 +112,34 @@ class IPSR_model(nn.Module):
         return self._forward(input)
 
     def _forward(self, input):
-        _, self.c, self.h, self.w = input.size()
-        if self.mask is not None and self.mask.dim() == 3:
-            return self._forward_per_sample(input)
+        B, self.c, self.h, self.w = input.size()
+        if not input.is_cuda:
+            return self._forward_reference_surface(input)
+        self._ensure_index(input)
+        if self.mask.dim() == 3:
+            # one hole per sample (extension): ONE launch sequence for the batch, every sample with its own index row and count
+            assert self.mask.size(0) == B, 'per-sample masks: %d masks for a batch of %d' % (self.mask.size(0), B)
+            mpi, counts = self._mpi32, self._counts
+        else:
+            mpi, counts = self._mpi32[0], self._counts.expand(B).contiguous()
+        return IPSRFunctionDeviceCounts.apply(input, self.ref.relu4_3, mpi, counts, self.shift_sz, self.stride, self.triple_weight)
+
+    def _forward_reference_surface(self, input):
+        """The reference's own call sequence (models/IPSR_model.py:45-63) through the 12-argument IPSRFunction.apply: what a CPU
+        tensor gets (the oracle-backed twin patches IPSRFunction for that) — the GPU path above is the same computation."""
+        if self.mask.dim() == 3:
+            raise NotImplementedError("per-sample masks need the GPU path")
         if self.cal_fixed_flag or self._index_shape != (self.h, self.w):
             latter = input.narrow(0, 0, 1).detach()
-            self.flag, self.nonmask_point_idx, self.flatten_offsets, self.mask_point_idx = \
-                util.cal_mask_given_mask_thred(latter.squeeze(0), self.mask, self.shift_sz, self.stride, self.mask_thred)
+            self._host_index = [util.cal_mask_given_mask_thred(latter.squeeze(0), self.mask, self.shift_sz, self.stride, self.mask_thred)]
+            self._flag32 = None
             self.cal_fixed_flag = False
             self._index_shape = (self.h, self.w)
-        else:
-            assert torch.is_tensor(self.flag), 'flag must have been figured out and has to be a tensor!'
         if not (torch.is_tensor(self.sp_x) or torch.is_tensor(self.sp_y)):
             self.sp_x, self.sp_y = util.cal_sps_for_Advanced_Indexing(self.h, self.w)
+        flag, nonmask, offsets, mpi = self._host_index[0]
         return IPSRFunction.apply(input, self.mask, self.ref, self.shift_sz, self.stride, self.triple_weight,
-                                  self.flag, self.nonmask_point_idx, self.mask_point_idx, self.flatten_offsets,
-                                  self.sp_x, self.sp_y)
+                                  flag, nonmask, mpi, offsets, self.sp_x, self.sp_y)
 
     def __repr__(self):
         return self.__class__.__name__ + '(' \

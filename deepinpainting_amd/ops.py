@@ -138,13 +138,17 @@ def corr_precision(corr):
         _precision.corr = prev
 
 
-def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want_index=True, corr=None):
+def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want_index=True, corr=None, counts=None):
     """Whole layer forward.  x, ref [B,C,h,w] fp32; mask_point_idx_i32 [M] i32 -> Forward.
     want_attn:  also materialise the dense attention rows [B,M,N] (the reference's `in_attention`; tests and
                 inspection only — the layer itself works on the compressed form);
     want_index: build the sparse trunc(kbar) the backward needs (skip under no_grad);
     corr:       "fp32" (the reference's arithmetic, default) or "bf16" (opt-in bf16-MFMA correlation); None = what the
-                enclosing `corr_precision` block says."""
+                enclosing `corr_precision` block says;
+    counts:     [B] int32 DEVICE tensor = masked positions per sample (ipsr_forward_masks).  mask_point_idx is then [Mcap]
+                (one index shared by the batch, e.g. straight from `index_prep`, no host sync) or [B,Mcap] (one row per
+                sample: per-sample masks); entries past counts[b] are ignored.  Everything sized by M (attn_rows, bwd_index)
+                is sized by the capacity Mcap; pass M = Mcap to `backward`."""
     if corr is None:
         corr = getattr(_precision, "corr", "fp32")
     if corr not in ("fp32", "bf16"):
@@ -160,7 +164,15 @@ def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want
         raise RuntimeError("IPSR layer: shift_sz=%d does not fit a %dx%d feature" % (patch, h, w))
     N = (h - patch + 1) * (w - patch + 1)       # window grid; = h*w for the reference's shift_sz = 1
     mpi = _req(mask_point_idx_i32, torch.int32, "mask_point_idx")
-    M = int(mpi.numel())
+    if counts is not None:
+        counts = _req(counts, torch.int32, "counts")
+        if counts.numel() != B or mpi.dim() not in (1, 2) or (mpi.dim() == 2 and mpi.size(0) != B):
+            raise RuntimeError("forward: counts must be [B] and mask_point_idx [Mcap] or [B,Mcap] (got %s, %s)" % (tuple(counts.shape), tuple(mpi.shape)))
+        M = int(mpi.size(-1))
+        if M < 1 or M > N:
+            raise RuntimeError("forward: index capacity %d outside [1, %d]" % (M, N))
+    else:
+        M = int(mpi.numel())
     L = _lib.lib()
     dev = x.device
     out = torch.empty_like(x)
@@ -171,6 +183,13 @@ def forward(x, ref, mask_point_idx_i32, patch=1, stride=1, want_attn=False, want
     bf = corr == "bf16"
     nbytes = (L.ipsr_forward_bf16corr_workspace_bytes if bf else L.ipsr_forward_workspace_bytes)(B, C, h, w, M, patch, stride)
     ws = _workspace(nbytes, dev)
+    if counts is not None:
+        _lib.check(L.ipsr_forward_masks(x.data_ptr(), ref.data_ptr(), mpi.data_ptr(), M if mpi.dim() == 2 else 0, counts.data_ptr(), M,
+                                        B, C, h, w, patch, stride, out.data_ptr(), ind.data_ptr(), vmax.data_ptr(),
+                                        attn.data_ptr() if attn is not None else None,
+                                        bidx.data_ptr() if bidx is not None else None, ws.data_ptr(), ws.numel(), _stream(), int(bf)),
+                   "ipsr_forward_masks")
+        return Forward(out, ind, vmax, attn, bidx)
     _lib.check((L.ipsr_forward_bf16corr if bf else L.ipsr_forward)(
         x.data_ptr(), ref.data_ptr(), mpi.data_ptr() if M else None, M, B, C, h, w,
         patch, stride, out.data_ptr(), ind.data_ptr(), vmax.data_ptr(),

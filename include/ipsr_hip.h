@@ -107,6 +107,21 @@ int ipsr_forward(const float* x, const float* ref, const int32_t* mask_point_idx
                  float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* ---- per-sample masks / device-side counts (extension; BASELINE.json config 3 "irregular free-form masks") -----------------
+ * The reference has ONE mask per batch and learns M on the host (util/util.py:132 syncs per position).  This entry point
+ * takes the number of masked positions from DEVICE memory, one count per sample, so that
+ *   (a) a batch whose samples have different holes runs as ONE launch sequence (mask_point_idx [B,Mcap], mpi_stride = Mcap,
+ *       counts[b] <= Mcap valid entries in row b) — per-sample results equal a batch-of-one ipsr_forward call bit for bit;
+ *   (b) the shared-mask case needs no host round trip at all (mask_point_idx [Mcap] straight from ipsr_index_prep with
+ *       mpi_stride = 0 and counts[b] = its *count for every b).
+ * Everything that ipsr_forward sizes by M is sized by the capacity Mcap here (workspace: query with M = Mcap; attn_rows
+ * [B,Mcap,N] with the rows past counts[b] zero; bwd_index [B, ipsr_bwd_index_ints(N, Mcap)], to be handed to
+ * ipsr_backward / ipsr_backward_patch with M = Mcap).  corr_bf16 != 0 selects the bf16 correlation (workspace: the bf16corr query). */
+int ipsr_forward_masks(const float* x, const float* ref, const int32_t* mask_point_idx, int mpi_stride, const int32_t* counts /*[B] device*/,
+                       int Mcap, int B, int C, int h, int w, int patch, int stride,
+                       float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index,
+                       void* ws, size_t ws_bytes, void* stream, int corr_bf16);
+
 /* ---- bf16 MFMA correlation (BASELINE.json config 5: "CDNA4 bf16 MFMA for patch-corr") — OPT-IN ----------------------
  * The same layer with the cross-correlation of models/IPSRFunction.py:59 computed on v_mfma_f32_32x32x16_bf16: both
  * operands (the normalised patches and ref.relu4_3) are rounded to bf16, products are exact, accumulation is fp32.

@@ -446,6 +446,48 @@ def test_layer_cfg3_freeform_mask_full_batch_vs_oracle(ops, signed):
         np.testing.assert_array_equal(gin.cpu().numpy()[b], orc.backward(g[b:b + 1], mp, fo.attn_rows, fo.bwd_index, 1.0)[0])
 
 
+@pytest.mark.parametrize("signed", [False, True])
+def test_device_side_counts_and_per_sample_masks_equal_host_sized_calls(ops, signed):
+    """ipsr_forward_masks (include/ipsr_hip.h): the masked positions given as a padded device index + device counts.
+    (a) shared mask, capacity N: every output bit-identical to ipsr_forward with the host-known M (and therefore to the
+    oracle); (b) one mask per sample in ONE call: every sample bit-identical to its own batch-of-one ipsr_forward, forward and
+    backward, including a sample with an EMPTY mask and one whose mask covers everything."""
+    rs = np.random.RandomState(91 + signed)
+    B, C, h = 5, 64, 16
+    N = h * h
+    x = rs.standard_normal((B, C, h, h)).astype(np.float32)
+    x = x if signed else np.abs(x)
+    ref = np.maximum(rs.standard_normal((B, C, h, h)), 0).astype(np.float32)
+    g = rs.standard_normal(x.shape).astype(np.float32)
+    feats = [(rs.rand(h, h) < p).astype(np.uint8) for p in (0.3, 0.1, 0.55)] + [np.zeros((h, h), np.uint8), np.ones((h, h), np.uint8)]
+    xd, rd, gd = dev(x), dev(ref), dev(g)
+    # (a) shared mask
+    flag, mpi_pad, cnt = ops.index_prep(dev(feats[0]), 1, 1, 1)
+    M = int(cnt.item())
+    f_host = ops.forward(xd, rd, mpi_pad[:M].contiguous(), want_attn=True)
+    f_dev = ops.forward(xd, rd, mpi_pad, want_attn=True, counts=cnt.expand(B).contiguous())
+    assert torch.equal(f_dev.out, f_host.out) and torch.equal(f_dev.ind, f_host.ind) and torch.equal(f_dev.vmax, f_host.vmax)
+    assert torch.equal(f_dev.attn_rows[:, :M], f_host.attn_rows) and not f_dev.attn_rows[:, M:].any()
+    assert torch.equal(ops.backward(gd, f_dev.bwd_index, 0.75, N), ops.backward(gd, f_host.bwd_index, 0.75, M))
+    # (b) per-sample masks
+    rows = [ops.index_prep(dev(f), 1, 1, 1) for f in feats]
+    mpi_all = torch.stack([r[1] for r in rows])
+    counts = torch.cat([r[2] for r in rows])
+    fb = ops.forward(xd, rd, mpi_all, want_attn=True, counts=counts)
+    gb = ops.backward(gd, fb.bwd_index, 0.75, N)
+    torch.cuda.synchronize()
+    for b in range(B):
+        Mb = int(counts[b].item())
+        f1 = ops.forward(xd[b:b + 1], rd[b:b + 1], mpi_all[b, :Mb].contiguous(), want_attn=True)
+        g1 = ops.backward(gd[b:b + 1], f1.bwd_index, 0.75, Mb)
+        assert torch.equal(fb.out[b], f1.out[0]) and torch.equal(fb.ind[b], f1.ind[0]), "sample %d (M=%d)" % (b, Mb)
+        if Mb:
+            assert torch.equal(fb.attn_rows[b, :Mb], f1.attn_rows[0])
+        assert torch.equal(gb[b], g1[0]), "backward of sample %d (M=%d)" % (b, Mb)
+        fo = orc.forward(x[b:b + 1], ref[b:b + 1], mpi_all[b, :Mb].cpu().numpy())
+        np.testing.assert_array_equal(fb.out[b].cpu().numpy(), fo.out[0])
+
+
 def test_layer_stress_size_cfg4_properties(ops):
     """BASELINE config 4 feature size (512x64x64, N=4096, M=1024), one sample: property checks."""
     rs = np.random.RandomState(17)
