@@ -317,7 +317,7 @@ def main():
 
     # the reference's exact sequence (strict_reference), same model and inputs, timed the same way after the headline loop
     strict = None
-    if args.dtype == "f32" and os.environ.get("IPSR_BENCH_NO_STRICT", "0") != "1":
+    if args.dtype == "f32" and os.environ.get("IPSR_BENCH_NO_STRICT", "0") != "1" and os.environ.get("IPSR_BENCH_STEP_ONLY", "0") != "1":
         ksteps = max(3, min(10, args.steps))
         model.strict_reference = True
         for _ in range(2):
@@ -367,6 +367,13 @@ def main():
         if "corr_argmax" in tj.get("kernel", "") and tj.get("workload", "").endswith("[%d,%d,%d,%d]" % (args.batch, C_FEAT, H_FEAT, H_FEAT)):
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_src = "stored rocprofv3 --pmc figure (profiles/traffic_corr_argmax.json, FETCH_SIZE x2 + WRITE_SIZE), not re-measured in this run"
+    if os.environ.get("IPSR_BENCH_STEP_ONLY", "0") == "1":
+        # profiling aid (rocprofv3 of the training steps alone): no layer micro-benchmarks, no CPU twin
+        print(json.dumps({"metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "note": "IPSR_BENCH_STEP_ONLY=1 (profiling run)"}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     fwd_ms, bwd_ms = layer_timing(device)
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,

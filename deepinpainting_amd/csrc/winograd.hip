@@ -121,14 +121,28 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
         const int ty = rem / TX, tx = rem - ty * TX;
         const float* xp = x + ((size_t)b * C + c) * H * Wd;
         const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+        if ((Wd & 3) == 0) {
+            // the window's inner four columns are the tile's own, 16-byte aligned: one float4 + two halo scalars per row
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int yy = y0 + i;
-            const bool yok = (unsigned)yy < (unsigned)H;
+            for (int i = 0; i < 6; ++i) {
+                const int yy = y0 + i;
+                const bool yok = (unsigned)yy < (unsigned)H;
+                const float* rp = xp + (size_t)(yok ? yy : 0) * Wd;
+                const float4 mid = yok ? *reinterpret_cast<const float4*>(rp + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+                d[i][0] = (yok && x0 >= 0) ? rp[x0] : 0.0f;
+                d[i][1] = mid.x; d[i][2] = mid.y; d[i][3] = mid.z; d[i][4] = mid.w;
+                d[i][5] = (yok && x0 + 5 < Wd) ? rp[x0 + 5] : 0.0f;
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int xx = x0 + j;
-                d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+            for (int i = 0; i < 6; ++i) {
+                const int yy = y0 + i;
+                const bool yok = (unsigned)yy < (unsigned)H;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int xx = x0 + j;
+                    d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+                }
             }
         }
     } else {
@@ -155,9 +169,13 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
         for (int j = 0; j < 6; ++j) V[(size_t)(i * 6 + j) * plane + (size_t)c * Tp + t] = v[i][j];
 }
 
-// y[b][k][4ty+i][4tx+j] = (A^T M A)[i][j]
-__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mo, int B, int K, int Kp, int H, int Wd, int TY, int TX,
-                                                          int Tp, float* __restrict__ y)
+// y[b][k][4ty+i][4tx+j] = (A^T M A)[i][j], M = the sum of the GEMM's `nsplit` partial results (ascending: deterministic).
+// EPI: 0 plain; 1 = + bias[k], ReLU; 2 = + bias[k], ReLU, 2x2 max-pool (y is then [B,K,H/2,W/2]) — the VGG16 chain
+// Conv2d(bias) -> ReLU(inplace) [-> MaxPool2d(2,2)] (models/vgg16.py:9-21) without a second pass over the activations.
+// NaN-propagating like torch's relu / max_pool2d.
+template <int EPI>
+__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mo, int nsplit, const float* __restrict__ bias,
+                                                          int B, int K, int Kp, int H, int Wd, int TY, int TX, int Tp, float* __restrict__ y)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
     const int T = B * TY * TX;
@@ -168,6 +186,13 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) m[i][j] = Mo[(size_t)(i * 6 + j) * plane + (size_t)k * Tp + t];
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const float* Ms = Mo + (size_t)sp * 36 * plane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + (size_t)k * Tp + t];
+    }
     float w[4][6], o[4][4];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {                 // columns: w[:,j] = A^T m[:,j]
@@ -179,8 +204,29 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) wino_at(w[i], o[i]);
+    if (EPI >= 1) {
+        const float bv = bias ? bias[k] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float v = o[i][j] + bv; o[i][j] = v < 0.0f ? 0.0f : v; }
+    }
     const int b = t / (TY * TX), rem = t - b * TY * TX;
     const int ty = rem / TX, tx = rem - ty * TX;
+    if (EPI == 2) {                                // H, W even (host-checked): the 4x4 tile pools to 2x2
+        const int Hh = H >> 1, Wh = Wd >> 1;
+        float* yp = y + ((size_t)b * K + k) * Hh * Wh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float a0 = o[2 * i][2 * j], a1 = o[2 * i][2 * j + 1], a2 = o[2 * i + 1][2 * j], a3 = o[2 * i + 1][2 * j + 1];
+                const float m01 = (a0 > a1 || a0 != a0) ? a0 : a1, m23 = (a2 > a3 || a2 != a2) ? a2 : a3;
+                const int yy = 2 * ty + i, xx = 2 * tx + j;
+                if (yy < Hh && xx < Wh) yp[(size_t)yy * Wh + xx] = (m01 > m23 || m01 != m01) ? m01 : m23;
+            }
+        return;
+    }
     float* yp = y + ((size_t)b * K + k) * H * Wd;
     const int y0 = 4 * ty, x0 = 4 * tx;
     if ((Wd & 3) == 0) {
@@ -286,7 +332,8 @@ __global__ void __launch_bounds__(256) wino_wrw_tile_kernel(const float* __restr
 }
 
 // dW[k][c][r][s] = (A'^T Mw[:][k][c] A')[r][s]
-__global__ void __launch_bounds__(256) wino_wrw_output_kernel(const float* __restrict__ Mw, int K, int C, int Kp, int Cp, float* __restrict__ dW)
+__global__ void __launch_bounds__(256) wino_wrw_output_kernel(const float* __restrict__ Mw, int nsplit, int K, int C, int Kp, int Cp,
+                                                              float* __restrict__ dW)
 {
     const int c = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
     if (c >= C) return;
@@ -296,6 +343,13 @@ __global__ void __launch_bounds__(256) wino_wrw_output_kernel(const float* __res
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) m[i][j] = Mw[(size_t)(i * 6 + j) * plane + (size_t)k * Cp + c];
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const float* Ms = Mw + (size_t)sp * 36 * plane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + (size_t)k * Cp + c];
+    }
     float w[3][6], o[3][3];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -319,8 +373,11 @@ __global__ void __launch_bounds__(256) wino_wrw_output_kernel(const float* __res
 // corr_argmax_fast_kernel's pipeline (see there for the measurements behind each choice): operand tiles HBM/L2 -> LDS by
 // global_load_lds_dwordx4 three stages ahead in a 4-slot ring, counted vmcnt + raw s_barrier per stage, a wave owns the
 // 32x32 sub-tiles {wm*32, +64} x {wn*32, +64} so that its two A (B) fragments of a k-step are ONE ds_read2st64_b32.
+// nsplit > 1: the reduction is cut into nsplit ranges of `sps` stages; range `ks` writes its own partial Mo + ks*36*Kp*Tp (summed,
+// in order, by the output transform).  Small layers have too few 128x128 tiles to fill 256 CUs x 2 otherwise (36 x 4 x 1 = 144
+// workgroups for a 512-channel 16x16 map), and tile counts just above a multiple of 512 leave a nearly empty second round.
 __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* __restrict__ U, const float* __restrict__ V, int C, int Kp, int Tp,
-                                                                  int ktiles, int ttiles, float* __restrict__ Mo)
+                                                                  int ktiles, int ttiles, int nsplit, int sps, float* __restrict__ Mo)
 {
     __shared__ __attribute__((aligned(16))) float lds[WG_NBUF * 2 * WG_BK * WG_BM];
     const int tid = threadIdx.x;
@@ -330,12 +387,13 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
 
     // all tiles of one xi (they share U[xi] and V[xi]) get consecutive logical ids -> one XCD's L2
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_xi = ktiles * ttiles;
+    const int per_xi = ktiles * ttiles * nsplit;
     const int xi = L / per_xi, rem = L - xi * per_xi;
-    const int kt = rem % ktiles, tt = rem / ktiles;
+    const int ks = rem % nsplit, kt = (rem / nsplit) % ktiles, tt = rem / (nsplit * ktiles);
     const int k0 = kt * WG_BM, t0 = tt * WG_BN;
-    const float* A = U + (size_t)xi * C * Kp;
-    const float* Bm = V + (size_t)xi * C * Tp;
+    const int s_lo = ks * sps;
+    const float* A = U + (size_t)xi * C * Kp + (size_t)s_lo * WG_BK * Kp;
+    const float* Bm = V + (size_t)xi * C * Tp + (size_t)s_lo * WG_BK * Tp;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -345,7 +403,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int nstage = C / WG_BK;
+    const int nstage = min(C / WG_BK - s_lo, sps);        // stages of this workgroup (>= 1)
     constexpr int NP = WG_BK / 4;                         // DMA pieces (1 KiB = 2 rows) per wave per stage: 2 of A, 2 of B
     const int dma_row = lane >> 5, dma_col = (lane & 31) * 4;
     auto dma_piece = [&](int s, int p) {
@@ -401,7 +459,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
         __builtin_amdgcn_s_barrier();
     }
 
-    float* out = Mo + (size_t)xi * Kp * Tp;
+    float* out = Mo + ((size_t)ks * 36 + xi) * Kp * Tp;
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) {
         const int t = t0 + wn * 32 + jn * 64 + r;
@@ -416,7 +474,28 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct WinoPlan { int TY, TX, T, Tp, Kp; size_t u_floats, v_floats, m_floats, total_bytes; };
+// how to cut the reduction of the 36 GEMMs: estimated time = rounds of 512 resident workgroups x (stages + pipeline fill) plus
+// the extra pass over the partial results; the candidate with the lowest estimate wins
+static void wino_choose_split(int tiles36, int stages, size_t m_bytes, int* nsplit, int* sps)
+{
+    double best = -1.0;
+    *nsplit = 1; *sps = stages;
+    const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int ns : cand) {
+        if (ns > 1 && stages / ns < 4) break;
+        const int per = cdiv(stages, ns), real = cdiv(stages, per);
+        const long wgs = (long)tiles36 * real;
+        const long rounds = (wgs + 511) / 512;
+        // a stage of two co-resident workgroups takes ~1.7 us; a last round that fills less than half the chip runs one
+        // workgroup per CU, ~1.5x faster each
+        const long tail = wgs - (rounds - 1) * 512;
+        double t = (rounds - 1) * (per + 3) * 1.7 + (per + 3) * (tail <= 256 ? 1.15 : 1.7);
+        t += (real - 1) * (double)m_bytes * 2.0 / 4.0e6;              // partials written + read at ~4 TB/s, in us
+        if (best < 0.0 || t < best) { best = t; *nsplit = real; *sps = per; }
+    }
+}
+
+struct WinoPlan { int TY, TX, T, Tp, Kp, nsplit, sps; size_t u_floats, v_floats, m_floats, total_bytes; };
 
 static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p)
 {
@@ -427,7 +506,9 @@ static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p)
     p->Kp = (K + WG_BM - 1) / WG_BM * WG_BM;
     p->u_floats = (size_t)36 * C * p->Kp;
     p->v_floats = (size_t)36 * C * p->Tp;
-    p->m_floats = (size_t)36 * p->Kp * p->Tp;
+    const size_t m1 = (size_t)36 * p->Kp * p->Tp;
+    wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), C / WG_BK, m1 * 4, &p->nsplit, &p->sps);
+    p->m_floats = m1 * p->nsplit;
     p->total_bytes = align_up(p->u_floats * 4, 256) + align_up(p->v_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
     return IPSR_OK;
 }
@@ -439,28 +520,39 @@ size_t winograd_ws_bytes(int B, int C, int K, int H, int W)
     return p.total_bytes;
 }
 
+size_t winograd_filter_floats(int C, int K) { return (size_t)36 * C * ((K + WG_BM - 1) / WG_BM * WG_BM); }
+
 // y[B,K,H,W] = conv3x3(x[B,C,H,W]) with weight element (c, k, r, s) at w[c*sc + k*sm + r*3 + s], taps flipped when `flip`.
+// u_cache (optional, winograd_filter_floats(C, K) floats owned by the caller): the transformed filter; computed into it when
+// !u_valid, reused as is otherwise (frozen weights: VGG16).  epilogue: 0 none, 1 bias + ReLU, 2 bias + ReLU + 2x2 max-pool.
 int launch_winograd(const float* x, const float* w, float* y, int B, int C, int K, int H, int W, long sc, long sm, int flip,
-                    void* ws, size_t ws_bytes, hipStream_t st)
+                    void* ws, size_t ws_bytes, hipStream_t st, const float* bias = nullptr, int epilogue = 0,
+                    float* u_cache = nullptr, int u_valid = 0)
 {
     WinoPlan p;
     if (int rc = wino_plan(B, C, K, H, W, &p)) return rc;
     if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    if (epilogue < 0 || epilogue > 2 || (epilogue == 2 && ((H | W) & 1)))
+        return fail(IPSR_ERR_INVALID, "winograd: epilogue %d on a %dx%d map", epilogue, H, W);
     Carver cv(ws, ws_bytes);
     float* U = cv.take<float>(p.u_floats);
     float* V = cv.take<float>(p.v_floats);
     float* Mo = cv.take<float>(p.m_floats);
-    wino_filter_kernel<<<dim3(cdiv(p.Kp, 256), C), 256, 0, st>>>(w, C, K, p.Kp, sc, sm, flip, U);
+    if (u_cache) U = u_cache;
+    if (!(u_cache && u_valid)) wino_filter_kernel<<<dim3(cdiv(p.Kp, 256), C), 256, 0, st>>>(w, C, K, p.Kp, sc, sm, flip, U);
     wino_input_kernel<<<dim3(cdiv(p.Tp, 256), C), 256, 0, st>>>(x, B, C, H, W, p.TY, p.TX, p.Tp, V);
     if (int rc = check_launch("wino_input_kernel")) return rc;
     const int ktiles = p.Kp / WG_BM, ttiles = p.Tp / WG_BN;
-    wino_gemm_kernel<<<36 * ktiles * ttiles, WG_THREADS, 0, st>>>(U, V, C, p.Kp, p.Tp, ktiles, ttiles, Mo);
+    wino_gemm_kernel<<<36 * ktiles * ttiles * p.nsplit, WG_THREADS, 0, st>>>(U, V, C, p.Kp, p.Tp, ktiles, ttiles, p.nsplit, p.sps, Mo);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
-    wino_output_kernel<<<dim3(cdiv(p.T, 256), K), 256, 0, st>>>(Mo, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
+    const dim3 og(cdiv(p.T, 256), K);
+    if (epilogue == 2) wino_output_kernel<2><<<og, 256, 0, st>>>(Mo, p.nsplit, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
+    else if (epilogue == 1) wino_output_kernel<1><<<og, 256, 0, st>>>(Mo, p.nsplit, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
+    else wino_output_kernel<0><<<og, 256, 0, st>>>(Mo, p.nsplit, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
     return check_launch("wino_output_kernel");
 }
 
-struct WinoWrwPlan { int TY, TX, T, Tp, Kp, Cp; size_t e_floats, v_floats, m_floats, total_bytes; };
+struct WinoWrwPlan { int TY, TX, T, Tp, Kp, Cp, nsplit, sps; size_t e_floats, v_floats, m_floats, total_bytes; };
 
 static int wino_wrw_plan(int B, int K, int C, int H, int W, WinoWrwPlan* p)
 {
@@ -471,7 +563,9 @@ static int wino_wrw_plan(int B, int K, int C, int H, int W, WinoWrwPlan* p)
     p->Cp = (C + WG_BN - 1) / WG_BN * WG_BN;
     p->e_floats = (size_t)36 * p->Tp * p->Kp;
     p->v_floats = (size_t)36 * p->Tp * p->Cp;
-    p->m_floats = (size_t)36 * p->Kp * p->Cp;
+    const size_t m1 = (size_t)36 * p->Kp * p->Cp;
+    wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4, &p->nsplit, &p->sps);
+    p->m_floats = m1 * p->nsplit;
     p->total_bytes = align_up(p->e_floats * 4, 256) + align_up(p->v_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
     return IPSR_OK;
 }
@@ -498,9 +592,9 @@ int launch_winograd_wrw(const float* et, const float* dt, float* dW, int B, int 
     if (int rc = check_launch("wino_wrw_window_kernel")) return rc;
     const int ktiles = p.Kp / WG_BM, ctiles = p.Cp / WG_BN;
     // M[xi][k][c] = sum_t Et[xi][t][k] * Vt[xi][t][c]: the same GEMM with the tiles as the reduction
-    wino_gemm_kernel<<<36 * ktiles * ctiles, WG_THREADS, 0, st>>>(Et, Vt, p.Tp, p.Kp, p.Cp, ktiles, ctiles, Mw);
+    wino_gemm_kernel<<<36 * ktiles * ctiles * p.nsplit, WG_THREADS, 0, st>>>(Et, Vt, p.Tp, p.Kp, p.Cp, ktiles, ctiles, p.nsplit, p.sps, Mw);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
-    wino_wrw_output_kernel<<<dim3(cdiv(C, 256), K), 256, 0, st>>>(Mw, K, C, p.Kp, p.Cp, dW);
+    wino_wrw_output_kernel<<<dim3(cdiv(C, 256), K), 256, 0, st>>>(Mw, p.nsplit, K, C, p.Kp, p.Cp, dW);
     return check_launch("wino_wrw_output_kernel");
 }
 
@@ -535,6 +629,30 @@ int ipsr_conv3x3_winograd(int op, const float* in, const float* weight, float* o
             return launch_winograd(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, ws, ws_bytes, st);
         default:     // ConvTranspose2d backward-data: dx = conv(dy, w as [ci][co]), reduction over Cout: (c=co, k=ci) at co*9 + ci*Cout*9
             return launch_winograd(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, ws, ws_bytes, st);
+    }
+}
+
+size_t ipsr_conv3x3_winograd_filter_floats(int op, int Cin, int Cout)
+{
+    if (op < 0 || op > 3 || Cin < 1 || Cout < 1) return 0;
+    const bool fwd = op == 0 || op == 2;
+    return winograd_filter_floats(fwd ? Cin : Cout, fwd ? Cout : Cin);
+}
+
+int ipsr_conv3x3_winograd_ex(int op, const float* in, const float* weight, const float* bias, int epilogue, float* filter_cache,
+                             int filter_cache_valid, float* out, int B, int Cin, int H, int W, int Cout,
+                             void* ws, size_t ws_bytes, void* stream)
+{
+    if (!in || !weight || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_ex: null pointer");
+    if (op < 0 || op > 3 || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_ex: bad argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u) || (reinterpret_cast<uintptr_t>(filter_cache) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_ex: out / workspace / filter_cache must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (op) {
+        case 0: return launch_winograd(in, weight, out, B, Cin, Cout, H, W, 9, (long)Cin * 9, 0, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
+        case 1: return launch_winograd(in, weight, out, B, Cout, Cin, H, W, (long)Cin * 9, 9, 1, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
+        case 2: return launch_winograd(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
+        default: return launch_winograd(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
     }
 }
 

@@ -79,18 +79,36 @@ class Vgg16(torch.nn.Module):
         self.load_state_dict(mapped)
 
     def _fused_slice(self, seq, x):
-        """No-grad HIP path of one slice (fp32, or bf16 activations under autocast): convolutions without bias (MIOpen has none; PyTorch would add it in a
-        separate pass), then ONE pass for bias + ReLU (+ the 2x2 max-pool when it follows) — ops.bias_act_ /
-        ops.bias_relu_pool2, bit-identical to Conv2d(bias) -> ReLU(inplace) -> MaxPool2d."""
+        """No-grad HIP path of one slice (fp32, or bf16 activations under autocast).  Per convolution:
+          * Winograd F(4x4,3x3) (csrc/winograd.hip) where models/hipconv.py selects it, with the bias + ReLU (+ the 2x2
+            max-pool when it follows) done in the kernel's output transform and the transformed filter cached per layer
+            (the weights are frozen);
+          * otherwise the convolution without bias (MIOpen has none; PyTorch would add it in a separate pass), then ONE pass
+            for bias + ReLU (+ pool) — ops.bias_act_ / ops.bias_relu_pool2.
+        Both are value-identical to Conv2d(bias) -> ReLU(inplace) -> MaxPool2d up to the convolution's own rounding."""
         from .. import ops
-        from .hipconv import conv_nobias
+        from . import hipconv
         mods = list(seq)
         i = 0
         while i < len(mods):
             m = mods[i]
             if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
-                y = conv_nobias(m, x)                      # Winograd F(4x4,3x3) / MIOpen per shape (models/hipconv.py)
-                if i + 2 < len(mods) and isinstance(mods[i + 2], nn.MaxPool2d) and y.size(2) % 2 == 0 and y.size(3) % 2 == 0:
+                pool = i + 2 < len(mods) and isinstance(mods[i + 2], nn.MaxPool2d) and x.size(2) % 2 == 0 and x.size(3) % 2 == 0
+                B, Cin, H, W = x.shape
+                if x.dtype == torch.float32 and not torch.is_autocast_enabled() and not m.weight.requires_grad and \
+                        hipconv.select(ops.CONV_FWD, B, Cin, H, W, m.out_channels, 3, 1, 1, 1) == "winograd":
+                    key = (m.weight.data_ptr(), m.weight._version, x.device)
+                    cache = getattr(m, "_ipsr_wino_filter", None)
+                    valid = cache is not None and cache[0] == key
+                    if not valid:
+                        cache = (key, ops.winograd_filter_cache(ops.CONV_FWD, Cin, m.out_channels, x.device))
+                        m._ipsr_wino_filter = cache
+                    x = ops.conv3x3_winograd(ops.CONV_FWD, x.contiguous(), m.weight, (B, Cin, H, W), m.out_channels, bias=m.bias,
+                                             epilogue="relu_pool" if pool else "relu", filter_cache=cache[1], filter_cache_valid=valid)
+                    i += 3 if pool else 2
+                    continue
+                y = hipconv.conv_nobias(m, x)
+                if pool:
                     x = ops.bias_relu_pool2(y, m.bias)
                     i += 3
                 else:

@@ -371,8 +371,19 @@ def winograd_supported(op, B, Cin, H, W, Cout):
     return _lib.lib().ipsr_conv3x3_winograd_workspace_bytes(op, B, Cin, H, W, Cout) > 0
 
 
-def conv3x3_winograd(op, inp, weight, in_shape, Cout):
-    """k3 s1 p1 convolution / transposed convolution / their input gradients by Winograd F(4x4,3x3) (ipsr_conv3x3_winograd)."""
+_EPILOGUE = {None: 0, "none": 0, "relu": 1, "relu_pool": 2}
+
+
+def winograd_filter_cache(op, Cin, Cout, device):
+    """An empty buffer for the transformed filter of one layer (see conv3x3_winograd's `filter_cache`)."""
+    n = _lib.lib().ipsr_conv3x3_winograd_filter_floats(op, Cin, Cout)
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def conv3x3_winograd(op, inp, weight, in_shape, Cout, bias=None, epilogue=None, filter_cache=None, filter_cache_valid=False):
+    """k3 s1 p1 convolution / transposed convolution / their input gradients by Winograd F(4x4,3x3) (ipsr_conv3x3_winograd_ex).
+    epilogue: None | "relu" (out = relu(conv + bias)) | "relu_pool" (... followed by the 2x2 max-pool; output [.,.,H/2,W/2]);
+    filter_cache: buffer from `winograd_filter_cache`; the transformed filter is written into it unless filter_cache_valid."""
     B, Cin, H, W = in_shape
     inp = _req(inp, torch.float32, "conv input")
     weight = _req(weight, torch.float32, "conv weight")
@@ -381,14 +392,24 @@ def conv3x3_winograd(op, inp, weight, in_shape, Cout):
     want_w = (Cout, Cin, 3, 3) if op in (CONV_FWD, CONV_BWD_DATA) else (Cin, Cout, 3, 3)
     if tuple(inp.shape) != want_in or tuple(weight.shape) != want_w:
         raise RuntimeError("conv3x3_winograd op %d: input %s / weight %s do not match %s / %s" % (op, tuple(inp.shape), tuple(weight.shape), want_in, want_w))
-    out = torch.empty((B, Cout, H, W) if fwd else (B, Cin, H, W), dtype=torch.float32, device=inp.device)
+    epi = _EPILOGUE[epilogue]
+    if epi and not fwd:
+        raise ValueError("conv3x3_winograd: an epilogue only makes sense on a forward op")
+    if epi == 2 and (H % 2 or W % 2):
+        raise RuntimeError("conv3x3_winograd: relu_pool needs even extents, got %dx%d" % (H, W))
+    kout = Cout if fwd else Cin
+    oshape = (B, kout, H // 2, W // 2) if epi == 2 else (B, kout, H, W)
+    out = torch.empty(oshape, dtype=torch.float32, device=inp.device)
     L = _lib.lib()
     nbytes = L.ipsr_conv3x3_winograd_workspace_bytes(op, B, Cin, H, W, Cout)
     if nbytes == 0:
         raise NotImplementedError("ipsr_conv3x3_winograd: op %d Cin=%d Cout=%d is not implemented" % (op, Cin, Cout))
+    if filter_cache is not None and filter_cache.numel() != L.ipsr_conv3x3_winograd_filter_floats(op, Cin, Cout):
+        raise RuntimeError("conv3x3_winograd: filter_cache has the wrong size")
     ws = _workspace(nbytes, inp.device)
-    _lib.check(L.ipsr_conv3x3_winograd(op, inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout,
-                                       ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv3x3_winograd")
+    _lib.check(L.ipsr_conv3x3_winograd_ex(op, inp.data_ptr(), weight.data_ptr(), _ptr(_f32(bias)), epi, _ptr(filter_cache),
+                                          int(bool(filter_cache_valid)), out.data_ptr(), B, Cin, H, W, Cout,
+                                          ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv3x3_winograd_ex")
     return out
 
 

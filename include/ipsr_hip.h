@@ -219,6 +219,16 @@ size_t ipsr_conv3x3_winograd_workspace_bytes(int op, int B, int Cin, int H, int 
 int ipsr_conv3x3_winograd(int op, const float* in, const float* weight, float* out, int B, int Cin, int H, int W, int Cout,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* The same with an epilogue and a reusable filter transform — the VGG16 chain Conv2d(bias) -> ReLU(inplace) [-> MaxPool2d(2,2)]
+ * (models/vgg16.py:9-21, run three times per step on FROZEN weights) in one pass over the activations:
+ *   epilogue 0 none | 1 = out = relu(conv + bias[k]) | 2 = out = maxpool2x2(relu(conv + bias[k])), out [.,.,H/2,W/2] (H, W even)
+ *   filter_cache (optional, ipsr_conv3x3_winograd_filter_floats(op, Cin, Cout) floats owned by the caller): the transformed
+ *   filter is written there when filter_cache_valid == 0 and reused unchanged when != 0.  bias may be NULL. */
+size_t ipsr_conv3x3_winograd_filter_floats(int op, int Cin, int Cout);
+int ipsr_conv3x3_winograd_ex(int op, const float* in, const float* weight, const float* bias, int epilogue, float* filter_cache,
+                             int filter_cache_valid, float* out, int B, int Cin, int H, int W, int Cout,
+                             void* ws, size_t ws_bytes, void* stream);
+
 /* Weight gradient of the same 3x3 / stride 1 / pad 1 layers by Winograd F(3x3,4x4) (the transposed algorithm: 4x4 tiles of one
  * operand against 6x6 windows of the other, reduced over all tiles of the batch on the matrix cores):
  *   transposed = 0  Conv2d           dw [Cout,Cin,3,3] = sum dy[.,co,o] * x[.,ci,o+r-1]

@@ -93,6 +93,31 @@ def test_winograd_f4x4_3x3_vs_fp64(kind, Cin, H, W, Cout):
     assert not ops.winograd_supported(fop, B, 24, H, W, Cout)          # reduction channels must be a multiple of 16: refuses
 
 
+@pytest.mark.parametrize("Cin,H,W,Cout,B", [(64, 16, 16, 96, 2), (1024, 16, 16, 512, 8), (32, 6, 10, 40, 3)])
+def test_winograd_fused_epilogues_and_filter_cache(Cin, H, W, Cout, B):
+    """ipsr_conv3x3_winograd_ex: bias + ReLU and bias + ReLU + 2x2 max-pool in the output transform (the VGG16 chain), the
+    cached filter transform, and the split reduction (the 1024 -> 512 @ 16x16 case splits 3 ways): equal to the plain call
+    followed by torch's bias / relu / max_pool2d, bit for bit (same GEMM, same sums)."""
+    from deepinpainting_amd import ops
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    plain = ops.conv3x3_winograd(ops.CONV_FWD, x, w, (B, Cin, H, W), Cout)
+    y64 = F.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1)
+    assert _rel(plain, y64) <= 1e-4
+    want_relu = torch.relu(plain + bias.view(1, -1, 1, 1))
+    cache = ops.winograd_filter_cache(ops.CONV_FWD, Cin, Cout, x.device)
+    got = ops.conv3x3_winograd(ops.CONV_FWD, x, w, (B, Cin, H, W), Cout, bias=bias, epilogue="relu", filter_cache=cache)
+    assert torch.equal(got, want_relu)
+    got2 = ops.conv3x3_winograd(ops.CONV_FWD, x, w, (B, Cin, H, W), Cout, bias=bias, epilogue="relu_pool", filter_cache=cache, filter_cache_valid=True)
+    assert torch.equal(got2, F.max_pool2d(want_relu, 2, 2))
+    # a stale cache is really used (proves the cached path skips the filter transform): zero it -> zero convolution
+    cache.zero_()
+    z = ops.conv3x3_winograd(ops.CONV_FWD, x, w, (B, Cin, H, W), Cout, bias=None, epilogue=None, filter_cache=cache, filter_cache_valid=True)
+    assert not z.any()
+
+
 @pytest.mark.parametrize("kind,Cin,H,W,Cout", [("conv", 32, 16, 16, 48), ("conv", 128, 32, 32, 160), ("conv", 20, 9, 13, 7),
                                                ("convT", 64, 16, 16, 24), ("convT", 256, 12, 20, 64), ("conv", 16, 4, 4, 16)])
 def test_winograd_weight_gradient_f3x3_4x4_vs_fp64(kind, Cin, H, W, Cout):
