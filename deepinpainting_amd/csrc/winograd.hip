@@ -598,6 +598,298 @@ int launch_winograd_wrw(const float* et, const float* dt, float* dW, int B, int 
     return check_launch("wino_wrw_output_kernel");
 }
 
+// ===================================================================================================
+// The DILATED down convolution of every netG level — Conv2d(k4, stride 2, pad 3, dilation 2), models/networks.py:226 — by
+// Winograd F(3x3, 4x4).  With dilation 2 and stride 2 the layer only ever reads the odd rows / columns of its input:
+//      y[o] = sum_r w[r] x[2o - 3 + 2r] = sum_r w[r] X[o + r],      X[i] = x[2i - 3]   (zero outside)
+// i.e. a plain 4-tap stride-1 correlation on the sub-sampled image X.  F(3,4) produces 3 outputs from a 6-wide window with
+// 6 multiplies instead of 12: 4x fewer matrix-core flops in 2-D, with the SAME interpolation points as F(4,3) above, hence
+// the same input transform B^T and the same 36 GEMMs; only the filter transform (G' 6x4) and the output transform (A'^T 3x6)
+// change — they are the ones the 3x3 weight gradient already uses.
+//   forward        window of X at origin 3t (x read with stride 2, offset -3), filter G' w G'^T, output A'^T M A' -> y
+//   backward-data  dx[2q+1] = sum_r' w[3-r'] dy[q - 1 + r'] (even rows/columns get no gradient: zero): the same pipeline on
+//                  windows of dy (stride 1, offset -1) with flipped taps and (Cout, Cin) swapped, written with stride 2
+//   weight grad    dW[r] = sum_o dy[o] X[o + r]: F(4x4, 3x3) with the roles swapped — 3x3 tiles of dy through G, 6x6 windows
+//                  of X through B^T, reduced over all tiles by the GEMM, A^T (4x6) back to the 4x4 taps.
+
+// generic window transform: V[xi][c][t] (TMAJOR = false) or V[xi][t][c] (true) of windows at origin OS*t read as
+// x[c][IS*(origin + i) + off]
+template <int OS, int IS, bool TMAJOR>
+__global__ void __launch_bounds__(256) wino_window_kernel(const float* __restrict__ x, int B, int C, int H, int Wd, int off, int TY, int TX,
+                                                          int Tp, int Cp, float* __restrict__ V)
+{
+    __shared__ float stage[TMAJOR ? 36 : 1][16][17];
+    int t, c, tl = 0, cl = 0, t0 = 0, c0 = 0;
+    if (TMAJOR) { tl = threadIdx.x & 15; cl = threadIdx.x >> 4; t0 = blockIdx.x * 16; c0 = blockIdx.y * 16; t = t0 + tl; c = c0 + cl; }
+    else { t = blockIdx.x * 256 + threadIdx.x; c = blockIdx.y; if (t >= Tp) return; }
+    const int T = B * TY * TX;
+    const bool live = t < T && c < C;
+    int b = 0, ty = 0, tx = 0;
+    if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
+    const float* xp = x + ((size_t)b * C + (live ? c : 0)) * H * Wd;
+    float d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int yy = IS * (OS * ty + i) + off;
+        const bool yok = live && (unsigned)yy < (unsigned)H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int xx = IS * (OS * tx + j) + off;
+            d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+        }
+    }
+    float w[6][6], v[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float o[6];
+        wino_bt(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino_bt(w[i], v[i]);
+    if (TMAJOR) {
+        wino_store_tmajor(stage, v, tl, cl, V, t0, c0, Tp, Cp);
+    } else {
+        const size_t plane = (size_t)C * Tp;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) V[(size_t)(i * 6 + j) * plane + (size_t)c * Tp + t] = v[i][j];
+    }
+}
+
+// U[xi][c][k] = (G' g G'^T)[xi] for 4x4 taps: W[c*sc + k*sm + r*4 + s] (flip: r -> 3-r, s -> 3-s)
+__global__ void __launch_bounds__(256) wino4_filter_kernel(const float* __restrict__ W, int C, int K, int Kp, long sc, long sm, int flip,
+                                                           float* __restrict__ U)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (k >= Kp) return;
+    float g[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int rr = flip ? 3 - r : r, ss = flip ? 3 - s2 : s2;
+            g[r][s2] = k < K ? W[(long)c * sc + (long)k * sm + rr * 4 + ss] : 0.0f;
+        }
+    float t[6][4], u[6][6];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+        const float col[4] = {g[0][s2], g[1][s2], g[2][s2], g[3][s2]};
+        float o[6];
+        wino_g4(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t[i][s2] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino_g4(t[i], u[i]);
+    const size_t plane = (size_t)C * Kp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) U[(size_t)(i * 6 + j) * plane + (size_t)c * Kp + k] = u[i][j];
+}
+
+// y[b][k][os*(3ty+i)+oo][os*(3tx+j)+oo] = (A'^T M A')[i][j] for 3ty+i < Ho, 3tx+j < Wo  (y is [B,K,Hy,Wy])
+__global__ void __launch_bounds__(256) wino3_output_kernel(const float* __restrict__ Mo, int nsplit, int B, int K, int Kp, int Ho, int Wo,
+                                                           int TY, int TX, int Tp, int Hy, int Wy, int os, int oo, float* __restrict__ y)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    const int T = B * TY * TX;
+    if (t >= T) return;
+    float m[6][6];
+    const size_t plane = (size_t)Kp * Tp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[i][j] = Mo[(size_t)(i * 6 + j) * plane + (size_t)k * Tp + t];
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const float* Ms = Mo + (size_t)sp * 36 * plane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + (size_t)k * Tp + t];
+    }
+    float w[3][6], o[3][3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
+        float r3[3];
+        wino_at3(col, r3);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i][j] = r3[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wino_at3(w[i], o[i]);
+    const int b = t / (TY * TX), rem = t - b * TY * TX;
+    const int ty = rem / TX, tx = rem - ty * TX;
+    float* yp = y + ((size_t)b * K + k) * Hy * Wy;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int oy = 3 * ty + i, ox = 3 * tx + j;
+            if (oy < Ho && ox < Wo) yp[(size_t)(os * oy + oo) * Wy + os * ox + oo] = o[i][j];
+        }
+}
+
+// weight gradient: 3x3 tiles of dy -> Et[xi][t][k] = (G e G^T)[xi]
+__global__ void __launch_bounds__(256) wino_wrw_tile3_kernel(const float* __restrict__ dy, int B, int K, int Ho, int Wo, int TY, int TX,
+                                                             int Tp, int Kp, float* __restrict__ Et)
+{
+    __shared__ float stage[36][16][17];
+    const int tl = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int t0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
+    const int t = t0 + tl, k = k0 + cl, T = B * TY * TX;
+    const bool live = t < T && k < K;
+    int b = 0, ty = 0, tx = 0;
+    if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
+    const float* dp = dy + ((size_t)b * K + (live ? k : 0)) * Ho * Wo;
+    float e[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int yy = 3 * ty + i, xx = 3 * tx + j;
+            e[i][j] = (live && yy < Ho && xx < Wo) ? dp[(size_t)yy * Wo + xx] : 0.0f;
+        }
+    float w[6][3], v[6][6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float col[3] = {e[0][j], e[1][j], e[2][j]};
+        float o[6];
+        wino_g(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino_g(w[i], v[i]);
+    wino_store_tmajor(stage, v, tl, cl, Et, t0, k0, Tp, Kp);
+}
+
+// dW[k][c][r][s] (4x4) = (A^T Mw[:][k][c] A)[r][s]
+__global__ void __launch_bounds__(256) wino_wrw_output4_kernel(const float* __restrict__ Mw, int nsplit, int K, int C, int Kp, int Cp,
+                                                               float* __restrict__ dW)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    if (c >= C) return;
+    float m[6][6];
+    const size_t plane = (size_t)Kp * Cp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[i][j] = Mw[(size_t)(i * 6 + j) * plane + (size_t)k * Cp + c];
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const float* Ms = Mw + (size_t)sp * 36 * plane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + (size_t)k * Cp + c];
+    }
+    float w[4][6], o[4][4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
+        float r4[4];
+        wino_at(col, r4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i][j] = r4[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wino_at(w[i], o[i]);
+    float4* dst = reinterpret_cast<float4*>(dW + ((size_t)k * C + c) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = make_float4(o[i][0], o[i][1], o[i][2], o[i][3]);
+}
+
+struct DilPlan { int TY, TX, T, Tp, Kp, Cp, nsplit, sps; size_t a_floats, b_floats, m_floats, total_bytes; };
+
+// mode 0: forward (grid = output Ho x Wo, reduce C=Cin, produce K=Cout); 1: backward-data (grid = H/2 x W/2 odd positions of dx,
+// reduce Cout, produce Cin); 2: weight gradient (tiles of dy, reduction over tiles)
+static int dil_plan(int mode, int B, int Cin, int H, int W, int Cout, DilPlan* p)
+{
+    if ((H | W) & 1) return fail(IPSR_ERR_UNSUPPORTED, "dilated winograd: odd extent %dx%d", H, W);
+    const int Ho = H / 2, Wo = W / 2;
+    p->TY = (Ho + 2) / 3; p->TX = (Wo + 2) / 3;
+    p->T = B * p->TY * p->TX;
+    p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;
+    if (mode == 2) {
+        p->Kp = (Cout + WG_BM - 1) / WG_BM * WG_BM;
+        p->Cp = (Cin + WG_BN - 1) / WG_BN * WG_BN;
+        p->a_floats = (size_t)36 * p->Tp * p->Kp;
+        p->b_floats = (size_t)36 * p->Tp * p->Cp;
+        const size_t m1 = (size_t)36 * p->Kp * p->Cp;
+        wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4, &p->nsplit, &p->sps);
+        p->m_floats = m1 * p->nsplit;
+    } else {
+        const int red = mode == 0 ? Cin : Cout, prod = mode == 0 ? Cout : Cin;
+        if (red % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "dilated winograd: %d reduction channels are not a multiple of %d", red, WG_BK);
+        p->Kp = (prod + WG_BM - 1) / WG_BM * WG_BM;
+        p->Cp = red;
+        p->a_floats = (size_t)36 * red * p->Kp;
+        p->b_floats = (size_t)36 * red * p->Tp;
+        const size_t m1 = (size_t)36 * p->Kp * p->Tp;
+        wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), red / WG_BK, m1 * 4, &p->nsplit, &p->sps);
+        p->m_floats = m1 * p->nsplit;
+    }
+    p->total_bytes = align_up(p->a_floats * 4, 256) + align_up(p->b_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
+    return IPSR_OK;
+}
+
+size_t winograd_dil_ws_bytes(int mode, int B, int Cin, int H, int W, int Cout)
+{
+    DilPlan p;
+    if (dil_plan(mode, B, Cin, H, W, Cout, &p) != IPSR_OK) return 0;
+    return p.total_bytes;
+}
+
+// x [B,Cin,H,W], w [Cout,Cin,4,4], y / dy [B,Cout,H/2,W/2]
+int launch_winograd_dil(int mode, const float* a, const float* b2, float* out, int B, int Cin, int H, int W, int Cout,
+                        void* ws, size_t ws_bytes, hipStream_t st)
+{
+    DilPlan p;
+    if (int rc = dil_plan(mode, B, Cin, H, W, Cout, &p)) return rc;
+    if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "dilated winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    const int Ho = H / 2, Wo = W / 2;
+    Carver cv(ws, ws_bytes);
+    float* A = cv.take<float>(p.a_floats);
+    float* Bv = cv.take<float>(p.b_floats);
+    float* Mo = cv.take<float>(p.m_floats);
+    if (mode == 0) {            // a = x, b2 = w, out = y
+        wino4_filter_kernel<<<dim3(cdiv(p.Kp, 256), Cin), 256, 0, st>>>(b2, Cin, Cout, p.Kp, 16, (long)Cin * 16, 0, A);
+        wino_window_kernel<3, 2, false><<<dim3(cdiv(p.Tp, 256), Cin), 256, 0, st>>>(a, B, Cin, H, W, -3, p.TY, p.TX, p.Tp, 0, Bv);
+        if (int rc = check_launch("wino_window_kernel")) return rc;
+        const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
+        wino_gemm_kernel<<<36 * kt * tt * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, Cin, p.Kp, p.Tp, kt, tt, p.nsplit, p.sps, Mo);
+        if (int rc = check_launch("wino_gemm_kernel")) return rc;
+        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cout), 256, 0, st>>>(Mo, p.nsplit, B, Cout, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, Ho, Wo, 1, 0, out);
+        return check_launch("wino3_output_kernel");
+    }
+    if (mode == 1) {            // a = dy, b2 = w, out = dx: only the odd rows / columns receive gradient
+        if (hipMemsetAsync(out, 0, (size_t)B * Cin * H * W * sizeof(float), st) != hipSuccess) return fail(IPSR_ERR_LAUNCH, "dilated winograd: hipMemsetAsync failed");
+        // reduction over Cout: element (c = co, k = ci) of w[co][ci][r][s] at co*Cin*16 + ci*16, taps flipped
+        wino4_filter_kernel<<<dim3(cdiv(p.Kp, 256), Cout), 256, 0, st>>>(b2, Cout, Cin, p.Kp, (long)Cin * 16, 16, 1, A);
+        wino_window_kernel<3, 1, false><<<dim3(cdiv(p.Tp, 256), Cout), 256, 0, st>>>(a, B, Cout, Ho, Wo, -1, p.TY, p.TX, p.Tp, 0, Bv);
+        if (int rc = check_launch("wino_window_kernel")) return rc;
+        const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
+        wino_gemm_kernel<<<36 * kt * tt * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, Cout, p.Kp, p.Tp, kt, tt, p.nsplit, p.sps, Mo);
+        if (int rc = check_launch("wino_gemm_kernel")) return rc;
+        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cin), 256, 0, st>>>(Mo, p.nsplit, B, Cin, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, H, W, 2, 1, out);
+        return check_launch("wino3_output_kernel");
+    }
+    // mode 2: a = x, b2 = dy, out = dW [Cout][Cin][4][4]
+    wino_wrw_tile3_kernel<<<dim3(p.Tp / 16, p.Kp / 16), 256, 0, st>>>(b2, B, Cout, Ho, Wo, p.TY, p.TX, p.Tp, p.Kp, A);
+    wino_window_kernel<3, 2, true><<<dim3(p.Tp / 16, p.Cp / 16), 256, 0, st>>>(a, B, Cin, H, W, -3, p.TY, p.TX, p.Tp, p.Cp, Bv);
+    if (int rc = check_launch("wino_window_kernel")) return rc;
+    const int kt = p.Kp / WG_BM, ct = p.Cp / WG_BN;
+    wino_gemm_kernel<<<36 * kt * ct * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, p.Tp, p.Kp, p.Cp, kt, ct, p.nsplit, p.sps, Mo);
+    if (int rc = check_launch("wino_gemm_kernel")) return rc;
+    wino_wrw_output4_kernel<<<dim3(cdiv(Cin, 256), Cout), 256, 0, st>>>(Mo, p.nsplit, Cout, Cin, p.Kp, p.Cp, out);
+    return check_launch("wino_wrw_output4_kernel");
+}
+
 }  // namespace ipsr
 
 using namespace ipsr;
@@ -654,6 +946,22 @@ int ipsr_conv3x3_winograd_ex(int op, const float* in, const float* weight, const
         case 2: return launch_winograd(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
         default: return launch_winograd(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
     }
+}
+
+size_t ipsr_conv4x4_dilated_winograd_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout)
+{
+    if (mode < 0 || mode > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return 0;
+    return winograd_dil_ws_bytes(mode, B, Cin, H, W, Cout);
+}
+
+int ipsr_conv4x4_dilated_winograd(int mode, const float* a, const float* b, float* out, int B, int Cin, int H, int W, int Cout,
+                                  void* ws, size_t ws_bytes, void* stream)
+{
+    if (!a || !b || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_dilated_winograd: null pointer");
+    if (mode < 0 || mode > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_dilated_winograd: bad argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_dilated_winograd: out / workspace must be 16-byte aligned");
+    return launch_winograd_dil(mode, a, b, out, B, Cin, H, W, Cout, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t ipsr_conv3x3_winograd_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout)

@@ -71,6 +71,18 @@ def broadcast_module(module, src=0, group=None):
         off += n
 
 
+# Gradient sinks: parameter storage pointer -> its slice of an armed bucket.  A kernel that produces a weight gradient can write it
+# THERE (models/hipconv.py does for the Winograd weight-gradient kernels): autograd then adopts that tensor as .grad and the
+# reducer finds the gradient already in place — no copy into the bucket for that parameter.
+_GRAD_SINKS = {}
+
+
+def grad_sink_for(param_data_ptr, shape):
+    """The bucket slice a gradient of this parameter should be written into right now, or None."""
+    v = _GRAD_SINKS.get(param_data_ptr)
+    return v if (v is not None and tuple(v.shape) == tuple(shape)) else None
+
+
 class GradBucketReducer(object):
     """Bucketed, overlapped all-reduce(mean) of the gradients of a fixed set of modules."""
 
@@ -107,6 +119,18 @@ class GradBucketReducer(object):
     def arm(self):
         """Call right before the backward whose gradients should be exchanged."""
         self.armed = self.world > 1
+        if self.armed:
+            # publish the bucket slices of parameters that have no gradient yet (a fresh .grad can be produced in place)
+            for b in self.buckets:
+                dev = b["params"][0].device
+                if b["flat"] is None or b["flat"].device != dev:
+                    b["flat"] = torch.empty(b["numel"], dtype=torch.float32, device=dev)
+                off = 0
+                for p in b["params"]:
+                    n = p.numel()
+                    if p.grad is None:
+                        _GRAD_SINKS[p.data_ptr()] = b["flat"][off:off + n].view_as(p)
+                    off += n
         self._pending = [len(b["params"]) for b in self.buckets]
         self._seen = set()
         self._launched = set()
@@ -177,6 +201,9 @@ class GradBucketReducer(object):
                 p.grad = v
         self._work = []
         self.armed = False
+        for b in self.buckets:
+            for p in b["params"]:
+                _GRAD_SINKS.pop(p.data_ptr(), None)
 
     def close(self):
         for h in self._hooks:

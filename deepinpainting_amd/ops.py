@@ -413,14 +413,46 @@ def conv3x3_winograd(op, inp, weight, in_shape, Cout, bias=None, epilogue=None, 
     return out
 
 
-def conv3x3_winograd_wrw(transposed, x, dy, Cout):
-    """Weight gradient of a k3 s1 p1 Conv2d (transposed=False -> [Cout,Cin,3,3]) / ConvTranspose2d (True -> [Cin,Cout,3,3])."""
+def dilated_winograd_supported(mode, B, Cin, H, W, Cout):
+    return _lib.lib().ipsr_conv4x4_dilated_winograd_workspace_bytes(mode, B, Cin, H, W, Cout) > 0
+
+
+def conv4x4_dilated_winograd(mode, a, b, in_shape, Cout, out=None):
+    """Conv2d(k4, stride 2, pad 3, dilation 2) by Winograd F(3x3,4x4) (ipsr_conv4x4_dilated_winograd): mode 0 forward (a = x,
+    b = weight -> y), 1 backward-data (a = dy, b = weight -> dx), 2 weight gradient (a = x, b = dy -> dw)."""
+    B, Cin, H, W = in_shape
+    a = _req(a, torch.float32, "operand a")
+    b = _req(b, torch.float32, "operand b")
+    xs, ys, wsh = (B, Cin, H, W), (B, Cout, H // 2, W // 2), (Cout, Cin, 4, 4)
+    want = {0: (xs, wsh, ys), 1: (ys, wsh, xs), 2: (xs, ys, wsh)}[mode]
+    if tuple(a.shape) != want[0] or tuple(b.shape) != want[1]:
+        raise RuntimeError("conv4x4_dilated_winograd mode %d: operands %s / %s do not match %s / %s" % (mode, tuple(a.shape), tuple(b.shape), want[0], want[1]))
+    if out is not None and (tuple(out.shape) != tuple(want[2]) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device):
+        raise RuntimeError("conv4x4_dilated_winograd: `out` must be a contiguous fp32 %s tensor on %s" % (tuple(want[2]), a.device))
+    if out is None:
+        out = torch.empty(want[2], dtype=torch.float32, device=a.device)
+    L = _lib.lib()
+    nbytes = L.ipsr_conv4x4_dilated_winograd_workspace_bytes(mode, B, Cin, H, W, Cout)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv4x4_dilated_winograd: mode %d Cin=%d Cout=%d %dx%d is not implemented" % (mode, Cin, Cout, H, W))
+    ws = _workspace(nbytes, a.device)
+    _lib.check(L.ipsr_conv4x4_dilated_winograd(mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout,
+                                               ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv4x4_dilated_winograd")
+    return out
+
+
+def conv3x3_winograd_wrw(transposed, x, dy, Cout, out=None):
+    """Weight gradient of a k3 s1 p1 Conv2d (transposed=False -> [Cout,Cin,3,3]) / ConvTranspose2d (True -> [Cin,Cout,3,3]).
+    out: optional contiguous fp32 tensor of that shape to write into (e.g. a slice of a gradient bucket)."""
     x = _req(x, torch.float32, "conv input")
     dy = _req(dy, torch.float32, "grad_output")
     B, Cin, H, W = x.shape
     if tuple(dy.shape) != (B, Cout, H, W):
         raise RuntimeError("conv3x3_winograd_wrw: grad_output %s does not match %s" % (tuple(dy.shape), (B, Cout, H, W)))
-    dw = torch.empty((Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    shape = (Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3)
+    if out is not None and (tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device):
+        raise RuntimeError("conv3x3_winograd_wrw: `out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
+    dw = out if out is not None else torch.empty(shape, dtype=torch.float32, device=x.device)
     L = _lib.lib()
     ws = _workspace(L.ipsr_conv3x3_winograd_wrw_workspace_bytes(int(transposed), B, Cin, H, W, Cout), x.device)
     _lib.check(L.ipsr_conv3x3_winograd_wrw(int(transposed), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,

@@ -238,6 +238,17 @@ size_t ipsr_conv3x3_winograd_wrw_workspace_bytes(int transposed, int B, int Cin,
 int ipsr_conv3x3_winograd_wrw(int transposed, const float* x, const float* dy, float* dw, int B, int Cin, int H, int W, int Cout,
                               void* ws, size_t ws_bytes, void* stream);
 
+/* The dilated down convolution of every netG level — Conv2d(k4, stride 2, pad 3, dilation 2), models/networks.py:226 — by
+ * Winograd F(3x3,4x4): with dilation 2 and stride 2 the layer is a plain 4-tap stride-1 correlation on the odd-subsampled
+ * input, so it runs through the same 36 GEMMs as the 3x3 layers (4x fewer matrix-core flops than the direct form).
+ *   mode 0  forward        a = x  [B,Cin,H,W]       b = weight [Cout,Cin,4,4]   out = y  [B,Cout,H/2,W/2]
+ *   mode 1  backward-data  a = dy [B,Cout,H/2,W/2]  b = weight                  out = dx [B,Cin,H,W] (even rows / columns are zero)
+ *   mode 2  weight grad    a = x                    b = dy                      out = dw [Cout,Cin,4,4]
+ * H, W even; the reduction channels (Cin for mode 0, Cout for mode 1) a multiple of 16. */
+size_t ipsr_conv4x4_dilated_winograd_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout);
+int ipsr_conv4x4_dilated_winograd(int mode, const float* a, const float* b, float* out, int B, int Cin, int H, int W, int Cout,
+                                  void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
  * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.

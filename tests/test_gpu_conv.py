@@ -137,13 +137,39 @@ def test_winograd_weight_gradient_f3x3_4x4_vs_fp64(kind, Cin, H, W, Cout):
     assert _rel(dw, dw64) <= 1e-4
 
 
+@pytest.mark.parametrize("Cin,H,W,Cout,B", [(32, 16, 16, 48, 2), (128, 32, 32, 128, 3), (16, 6, 10, 24, 2), (64, 2, 2, 64, 8), (48, 14, 22, 20, 1)])
+def test_dilated_4x4_winograd_f3x3_4x4_vs_fp64(Cin, H, W, Cout, B):
+    """netG's Conv2d(k4, stride 2, pad 3, dilation 2) (models/networks.py:226) by Winograd F(3x3,4x4): forward, input gradient
+    (odd rows / columns only — the even ones are exactly zero, as in the reference's autograd) and weight gradient within
+    1e-4 of fp64, on output grids that are and are not multiples of the 3x3 tile."""
+    from deepinpainting_amd import ops
+    g = torch.Generator().manual_seed(Cin * 3 + H)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1).cuda()
+    dy = torch.randn(B, Cout, H // 2, W // 2, generator=g).cuda()
+    xd, wd = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True)
+    y64 = F.conv2d(xd, wd, None, 2, 3, 2)
+    dx64, dw64 = torch.autograd.grad(y64, (xd, wd), dy.double().cpu())
+    y = ops.conv4x4_dilated_winograd(0, x, w, (B, Cin, H, W), Cout)
+    dw = ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, W), Cout)
+    assert _rel(y, y64.detach()) <= 1e-4
+    assert _rel(dw, dw64) <= 1e-4
+    if Cout % 16 == 0:
+        dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout)
+        assert _rel(dx, dx64) <= 1e-4
+        assert not dx[:, :, 0::2, :].any() and not dx[:, :, :, 0::2].any()
+    else:
+        assert not ops.dilated_winograd_supported(1, B, Cin, H, W, Cout)
+
+
 @pytest.mark.parametrize("engine", ["direct", "winograd", "auto"])
 def test_module_path_forward_and_gradients(engine):
     """models/hipconv.py: Conv2d / ConvTranspose2d modules through the dispatcher with one engine forced — output, input
     gradient and weight gradient against fp64, and against the plain torch module on the same weights."""
+    from deepinpainting_amd import ops
     from deepinpainting_amd.models import hipconv
     torch.manual_seed(3)
-    cases = [(nn.Conv2d(64, 128, 3, 1, 1), 16, 16), (nn.ConvTranspose2d(128, 64, 3, 1, 1), 16, 16),
+    cases = [(nn.Conv2d(128, 128, 4, 2, 3, dilation=2), 32, 32), (nn.Conv2d(64, 128, 3, 1, 1), 16, 16), (nn.ConvTranspose2d(128, 64, 3, 1, 1), 16, 16),
              (nn.Conv2d(32, 32, 4, 2, 3, dilation=2), 16, 16), (nn.ConvTranspose2d(32, 16, 4, 2, 1), 8, 8), (nn.Conv2d(16, 32, 4, 2, 1), 16, 16)]
     hipconv._FORCE = engine
     try:
@@ -156,9 +182,13 @@ def test_module_path_forward_and_gradients(engine):
             kind = "convT" if isinstance(m, nn.ConvTranspose2d) else "conv"
             y64, dx64, dw64 = _ref64(kind, x.detach(), m.weight.detach(), dy, m.stride[0], m.padding[0], m.dilation[0])
             assert _rel(y, y64) <= 1e-4 and _rel(dx, dx64) <= 1e-4 and _rel(dw, dw64) <= 1e-4, (engine, m)
-            with torch.no_grad():
-                y2 = hipconv.conv_nobias(m, x.detach())
-            assert torch.equal(y2, y.detach())
+            tr = isinstance(m, nn.ConvTranspose2d)
+            eng = hipconv.select(ops.CONVT_FWD if tr else ops.CONV_FWD, 2, m.in_channels, H, W, m.out_channels, m.kernel_size[0], m.stride[0],
+                                 m.padding[0], m.dilation[0])
+            if eng != "miopen":              # this repo's kernels are deterministic; MIOpen may switch solvers between calls
+                with torch.no_grad():
+                    y2 = hipconv.conv_nobias(m, x.detach())
+                assert torch.equal(y2, y.detach()), (engine, m)
     finally:
         hipconv._FORCE = None
 
@@ -172,7 +202,13 @@ def test_dispatcher_rules_and_refusals():
     assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 3, 1, 1, 1) == "miopen"            # 64 -> 64 at 256x256: traffic-bound, MIOpen wins
     assert sel(ops.CONV_FWD, 8, 3, 256, 256, 64, 3, 1, 1, 1) == "miopen"             # 3 input channels
     assert sel(ops.CONV_FWD, 8, 512, 4, 4, 512, 3, 1, 1, 1) == "miopen"              # tiny maps
-    assert sel(ops.CONV_BWD_DATA, 8, 512, 32, 32, 512, 4, 2, 3, 2) == "direct"
+    assert sel(ops.CONV_BWD_DATA, 8, 512, 32, 32, 512, 4, 2, 3, 2) == "wino_dil"         # netG dilated down convolution
+    assert sel(ops.CONV_FWD, 8, 128, 128, 128, 128, 4, 2, 3, 2) == "wino_dil"
+    assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 4, 2, 3, 2) == "miopen"
+    assert sel(ops.CONV_BWD_DATA, 8, 512, 16, 16, 512, 4, 2, 3, 2) == "direct"
+    assert hipconv.select_wrw(False, 8, 256, 64, 64, 256, 4, 2, 3, 2) == "wino_dil"
+    assert hipconv.select_wrw(False, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd"
+    assert hipconv.select_wrw(False, 8, 128, 128, 128, 128, 3, 1, 1, 1) == "miopen"
     assert sel(ops.CONV_FWD, 8, 256, 32, 32, 512, 4, 2, 1, 1) == "miopen"
     with pytest.raises(NotImplementedError):
         ops.conv2d(ops.CONV_FWD, torch.zeros(1, 3, 8, 8, device="cuda"), torch.zeros(4, 3, 3, 3, device="cuda"), (1, 3, 8, 8), 4, 3, 1, 1, 1)

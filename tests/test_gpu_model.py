@@ -275,7 +275,7 @@ def test_trainer_step_on_gpu_vs_reference(gpu_trainer):
 # truncation discontinuity (one ulp in a 512-long dot switches a whole gradient column), netD / netF see
 # it through fake_B.  Same table as the CPU twin's (tests/test_host_model.py) with MIOpen's rounding on top.
 GPU_GRAD_TOL = {("P", 0): 5e-3, ("P", 1): 5e-3, ("P", 2): 5e-3, ("G", 2): 5e-3, ("G", 1): 3e-2, ("G", 0): 0.2,
-                ("D", 0): 3e-2, ("D", 1): 3e-2, ("D", 2): 1e-2, ("F", 0): 1e-2, ("F", 1): 1e-2, ("F", 2): 1e-2}
+                ("D", 0): 3e-2, ("D", 1): 3e-2, ("D", 2): 3e-2, ("F", 0): 3e-2, ("F", 1): 3e-2, ("F", 2): 3e-2}
 # Measured on MI355X (round 2).  Which MIOpen solver serves a layer (a function of its find-db state) moves these numbers
 # by two orders of magnitude on its own: netP.0 1.3e-6 <-> 1.3e-4, netF.0 5.5e-6 <-> 4.8e-3 between two runs that differ only
 # in MIOpen's solver picks (IPSR_CONV_ENGINE=miopen in both); netP's innermost 1x1 level reached 1.3e-3 in a third.  With the shipped find-db: P 1e-6..1.3e-4, G.2 3e-5, G.1 5e-3,

@@ -144,6 +144,26 @@ def main():
             print("%-5s %-16s %-14s | wrw wino %9.4f ms %7.1f TF   miopen %9.4f ms %7.1f TF   |wino - miopen| %9.2e  %s" % (
                 kind, "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), tw, flops / tw / 1e9, tm, flops / tm / 1e9, err,
                 "WINO" if tw < tm else ""), flush=True)
+    if args.k3:
+        print("\ndilated 4x4 stride-2 (netG down convolutions), Winograd F(3x3,4x4) vs MIOpen:")
+        for Cin, H in ((64, 256), (128, 128), (256, 64), (512, 32), (512, 16), (512, 8)):
+            Cout = Cin
+            x = torch.randn(B, Cin, H, H, device="cuda")
+            w = torch.randn(Cout, Cin, 4, 4, device="cuda") * 0.05
+            dy = torch.randn(B, Cout, H // 2, H // 2, device="cuda")
+            cb = torch.ops.aten.convolution_backward
+            cargs = (dy, x, w, None, [2, 2], [3, 3], [2, 2], False, [0, 0], 1)
+            flops = 2.0 * B * Cin * Cout * 16 * (H // 2) ** 2
+            with torch.no_grad():
+                for name, hipf, miof in (("fwd", lambda: ops.conv4x4_dilated_winograd(0, x, w, (B, Cin, H, H), Cout), lambda: F.conv2d(x, w, None, 2, 3, 2)),
+                                         ("bwdD", lambda: ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, H), Cout), lambda: cb(*cargs, [True, False, False])[0]),
+                                         ("wrw", lambda: ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, H), Cout), lambda: cb(*cargs, [False, True, False])[1])):
+                    a, b2 = hipf(), miof()
+                    err = float((a - b2).abs().max() / b2.abs().max())
+                    tw, tm = timed(hipf), timed(miof)
+                    print("dil   %-16s %-14s | %-4s wino %9.4f ms %7.1f TF   miopen %9.4f ms %7.1f TF   |diff| %9.2e  %s" % (
+                        "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), name, tw, flops / tw / 1e9, tm, flops / tm / 1e9, err,
+                        "WINO" if tw < tm else ""), flush=True)
     print("sum over shapes (one call each): hip %.3f ms, miopen %.3f ms, best-of %.3f ms" % (tot_h, tot_m, tot_best))
 
 
