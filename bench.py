@@ -16,6 +16,8 @@ Rank 0 prints ONE JSON line.  `value` = images/s of the whole job (all ranks).  
   roofline      the layer's dominant kernel (fp32-MFMA correlation + arg-max): algorithmic FLOPs per launch
                 (2*N*N*C per sample) over its mean duration, measured live with HIP events on
                 the launch stream inside the timed steps (C-ABI hook ipsr_profile_*).
+  conv_roofline the convolutions' matrix-core kernel (ipsr::wino_gemm_kernel, all its launches in the timed steps): executed
+                flops over summed launch time, HIP events on the launch stream (region 3 of the C-ABI hook).
   cpu_baseline  the CPU twin (oracle C restatement of the layer + PyTorch-CPU convs, oracle/cpu_model.py)
                 timed on this host's cores on a bounded sample (rank 0, N=1 only).
   ipsr_layer_ms IPSR layer forward+backward at the same shape (second half of BASELINE.json's metric): `in_step` = HIP
@@ -314,6 +316,18 @@ def main():
         return [buf[i] for i in range(n)]
     kern_ms, fwd_in_step, bwd_in_step = read_region(0), read_region(1), read_region(2)
     lib.ipsr_profile_enable(0)
+    # region 3: every launch of the convolutions' matrix-core kernel (Winograd GEMM), with its flops — in a few EXTRA steps
+    # after the timed loop (~100 more event records per step would perturb the headline number)
+    gsteps = 3
+    lib.ipsr_profile_enable_mask(gsteps, 0x8)
+    for _ in range(gsteps):
+        train_step(model, img, mask, ref)
+    torch.cuda.synchronize()
+    ncap = 64 * gsteps
+    gms, gwork = (ctypes.c_float * ncap)(), (ctypes.c_double * ncap)()
+    ng = lib.ipsr_profile_read_region_work(3, ctypes.cast(gms, ctypes.c_void_p), ctypes.cast(gwork, ctypes.c_void_p), ncap)
+    gemm_ms, gemm_flops = sum(gms[i] for i in range(ng)), sum(gwork[i] for i in range(ng))
+    lib.ipsr_profile_enable(0)
 
     # the reference's exact sequence (strict_reference), same model and inputs, timed the same way after the headline loop
     strict = None
@@ -404,10 +418,20 @@ def main():
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,
                      "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": flops, "kernel_ms": round(kms, 5), "launches_timed": len(kern_ms)},
         # the whole step against the same roofline: direct-convolution FLOPs of the step AS EXECUTED here
+        # the convolutions' own matrix-core kernel: every launch of ipsr::wino_gemm_kernel (the 36 GEMMs of the Winograd
+        # F(4x4,3x3) / F(3x3,4x4) convolutions: VGG16, netG's 3x3 and dilated 4x4 layers, forward / input / weight gradients)
+        # inside the timed steps; flops = the multiplies the kernel executes (4x fewer than the direct convolutions it replaces)
+        "conv_roofline": {"kernel": "ipsr::wino_gemm_kernel (fp32 MFMA, 36 GEMMs per convolution)", "bound": "mfma",
+                          "achieved": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2) if ng else None, "peak": PEAK_FP32_MFMA_TFLOPS,
+                          "unit": "TFLOP/s", "frac": round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ng else None,
+                          "launches_timed": ng, "launches_per_step": round(ng / gsteps, 1),
+                          "kernel_ms_per_step": round(gemm_ms / gsteps, 3),
+                          "direct_equivalent_tflops": round(4.0 * gemm_flops / (gemm_ms * 1e-3) / 1e12, 1) if ng else None},
         "step_roofline": {"bound": "mfma", "flops_per_image": STEP_FLOPS_PER_IMAGE,
                           "achieved": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                           "unit": "TFLOP/s per GPU", "frac": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                          "note": "fp32 only; MIOpen's Winograd kernels execute fewer real multiplies than this direct count"}
+                          "note": "direct-convolution flop count of the step as executed; this repo's Winograd F(4x4,3x3)/F(3x3,4x4) kernels and "
+                                  "MIOpen's F(2x2,3x3)/F(3x3,2x2) execute fewer real multiplies than this count"}
         if args.dtype == "f32" else None,
         "strict_reference": strict,
         "losses_last_step": {k: round(v, 4) for k, v in errs.items()},

@@ -68,8 +68,10 @@ SIGNATURES = {
     "innercos_loss_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p]),
     "ipsr_profile_enable": (c_int, [c_int]),
+    "ipsr_profile_enable_mask": (c_int, [c_int, ctypes.c_uint]),
     "ipsr_profile_read": (c_int, [c_void_p, c_int]),
     "ipsr_profile_read_region": (c_int, [c_int, c_void_p, c_int]),
+    "ipsr_profile_read_region_work": (c_int, [c_int, c_void_p, c_void_p, c_int]),
 }
 
 

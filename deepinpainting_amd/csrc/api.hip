@@ -35,10 +35,12 @@ int check_launch(const char* what)
 }
 
 // ---- opt-in profiling rings ----------------------------------------------------------------------------
-// region 0: the correlation + arg-max kernel; 1: a whole ipsr_forward; 2: a whole ipsr_backward(_patch)
-constexpr int N_REGIONS = 3;
+// region 0: the correlation + arg-max kernel; 1: a whole ipsr_forward; 2: a whole ipsr_backward(_patch);
+// 3: every launch of the Winograd GEMM kernel (the convolutions' matrix-core kernel), with the launch's flop count
+constexpr int N_REGIONS = 4;
 struct EvRing {
     hipEvent_t* ev = nullptr;      // 2*capacity events: start0, stop0, start1, ...
+    double* work = nullptr;        // per entry: work units the caller attached (flops), 0 if none
     int cap = 0, n = 0;
     bool open = false;
 };
@@ -52,11 +54,12 @@ void profile_mark_start(hipStream_t st, int region)
     r.open = true;
 }
 
-void profile_mark_stop(hipStream_t st, int region)
+void profile_mark_stop(hipStream_t st, int region, double work)
 {
     EvRing& r = g_ring[region];
     if (!r.open) return;
     (void)hipEventRecord(r.ev[2 * r.n + 1], st);
+    r.work[r.n] = work;
     r.open = false;
     ++r.n;
 }
@@ -88,17 +91,21 @@ static FwdPlan plan_forward(int B, int C, int h, int w, int M, int patch, size_t
     FwdPlan p;
     p.K = C * patch * patch;
     p.N = (h - patch + 1) * (w - patch + 1);
-    p.ld = patch > 1 ? (p.N + 127) & ~127 : p.N;
+    p.ld = p.N;
     p.Cp = (p.K + 7) & ~7;
     p.Mc = M > 0 ? (M + 31) & ~31 : 32;
     const size_t Mx = M > 0 ? M : 1;
     size_t sz[WS_COUNT];
-    sz[WS_XN] = (size_t)B * p.K * p.ld * 4;
+    const size_t hw = (size_t)h * w;
+    // patch > 1 (shifted-sum form): WS_XN = the 1x1 correlation matrix R [B][hw][hw]; WS_XU = the per-position norms n1 [B][hw];
+    // WS_CORR = partials of the 1x1 correlation launch; WS_RU = partials of the window arg-max.  Nothing is unfolded but xT.
+    sz[WS_XN] = patch > 1 ? (size_t)B * hw * hw * 4 : (size_t)B * p.K * p.ld * 4;
     sz[WS_XT] = (size_t)B * p.N * p.Cp * 4;
     sz[WS_INV] = (size_t)B * p.N * 4;
-    sz[WS_CORR] = corr_bf16 ? corr_argmax_bf16_ws_bytes(B, p.K, p.N, p.ld) : corr_argmax_ws_bytes(B, p.K, p.N);
-    sz[WS_XU] = 0;                                        // (the unfolded x is no longer materialised)
-    sz[WS_RU] = patch > 1 ? (size_t)B * p.K * p.ld * 4 : 0;
+    if (patch > 1) sz[WS_CORR] = corr_argmax_ws_bytes(B, C, (int)hw);
+    else sz[WS_CORR] = corr_bf16 ? corr_argmax_bf16_ws_bytes(B, p.K, p.N, p.ld) : corr_argmax_ws_bytes(B, p.K, p.N);
+    sz[WS_XU] = patch > 1 ? (size_t)B * hw * 4 : 0;
+    sz[WS_RU] = patch > 1 ? window_corr_ws_bytes(B, p.N) : 0;
     sz[WS_OU] = patch > 1 ? (size_t)B * p.K * p.N * 4 : 0;
     sz[WS_WN] = sz[WS_WO] = sz[WS_KQ] = sz[WS_JQ] = (size_t)B * Mx * 4;
     sz[WS_DLIST] = (size_t)B * p.Mc * 4;
@@ -124,22 +131,29 @@ int ipsr_abi_version(void) { return 5; }
 
 const char* ipsr_last_error(void) { return g_err; }
 
-int ipsr_profile_enable(int capacity)
+int ipsr_profile_enable_mask(int capacity, unsigned region_mask)
 {
     for (EvRing& r : g_ring) {
         for (int i = 0; i < 2 * r.cap; ++i) (void)hipEventDestroy(r.ev[i]);
         delete[] r.ev;
+        delete[] r.work;
         r = EvRing();
     }
     if (capacity <= 0) return IPSR_OK;
-    for (EvRing& r : g_ring) {
-        r.ev = new hipEvent_t[2 * (size_t)capacity];
-        for (int i = 0; i < 2 * capacity; ++i)
+    for (int ri = 0; ri < N_REGIONS; ++ri) {
+        if (!((region_mask >> ri) & 1u)) continue;
+        EvRing& r = g_ring[ri];
+        const int cap_r = ri == 3 ? 64 * capacity : capacity;        // tens of GEMM launches per training step
+        r.work = new double[(size_t)cap_r];
+        r.ev = new hipEvent_t[2 * (size_t)cap_r];
+        for (int i = 0; i < 2 * cap_r; ++i)
             if (hipEventCreate(&r.ev[i]) != hipSuccess) return fail(IPSR_ERR_LAUNCH, "ipsr_profile_enable: hipEventCreate failed");
-        r.cap = capacity;
+        r.cap = cap_r;
     }
     return IPSR_OK;
 }
+
+int ipsr_profile_enable(int capacity) { return ipsr_profile_enable_mask(capacity, 0x7u); }
 
 int ipsr_profile_read_region(int region, float* ms, int max_n)
 {
@@ -157,6 +171,15 @@ int ipsr_profile_read_region(int region, float* ms, int max_n)
 }
 
 int ipsr_profile_read(float* ms, int max_n) { return ipsr_profile_read_region(0, ms, max_n); }
+
+int ipsr_profile_read_region_work(int region, float* ms, double* work, int max_n)
+{
+    if (!ms || !work || max_n < 0 || region < 0 || region >= N_REGIONS) return fail(IPSR_ERR_INVALID, "ipsr_profile_read_region_work: bad arguments");
+    EvRing& r = g_ring[region];
+    const int avail = r.n;
+    for (int i = 0; i < avail && i < max_n; ++i) work[i] = r.work[i];
+    return ipsr_profile_read_region(region, ms, max_n);
+}
 
 size_t ipsr_feat_mask_workspace_bytes(int H, int W, int layers)
 {
@@ -249,24 +272,26 @@ static int forward_impl(const float* x, const float* ref, const int32_t* mask_po
 
     // shift_sz > 1: from here on a "channel" is one of the K numbers of a patch and a "position" one of the N' windows.
     // The result comes back as patches and is overlap-added at the end.
-    const float* rs = ref;
     float* outs = out;
+    AttnArgs a{};                      // every field defined (mcount = NULL, mpi_stride = 0: one shared mask)
     if (patch > 1) {
-        // x is consumed through its normalised / patch-major copies only: those are produced straight from the feature;
-        // only the reference side (operand B of the correlation) is materialised unfolded
-        float* ru = reinterpret_cast<float*>(slice[WS_RU]);
-        if (int rc = launch_unfold(ref, B, C, h, w, patch, p.ld, ru, st)) return rc;
-        if (int rc = launch_unfold_normalize(x, B, C, h, w, patch, p.ld, xn, xT, p.Cp, inv, st)) return rc;
-        rs = ru;
+        if (corr_bf16) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward_bf16corr: shift_sz > 1 runs the fp32 shifted-sum correlation only");
+        // window norms + patch-major raw windows straight from the feature; the correlation of p x p windows = sums of shifted
+        // diagonals of the 1x1 correlation R = x^T ref (8x fewer flops at p = 3, nothing unfolded): corr_argmax.hip
+        float* R = xn;                                              // WS_XN slot
+        float* n1 = reinterpret_cast<float*>(slice[WS_XU]);
+        if (int rc = launch_window_prepare(x, B, C, h, w, patch, n1, inv, xT, p.Cp, st)) return rc;
+        CorrPartials unused;
+        if (int rc = launch_corr_argmax(x, ref, B, C, h * w, nullptr, nullptr, R, slice[WS_CORR], sz[WS_CORR], st, &unused, 0)) return rc;
+        if (int rc = launch_window_corr_argmax(R, inv, B, h, w, patch, slice[WS_RU], sz[WS_RU], st, &a.part)) return rc;
         outs = reinterpret_cast<float*>(slice[WS_OU]);
     } else {
         if (int rc = launch_patch_normalize(x, B, p.K, p.N, xn, xT, p.Cp, inv, st, p.ld, p.ld)) return rc;
-    }
-    AttnArgs a{};                      // every field defined (mcount = NULL, mpi_stride = 0: one shared mask)
-    if (corr_bf16) {
-        if (int rc = launch_corr_argmax_bf16(xn, rs, B, p.K, p.N, ind, vmax, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
-    } else {
-        if (int rc = launch_corr_argmax(xn, rs, B, p.K, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
+        if (corr_bf16) {
+            if (int rc = launch_corr_argmax_bf16(xn, ref, B, p.K, p.N, ind, vmax, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
+        } else {
+            if (int rc = launch_corr_argmax(xn, ref, B, p.K, p.N, ind, vmax, nullptr, slice[WS_CORR], sz[WS_CORR], st, &a.part, p.ld)) return rc;
+        }
     }
     a.xT = xT; a.inv = inv; a.ind = ind; a.vmax = vmax; a.mpi = mask_point_idx;
     a.mcount = mcount; a.mpi_stride = mpi_stride;

@@ -516,6 +516,88 @@ corr_argmax_bf16_kernel(const uint4* __restrict__ xnp, const uint4* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// shift_sz > 1: correlation of p x p windows as sums of shifted diagonals of the 1x1 correlation R = x^T ref
+//     S[k'][q'] = inv[k'] * sum_{dy,dx} R[(ky+dy)*w + kx+dx][(qy+dy)*w + qx+dx]
+// (oracle: window_corr_argmax).  R [B][hw][hw] comes from corr_argmax_*_kernel<WRITE_S> on the RAW features: 2*N*N*C flop
+// instead of the 2*N'*N'*C*p*p of contracting unfolded patches (8x fewer at p = 3), and nothing is unfolded.  This kernel is
+// the p*p-tap stencil + running arg-max: thread = window q', loop over a range of k' (k-split for parallelism; the partials go
+// to the same merge as the correlation kernel's).  The taps of one (k', q') are p*p coalesced loads (neighbouring q' read
+// neighbouring addresses); every R element is touched p*p times in all, from L2 / Infinity Cache.
+__global__ void __launch_bounds__(256) window_corr_argmax_kernel(const float* __restrict__ R, const float* __restrict__ inv, int hw, int w,
+                                                                 int nW, int Np, int patch, int ksplit, int kper,
+                                                                 float* __restrict__ pval, int32_t* __restrict__ pidx)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x, ks = blockIdx.y, b = blockIdx.z;
+    if (q >= Np) return;
+    const float* Rb = R + (size_t)b * hw * hw + (size_t)(q / nW) * w + q % nW;      // column base of this window
+    const float* invb = inv + (size_t)b * Np;
+    const int k_lo = ks * kper, k_hi = min(Np, k_lo + kper);
+    float best = -INFINITY;
+    int bidx = k_lo;
+    int ky = k_lo / nW, kx = k_lo - ky * nW;
+    for (int k = k_lo; k < k_hi; ++k) {
+        const float* Rk = Rb + (size_t)(ky * w + kx) * hw;
+        float acc = 0.0f;
+        bool first = true;
+        for (int dy = 0; dy < patch; ++dy)
+            for (int dx = 0; dx < patch; ++dx) {
+                const int d = dy * w + dx;
+                const float v = Rk[(size_t)d * hw + d];
+                acc = first ? v : acc + v;
+                first = false;
+            }
+        const float sv = invb[k] * acc;
+        if (takes_over(sv, best)) { best = sv; bidx = k; }
+        if (++kx == nW) { kx = 0; ++ky; }
+    }
+    pval[((size_t)b * ksplit + ks) * Np + q] = best;
+    pidx[((size_t)b * ksplit + ks) * Np + q] = bidx;
+}
+
+__global__ void argmax_merge_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx, int B, int N, int ksplit,
+                                    int32_t* __restrict__ ind, float* __restrict__ vmax);
+
+// partial buffers of the window arg-max: [B][ksplit][N'] values + indices
+static void window_plan(int B, int Np, int* ksplit, int* kper)
+{
+    const int qblocks = cdiv(Np, 256) * B;
+    int ks = 1;
+    while (qblocks * ks < 1024 && ks < 64 && cdiv(Np, ks * 2) >= 32) ks *= 2;
+    *kper = cdiv(Np, ks);
+    *ksplit = cdiv(Np, *kper);
+}
+
+size_t window_corr_ws_bytes(int B, int Np)
+{
+    int ks, kper;
+    window_plan(B, Np, &ks, &kper);
+    return 2 * align_up((size_t)B * ks * Np * 4, 256) + 2 * align_up((size_t)B * Np * 4, 256) + 256;
+}
+
+int launch_window_corr_argmax(const float* R, const float* inv, int B, int h, int w, int patch, void* ws, size_t ws_bytes, hipStream_t st,
+                              CorrPartials* partials)
+{
+    const int nW = w - patch + 1, Np = (h - patch + 1) * nW;
+    int ks, kper;
+    window_plan(B, Np, &ks, &kper);
+    if (ws_bytes < window_corr_ws_bytes(B, Np)) return fail(IPSR_ERR_WORKSPACE, "window correlation: workspace %zu < %zu", ws_bytes, window_corr_ws_bytes(B, Np));
+    Carver cv(ws, ws_bytes);
+    float* pval = cv.take<float>((size_t)B * ks * Np);
+    int32_t* pidx = cv.take<int32_t>((size_t)B * ks * Np);
+    float* mval = cv.take<float>((size_t)B * Np);
+    int32_t* midx = cv.take<int32_t>((size_t)B * Np);
+    window_corr_argmax_kernel<<<dim3(cdiv(Np, 256), ks, B), 256, 0, st>>>(R, inv, h * w, w, nW, Np, patch, ks, kper, pval, pidx);
+    if (int rc = check_launch("window_corr_argmax_kernel")) return rc;
+    // fold the k-splits here, once: the stage kernel's consumers (one merge per 32x32 gather tile over K = C*p*p channels)
+    // would otherwise re-fold the same 16 partials thousands of times
+    argmax_merge_kernel<<<cdiv(B * Np, 256), 256, 0, st>>>(pval, pidx, B, Np, ks, midx, mval);
+    partials->pval = mval;
+    partials->pidx = midx;
+    partials->ksplit = 1;
+    return check_launch("argmax_merge_kernel");
+}
+
 // merge the k-split partials in ascending k order
 __global__ void __launch_bounds__(256) argmax_merge_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
                                                            int B, int N, int ksplit, int32_t* __restrict__ ind,

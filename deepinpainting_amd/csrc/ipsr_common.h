@@ -16,7 +16,7 @@ int check_launch(const char* what);
 
 // opt-in event bracketing of the dominant kernel (see ipsr_profile_enable in ipsr_hip.h)
 void profile_mark_start(hipStream_t st, int region = 0);
-void profile_mark_stop(hipStream_t st, int region = 0);
+void profile_mark_stop(hipStream_t st, int region = 0, double work = 0.0);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -134,6 +134,12 @@ int launch_unfold_normalize(const float* x, int B, int C, int h, int w, int patc
 int launch_unfold(const float* x, int B, int C, int h, int w, int patch, int ld, float* xu, hipStream_t st);
 // addend != NULL: out = addend + fold(yu)
 int launch_fold(const float* yu, int B, int C, int h, int w, int patch, float* out, hipStream_t st, const float* addend = nullptr);
+// shift_sz > 1 (shifted-sum form): per-position norms -> window inverse norms + the patch-major raw windows; the window
+// correlation + arg-max partials from the 1x1 correlation matrix R [B][hw][hw]
+int launch_window_prepare(const float* x, int B, int C, int h, int w, int patch, float* n1, float* inv, float* xT, int Cp, hipStream_t st);
+size_t window_corr_ws_bytes(int B, int Np);
+int launch_window_corr_argmax(const float* R, const float* inv, int B, int h, int w, int patch, void* ws, size_t ws_bytes, hipStream_t st,
+                              CorrPartials* partials);
 size_t corr_argmax_ws_bytes(int B, int C, int N);
 // ld: row stride of xn and ref (0 = N).  ld > N: operands zero-padded to whole 128-column tiles, patches k >= N are
 // excluded from the arg-max.

@@ -279,6 +279,93 @@ int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float
     return check_launch("patch_normalize_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// shift_sz > 1, the shifted-sum form (see window_corr_argmax in oracle/ipsr_oracle.c and corr_argmax.hip):
+//   chan_sumsq_kernel      n1[b][a] = squared channel norm of position a, in the canonical order of the p = 1 normalisation
+//   window_inv_kernel      inv[b][k'] = 1 / (sqrt(sum_{dy,dx} n1[(ky+dy)*w + kx+dx]) + 1e-8)
+//   unfold_patchmajor_kernel   xT[b][k'][(c*p+dy)*p+dx] = x[b][c][ky+dy][kx+dx]   (raw windows, patch-major: the recurrence /
+//                          gather / reconstruction operand).  The normalised unfolded matrix xn is no longer needed.
+__global__ void __launch_bounds__(NCOL * NSEG) chan_sumsq_kernel(const float* __restrict__ x, int C, int N, float* __restrict__ n1)
+{
+    __shared__ float part[NSEG][NCOL];
+    const int tid = threadIdx.x;
+    const int col = tid & (NCOL - 1), seg = tid / NCOL;
+    const int ntile = (N + NCOL - 1) / NCOL;
+    const int b = blockIdx.x / ntile, k = (blockIdx.x % ntile) * NCOL + col;
+    const float* xb = x + (size_t)b * C * N;
+    const int L = (C + NSEG - 1) / NSEG;
+    const int c_lo = seg * L, c_hi = min(C, c_lo + L);
+    float acc = 0.0f;
+    if (k < N)
+        for (int c = c_lo; c < c_hi; ++c) { const float v = xb[(size_t)c * N + k]; acc = __builtin_fmaf(v, v, acc); }
+    part[seg][col] = acc;
+    __syncthreads();
+    if (seg == 0 && k < N) {
+        float tot = part[0][col];
+#pragma unroll
+        for (int s2 = 1; s2 < NSEG; ++s2) tot = tot + part[s2][col];
+        n1[(size_t)b * N + k] = tot;
+    }
+}
+
+__global__ void __launch_bounds__(256) window_inv_kernel(const float* __restrict__ n1, int h, int w, int patch, int nW, int Np,
+                                                         float* __restrict__ inv)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (k >= Np) return;
+    const float* nb = n1 + (size_t)b * h * w + (size_t)(k / nW) * w + k % nW;
+    float tot = 0.0f;
+    bool first = true;
+    for (int dy = 0; dy < patch; ++dy)
+        for (int dx = 0; dx < patch; ++dx) { const float v = nb[dy * w + dx]; tot = first ? v : tot + v; first = false; }
+    inv[(size_t)b * Np + k] = 1.0f / (sqrtf(tot) + 1e-8f);
+}
+
+__global__ void __launch_bounds__(NCOL * NSEG) unfold_patchmajor_kernel(const float* __restrict__ x, int C, int h, int w, int patch, int nW,
+                                                                        int N, int Cp, float* __restrict__ xT)
+{
+    __shared__ float tile[32][NCOL + 1];
+    const int tid = threadIdx.x;
+    const int col = tid & (NCOL - 1), seg = tid / NCOL;
+    const int ntile = (N + NCOL - 1) / NCOL;
+    const int b = blockIdx.x / ntile, k0 = (blockIdx.x % ntile) * NCOL;
+    const int k = k0 + col;
+    const int pp = patch * patch, K = C * pp;
+    const float* xb = x + (size_t)b * C * h * w;
+    const int wi = k < N ? k / nW : 0, wj = k < N ? k - wi * nW : 0;
+    const float* win = xb + (size_t)wi * w + wj;
+    float* xTb = xT + (size_t)b * N * Cp;
+    for (int r0 = 0; r0 < Cp; r0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = seg + 8 * i, r = r0 + rl;
+            float v = 0.0f;
+            if (r < K && k < N) {
+                const int c = r / pp, d = r - c * pp, dy = d / patch, dx = d - dy * patch;
+                v = win[((size_t)c * h + dy) * w + dx];
+            }
+            tile[rl][col] = v;
+        }
+        __syncthreads();
+        const int rr = r0 + col;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kl = seg + 8 * i;
+            if (rr < Cp && k0 + kl < N) xTb[(size_t)(k0 + kl) * Cp + rr] = tile[col][kl];
+        }
+        __syncthreads();
+    }
+}
+
+int launch_window_prepare(const float* x, int B, int C, int h, int w, int patch, float* n1, float* inv, float* xT, int Cp, hipStream_t st)
+{
+    const int nW = w - patch + 1, Np = (h - patch + 1) * nW, N = h * w;
+    chan_sumsq_kernel<<<B * cdiv(N, NCOL), NCOL * NSEG, 0, st>>>(x, C, N, n1);
+    window_inv_kernel<<<dim3(cdiv(Np, 256), B), 256, 0, st>>>(n1, h, w, patch, nW, Np, inv);
+    unfold_patchmajor_kernel<<<B * cdiv(Np, NCOL), NCOL * NSEG, 0, st>>>(x, C, h, w, patch, nW, Np, Cp, xT);
+    return check_launch("unfold_patchmajor_kernel");
+}
+
 int launch_unfold_normalize(const float* x, int B, int C, int h, int w, int patch, int ldn, float* xn, float* xT, int Cp, float* inv,
                             hipStream_t st)
 {

@@ -543,7 +543,9 @@ int launch_winograd(const float* x, const float* w, float* y, int B, int C, int 
     wino_input_kernel<<<dim3(cdiv(p.Tp, 256), C), 256, 0, st>>>(x, B, C, H, W, p.TY, p.TX, p.Tp, V);
     if (int rc = check_launch("wino_input_kernel")) return rc;
     const int ktiles = p.Kp / WG_BM, ttiles = p.Tp / WG_BN;
+    profile_mark_start(st, 3);
     wino_gemm_kernel<<<36 * ktiles * ttiles * p.nsplit, WG_THREADS, 0, st>>>(U, V, C, p.Kp, p.Tp, ktiles, ttiles, p.nsplit, p.sps, Mo);
+    profile_mark_stop(st, 3, 72.0 * C * p.Kp * p.Tp);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     const dim3 og(cdiv(p.T, 256), K);
     if (epilogue == 2) wino_output_kernel<2><<<og, 256, 0, st>>>(Mo, p.nsplit, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
@@ -592,7 +594,9 @@ int launch_winograd_wrw(const float* et, const float* dt, float* dW, int B, int 
     if (int rc = check_launch("wino_wrw_window_kernel")) return rc;
     const int ktiles = p.Kp / WG_BM, ctiles = p.Cp / WG_BN;
     // M[xi][k][c] = sum_t Et[xi][t][k] * Vt[xi][t][c]: the same GEMM with the tiles as the reduction
+    profile_mark_start(st, 3);
     wino_gemm_kernel<<<36 * ktiles * ctiles * p.nsplit, WG_THREADS, 0, st>>>(Et, Vt, p.Tp, p.Kp, p.Cp, ktiles, ctiles, p.nsplit, p.sps, Mw);
+    profile_mark_stop(st, 3, 72.0 * p.Tp * p.Kp * p.Cp);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     wino_wrw_output_kernel<<<dim3(cdiv(C, 256), K), 256, 0, st>>>(Mw, p.nsplit, K, C, p.Kp, p.Cp, dW);
     return check_launch("wino_wrw_output_kernel");
@@ -862,7 +866,9 @@ int launch_winograd_dil(int mode, const float* a, const float* b2, float* out, i
         wino_window_kernel<3, 2, false><<<dim3(cdiv(p.Tp, 256), Cin), 256, 0, st>>>(a, B, Cin, H, W, -3, p.TY, p.TX, p.Tp, 0, Bv);
         if (int rc = check_launch("wino_window_kernel")) return rc;
         const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
+        profile_mark_start(st, 3);
         wino_gemm_kernel<<<36 * kt * tt * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, Cin, p.Kp, p.Tp, kt, tt, p.nsplit, p.sps, Mo);
+        profile_mark_stop(st, 3, 72.0 * Cin * p.Kp * p.Tp);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
         wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cout), 256, 0, st>>>(Mo, p.nsplit, B, Cout, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, Ho, Wo, 1, 0, out);
         return check_launch("wino3_output_kernel");
@@ -874,7 +880,9 @@ int launch_winograd_dil(int mode, const float* a, const float* b2, float* out, i
         wino_window_kernel<3, 1, false><<<dim3(cdiv(p.Tp, 256), Cout), 256, 0, st>>>(a, B, Cout, Ho, Wo, -1, p.TY, p.TX, p.Tp, 0, Bv);
         if (int rc = check_launch("wino_window_kernel")) return rc;
         const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
+        profile_mark_start(st, 3);
         wino_gemm_kernel<<<36 * kt * tt * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, Cout, p.Kp, p.Tp, kt, tt, p.nsplit, p.sps, Mo);
+        profile_mark_stop(st, 3, 72.0 * Cout * p.Kp * p.Tp);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
         wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cin), 256, 0, st>>>(Mo, p.nsplit, B, Cin, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, H, W, 2, 1, out);
         return check_launch("wino3_output_kernel");
@@ -884,7 +892,9 @@ int launch_winograd_dil(int mode, const float* a, const float* b2, float* out, i
     wino_window_kernel<3, 2, true><<<dim3(p.Tp / 16, p.Cp / 16), 256, 0, st>>>(a, B, Cin, H, W, -3, p.TY, p.TX, p.Tp, p.Cp, Bv);
     if (int rc = check_launch("wino_window_kernel")) return rc;
     const int kt = p.Kp / WG_BM, ct = p.Cp / WG_BN;
+    profile_mark_start(st, 3);
     wino_gemm_kernel<<<36 * kt * ct * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, p.Tp, p.Kp, p.Cp, kt, ct, p.nsplit, p.sps, Mo);
+    profile_mark_stop(st, 3, 72.0 * p.Tp * p.Kp * p.Cp);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     wino_wrw_output4_kernel<<<dim3(cdiv(Cin, 256), Cout), 256, 0, st>>>(Mo, p.nsplit, Cout, Cin, p.Kp, p.Cp, out);
     return check_launch("wino_wrw_output4_kernel");

@@ -270,14 +270,19 @@ int innercos_loss_backward(const float* x, int B, int Cx, int Cuse, int N, const
  *             ipsr_corr_argmax)
  *   region 1  every whole ipsr_forward call (all its kernels)
  *   region 2  every whole ipsr_backward / ipsr_backward_patch call
+ *   region 3  every launch of the Winograd GEMM kernel (see ipsr_profile_read_region_work)
  * so that a training step can report the layer's time ON ITS REAL INPUTS.  ipsr_profile_read_region synchronises the
  * recorded pairs of one region, writes their elapsed times (ms) to the HOST array `ms` and resets that ring; it returns
  * the number written.  ipsr_profile_read(ms, n) == ipsr_profile_read_region(0, ms, n).  ipsr_profile_enable(capacity)
  * sizes every ring for `capacity` regions; ipsr_profile_enable(0) disables and frees.  This is the only global state in
  * the library and it is off by default; enable/read are not re-entrant (call them from one thread, outside a timed step). */
-int ipsr_profile_enable(int capacity);
+int ipsr_profile_enable(int capacity);                              /* regions 0..2 */
+int ipsr_profile_enable_mask(int capacity, unsigned region_mask);   /* bit r = region r (region 3 is off unless asked for) */
 int ipsr_profile_read(float* ms /*[host]*/, int max_n);
 int ipsr_profile_read_region(int region, float* ms /*[host]*/, int max_n);
+/* region 3 = every launch of the Winograd GEMM kernel (csrc/winograd.hip, the convolutions' matrix-core kernel; its ring holds
+ * 64 x capacity launches); `work` receives the flop count (2 x 36 x rows x columns x reduction, padded sizes) of each launch. */
+int ipsr_profile_read_region_work(int region, float* ms /*[host]*/, double* work /*[host]*/, int max_n);
 
 #ifdef __cplusplus
 }

@@ -106,21 +106,28 @@ int ipsr_index_prep_cpu(const uint8_t* feat, int h, int w, int patch, int stride
 }
 
 /* ---- K3: NonparametricShift._extract_patches/_build (util/NonparametricShift.py:36-73) ----- */
+/* squared L2 norm over the channels of position k: 8 contiguous channel segments, one fmaf chain each, partials added in order */
+static float chan_sumsq(const float* xb, int C, int N, int k)
+{
+    const int L = (C + 7) / 8;
+    float tot = 0.0f;
+    for (int s = 0; s < 8; ++s) {
+        float part = 0.0f;
+        int c1 = (s + 1) * L < C ? (s + 1) * L : C;
+        for (int c = s * L; c < c1; ++c) part = fmaf(xb[(size_t)c * N + k], xb[(size_t)c * N + k], part);
+        tot = (s == 0) ? part : tot + part;
+    }
+    return tot;
+}
+
 HOT int ipsr_patch_normalize_cpu(const float* x, int B, int C, int N, float* xn, float* inv)
 {
     if (!x || !xn || !inv || B < 1 || C < 1 || N < 1) return IPSR_ERR_INVALID;
-    const int L = (C + 7) / 8;
     for (int b = 0; b < B; ++b) {
         const float* xb = x + (size_t)b * C * N;
         float* xnb = xn + (size_t)b * C * N;
         for (int k = 0; k < N; ++k) {
-            float tot = 0.0f;
-            for (int s = 0; s < 8; ++s) {
-                float part = 0.0f;
-                int c1 = (s + 1) * L < C ? (s + 1) * L : C;
-                for (int c = s * L; c < c1; ++c) part = fmaf(xb[(size_t)c * N + k], xb[(size_t)c * N + k], part);
-                tot = (s == 0) ? part : tot + part;
-            }
+            const float tot = chan_sumsq(xb, C, N, k);
             /* enc_patches[i]*(1/(enc_patches[i].norm(2)+1e-8))   NonparametricShift.py:40 */
             float iv = 1.0f / (sqrtf(tot) + 1e-8f);
             inv[(size_t)b * N + k] = iv;
@@ -251,34 +258,108 @@ int ipsr_fold_cpu(const float* yu, int B, int C, int h, int w, int patch, float*
     return IPSR_OK;
 }
 
+/* shift_sz > 1: the correlation of p x p windows (the reference's conv2d with p x p kernels, IPSRFunction.py:59) and the window
+ * norm (NonparametricShift.py:40), written as what they are — sums over the p*p taps of the 1x1 quantities:
+ *     nsq[k'] = sum_{dy,dx} n1[(ky+dy)*w + kx+dx],                 n1[a] = channel sum of squares at position a (as for p = 1)
+ *     inv[k'] = 1 / (sqrt(nsq[k']) + 1e-8)
+ *     S[k'][q'] = inv[k'] * sum_{dy,dx} R[(ky+dy)*w + kx+dx][(qy+dy)*w + qx+dx],     R[a][b] = <x[:,a], ref[:,b]> (one fmaf chain over c)
+ * (taps in ascending (dy, dx), plain adds from the first term; one multiply at the end).  Mathematically identical to
+ * normalising the unfolded patches and contracting over C*p*p; canonical order chosen so that the GPU computes R ONCE
+ * (2*N*N*C flop instead of 2*N'*N'*C*p*p: 8x fewer at p = 3) and sums shifted diagonals of it. */
+HOT static int window_corr_argmax(const float* x, const float* ref, int B, int C, int h, int w, int patch,
+                                  float* inv, int32_t* ind, float* vmax)
+{
+    const int N = h * w, nH = h - patch + 1, nW = w - patch + 1, Np = nH * nW;
+    float* n1 = (float*)malloc(sizeof(float) * N);
+    float* R = (float*)malloc(sizeof(float) * (size_t)N * N);
+    if (!n1 || !R) { free(n1); free(R); return IPSR_ERR_INVALID; }
+    for (int b = 0; b < B; ++b) {
+        const float* xb = x + (size_t)b * C * N;
+        const float* rb = ref + (size_t)b * C * N;
+        for (int a = 0; a < N; ++a) n1[a] = chan_sumsq(xb, C, N, a);
+        for (int k = 0; k < Np; ++k) {
+            const int base = (k / nW) * w + k % nW;
+            float tot = 0.0f;
+            int first = 1;
+            for (int dy = 0; dy < patch; ++dy)
+                for (int dx = 0; dx < patch; ++dx) { const float v = n1[base + dy * w + dx]; tot = first ? v : tot + v; first = 0; }
+            inv[(size_t)b * Np + k] = 1.0f / (sqrtf(tot) + 1e-8f);
+        }
+#pragma omp parallel for schedule(static)
+        for (int a = 0; a < N; ++a) {
+            float* Ra = R + (size_t)a * N;
+            for (int q = 0; q < N; ++q) Ra[q] = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float xa = xb[(size_t)c * N + a];
+                const float* r = rb + (size_t)c * N;
+                for (int q = 0; q < N; ++q) Ra[q] = fmaf(xa, r[q], Ra[q]);
+            }
+        }
+#pragma omp parallel for schedule(static)
+        for (int q = 0; q < Np; ++q) {
+            const int qb = (q / nW) * w + q % nW;
+            float best = 0.0f;
+            int bi = 0;
+            for (int k = 0; k < Np; ++k) {
+                const int kb = (k / nW) * w + k % nW;
+                float acc = 0.0f;
+                int first = 1;
+                for (int dy = 0; dy < patch; ++dy)
+                    for (int dx = 0; dx < patch; ++dx) {
+                        const float v = R[(size_t)(kb + dy * w + dx) * N + qb + dy * w + dx];
+                        acc = first ? v : acc + v;
+                        first = 0;
+                    }
+                const float sv = inv[(size_t)b * Np + k] * acc;
+                if (k == 0 || sv > best || (sv != sv && best == best)) { best = sv; bi = k; }      /* torch.max semantics */
+            }
+            ind[(size_t)b * Np + q] = bi;
+            vmax[(size_t)b * Np + q] = best;
+        }
+    }
+    free(n1); free(R);
+    return IPSR_OK;
+}
+
+/* the layer behind the correlation: recurrence, kbar, reconstruction and the sparse trunc(kbar), on patches x [B,C,N] with their
+ * inverse norms `inv`, arg-max `ind` and maximum `vmax` already known */
+static int attention_core(const float* x, const float* inv, const int32_t* ind, const float* vmax, const int32_t* mask_point_idx, int M,
+                          int B, int C, int N, float* out, float* attn_rows, int32_t* bwd_index);
+
 HOT int ipsr_forward_cpu(const float* x, const float* ref, const int32_t* mask_point_idx, int M,
                          int B, int C, int h, int w, int patch, int stride,
                          float* out, int32_t* ind, float* vmax, float* attn_rows, int32_t* bwd_index)
 {
     if (!x || !ref || !out || !ind || !vmax || B < 1 || C < 1 || h < 1 || w < 1 || M < 0) return IPSR_ERR_INVALID;
     if (stride != 1 || patch < 1) return IPSR_ERR_UNSUPPORTED;
+    if (M > 0 && (!mask_point_idx || !attn_rows)) return IPSR_ERR_INVALID;
     if (patch > 1) {                                  /* outputs ind/vmax/attn_rows/bwd_index live on the N' window grid */
         if (h < patch || w < patch) return IPSR_ERR_INVALID;
         const int nH = h - patch + 1, nW = w - patch + 1, K = C * patch * patch;
         const size_t un = (size_t)B * K * nH * nW;
         float* xu = (float*)malloc(sizeof(float) * un);
-        float* ru = (float*)malloc(sizeof(float) * un);
         float* ou = (float*)malloc(sizeof(float) * un);
+        float* inv = (float*)malloc(sizeof(float) * (size_t)B * nH * nW);
         int rc = ipsr_unfold_cpu(x, B, C, h, w, patch, xu);
-        if (rc == IPSR_OK) rc = ipsr_unfold_cpu(ref, B, C, h, w, patch, ru);
-        if (rc == IPSR_OK) rc = ipsr_forward_cpu(xu, ru, mask_point_idx, M, B, K, nH, nW, 1, 1, ou, ind, vmax, attn_rows, bwd_index);
+        if (rc == IPSR_OK) rc = window_corr_argmax(x, ref, B, C, h, w, patch, inv, ind, vmax);
+        if (rc == IPSR_OK) rc = attention_core(xu, inv, ind, vmax, mask_point_idx, M, B, K, nH * nW, ou, attn_rows, bwd_index);
         if (rc == IPSR_OK) rc = ipsr_fold_cpu(ou, B, C, h, w, patch, out);
-        free(xu); free(ru); free(ou);
+        free(xu); free(ou); free(inv);
         return rc;
     }
-    if (M > 0 && (!mask_point_idx || !attn_rows)) return IPSR_ERR_INVALID;
     const int N = h * w;
     float* xn = (float*)malloc(sizeof(float) * (size_t)B * C * N);
     float* inv = (float*)malloc(sizeof(float) * (size_t)B * N);
     int rc = ipsr_patch_normalize_cpu(x, B, C, N, xn, inv);
     if (rc == IPSR_OK) rc = ipsr_corr_argmax_cpu(xn, ref, B, C, N, ind, vmax, NULL);
-    if (rc != IPSR_OK) { free(xn); free(inv); return rc; }
+    if (rc == IPSR_OK) rc = attention_core(x, inv, ind, vmax, mask_point_idx, M, B, C, N, out, attn_rows, bwd_index);
+    free(xn); free(inv);
+    return rc;
+}
 
+HOT static int attention_core(const float* x, const float* inv, const int32_t* ind, const float* vmax, const int32_t* mask_point_idx, int M,
+                              int B, int C, int N, float* out, float* attn_rows, int32_t* bwd_index)
+{
     int8_t* is_mask = (int8_t*)calloc(N, 1);
     for (int l = 0; l < M; ++l) is_mask[mask_point_idx[l]] = 1;
     float* o = (float*)malloc(sizeof(float) * C);
@@ -287,7 +368,7 @@ HOT int ipsr_forward_cpu(const float* x, const float* ref, const int32_t* mask_p
 
     for (int b = 0; b < B; ++b) {
         const float* xb = x + (size_t)b * C * N;
-        const float* xnb = xn + (size_t)b * C * N;
+        const float* invb = inv + (size_t)b * N;
         const int32_t* indb = ind + (size_t)b * N;
         const float* vb = vmax + (size_t)b * N;
         float* outb = out + (size_t)b * C * N;
@@ -304,7 +385,7 @@ HOT int ipsr_forward_cpu(const float* x, const float* ref, const int32_t* mask_p
                 for (int k = 0; k < N; ++k) a[k] = 0.0f;
                 a[kq] = 1.0f;
             } else {
-                for (int c = 0; c < C; ++c) u[c] = xnb[(size_t)c * N + q];        /* value_2 :109 */
+                for (int c = 0; c < C; ++c) u[c] = xb[(size_t)c * N + q] * invb[q];  /* value_2 :109 (= the normalised patch) */
                 const float at = lane_dot(u, o, C);                               /* :116 */
                 const float v = vb[q];                                            /* vamx_mask :70 */
                 const float s = at + v;
@@ -356,7 +437,7 @@ HOT int ipsr_forward_cpu(const float* x, const float* ref, const int32_t* mask_p
             free(fillA); free(fillB);
         }
     }
-    free(is_mask); free(o); free(u); free(kk); free(xn); free(inv);
+    free(is_mask); free(o); free(u); free(kk);
     return IPSR_OK;
 }
 

@@ -48,8 +48,8 @@ def test_host_side_queries_and_argument_errors(built):
     L = built.lib()
     assert L.ipsr_bwd_index_ints(1024, 256) == 2 * 1025 + 1024 + 2 * (256 * 257 // 2)
     assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 1, 1) > 8 * 512 * 1024 * 4 * 2
-    # shift_sz = 3: two [K=4608, ld=1024] correlation operands, the patch-major copy and the un-folded result [K, N'=900]
-    assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 3, 1) > 8 * 4608 * (2 * 1024 + 2 * 900) * 4
+    # shift_sz = 3: the patch-major windows xT [8,900,4608], the un-folded result [8,4608,900] and the 1x1 correlation R [8,1024,1024]
+    assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 3, 1) > (2 * 8 * 4608 * 900 + 8 * 1024 * 1024) * 4
     assert L.ipsr_forward_workspace_bytes(8, 512, 32, 32, 256, 3, 2) == 0          # stride != 1: unsupported
     assert L.ipsr_backward_workspace_bytes(8, 512, 32, 32, 1) == 0
     assert L.ipsr_backward_workspace_bytes(8, 512, 32, 32, 3) >= 2 * 8 * 4608 * 900 * 4
