@@ -127,9 +127,6 @@ int launch_index_prep(const uint8_t* feat, int h, int w, int patch, int stride, 
 // ldx / ldn: row strides of x / xn (0 = N); with ldn > N the pad columns of xn are zero-filled.
 int launch_patch_normalize(const float* x, int B, int C, int N, float* xn, float* xT, int Cp, float* inv,
                            hipStream_t st, int ldx = 0, int ldn = 0);
-// shift_sz > 1: patches read straight from the [C,h,w] feature (normalize.hip); same outputs as launch_patch_normalize on the unfolded x
-int launch_unfold_normalize(const float* x, int B, int C, int h, int w, int patch, int ldn, float* xn, float* xT, int Cp, float* inv,
-                            hipStream_t st);
 // shift_sz > 1 (unfold.hip): p x p windows, stride 1, rows k = (c*p+dy)*p+dx; xu row stride ld >= N' (pad columns zeroed)
 int launch_unfold(const float* x, int B, int C, int h, int w, int patch, int ld, float* xu, hipStream_t st);
 // addend != NULL: out = addend + fold(yu)

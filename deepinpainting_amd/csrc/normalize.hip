@@ -100,83 +100,6 @@ __global__ void __launch_bounds__(NCOL * NSEG) patch_normalize_kernel(const floa
 }
 
 // ---------------------------------------------------------------------------------------------------
-// shift_sz > 1: the same kernel reading the patches straight out of the [C,h,w] feature (row k = (c*p+dy)*p+dx of the
-// unfolded matrix, column = window (i,j): x[c][i+dy][j+dx]) — the unfolded x is never written to memory.  The feature
-// of one sample (8 MB at 512x64x64) stays in L2 across the three passes; xn (row stride ldn, pad columns zeroed) and the
-// patch-major copy xT are the only HBM traffic.  Canonical order of the norm: as above with C -> K = C*p*p.
-__global__ void __launch_bounds__(NCOL * NSEG) unfold_normalize_kernel(const float* __restrict__ x, int C, int h, int w, int patch, int nW,
-                                                                       int N, int Cp, int ldn,
-                                                                       float* __restrict__ xn, float* __restrict__ xT,
-                                                                       float* __restrict__ inv)
-{
-    __shared__ float part[NSEG][NCOL];
-    __shared__ float inv_s[NCOL];
-    __shared__ float tile[32][NCOL + 1];
-
-    const int tid = threadIdx.x;
-    const int col = tid & (NCOL - 1), seg = tid / NCOL;
-    const int ntile = (ldn + NCOL - 1) / NCOL;
-    const int b = blockIdx.x / ntile, k0 = (blockIdx.x % ntile) * NCOL;
-    const int k = k0 + col;                                  // window index of this thread's column
-    const int pp = patch * patch, K = C * pp;
-    const float* xb = x + (size_t)b * C * h * w;
-    const int wi = k < N ? k / nW : 0, wj = k < N ? k - wi * nW : 0;
-    const float* win = xb + (size_t)wi * w + wj;              // top-left pixel of the window, channel 0
-
-    // phase 1: one fmaf chain per (segment, column) over the rows of the segment
-    const int L = (K + NSEG - 1) / NSEG;
-    const int r_lo = seg * L, r_hi = min(K, r_lo + L);
-    float acc = 0.0f;
-    if (k < N && r_lo < r_hi) {
-        int c = r_lo / pp, d = r_lo - c * pp, dy = d / patch, dx = d - dy * patch;
-        for (int r = r_lo; r < r_hi; ++r) {
-            const float v = win[((size_t)c * h + dy) * w + dx];
-            acc = __builtin_fmaf(v, v, acc);
-            if (++dx == patch) { dx = 0; if (++dy == patch) { dy = 0; ++c; } }
-        }
-    }
-    part[seg][col] = acc;
-    __syncthreads();
-    if (seg == 0) {
-        float tot = part[0][col];
-#pragma unroll
-        for (int s = 1; s < NSEG; ++s) tot = tot + part[s][col];
-        const float iv = 1.0f / (sqrtf(tot) + 1e-8f);
-        inv_s[col] = iv;
-        if (k < N) inv[(size_t)b * N + k] = iv;
-    }
-    __syncthreads();
-
-    // phase 2: scale (row-major xn) and transpose (patch-major xT), 32 rows at a time
-    const float iv = inv_s[col];
-    float* xnb = xn + (size_t)b * K * ldn;
-    float* xTb = xT + (size_t)b * N * Cp;
-    for (int r0 = 0; r0 < Cp; r0 += 32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rl = seg + 8 * i, r = r0 + rl;
-            float v = 0.0f;
-            if (r < K && k < N) {
-                const int c = r / pp, d = r - c * pp, dy = d / patch, dx = d - dy * patch;
-                v = win[((size_t)c * h + dy) * w + dx];
-                xnb[(size_t)r * ldn + k] = v * iv;
-            } else if (r < K && k < ldn) {
-                xnb[(size_t)r * ldn + k] = 0.0f;
-            }
-            tile[rl][col] = v;
-        }
-        __syncthreads();
-        const int rr = r0 + col;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kl = seg + 8 * i;
-            if (rr < Cp && k0 + kl < N) xTb[(size_t)(k0 + kl) * Cp + rr] = tile[col][kl];
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Register-resident variant for C <= 512 (segment length L <= 64): a thread keeps its (segment, column) slice
 // of x in registers between the norm and the scaling, so x is read from HBM exactly once and nothing goes
 // through LDS on the way to xn.  The patch-major copy xT is transposed through an LDS tile so that it leaves the
@@ -366,12 +289,5 @@ int launch_window_prepare(const float* x, int B, int C, int h, int w, int patch,
     return check_launch("unfold_patchmajor_kernel");
 }
 
-int launch_unfold_normalize(const float* x, int B, int C, int h, int w, int patch, int ldn, float* xn, float* xT, int Cp, float* inv,
-                            hipStream_t st)
-{
-    const int nW = w - patch + 1, N = (h - patch + 1) * nW;
-    unfold_normalize_kernel<<<B * cdiv(ldn, NCOL), NCOL * NSEG, 0, st>>>(x, C, h, w, patch, nW, N, Cp, ldn, xn, xT, inv);
-    return check_launch("unfold_normalize_kernel");
-}
 
 }  // namespace ipsr

@@ -23,6 +23,7 @@ cap = {}
 def spy_f(*a, **k):
     f = orig_f(*a, **k)
     cap["x"], cap["ref"], cap["mpi"], cap["f"] = a[0].clone(), a[1].clone(), a[2].clone(), f
+    cap["args"], cap["kw"] = a[3:], k
     return f
 def spy_b(g, bidx, tw, M, patch=1):
     cap["g"], cap["tw"], cap["M"] = g.clone(), tw, M
@@ -53,20 +54,33 @@ hist = torch.bincount(torch.clamp(tot.reshape(-1), max=300) // 10, minlength=31)
 print("combined column length histogram (bins of 10, all samples):", hist.tolist())
 
 def timed(fn, n=30):
+    """Kernel time through the C-ABI's own HIP-event hook (regions 1 = ipsr_forward, 2 = ipsr_backward): wall time around a
+    single call would mostly measure the host (allocation of the outputs, launch latency) at these durations."""
+    from deepinpainting_amd import _lib
+    import ctypes
+    lib = _lib.lib()
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    ts = []
+    lib.ipsr_profile_enable(n)
     for _ in range(n):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
-    return statistics.median(ts)
+        fn()
+    torch.cuda.synchronize()
+    out = []
+    buf = (ctypes.c_float * 4096)()
+    for region in (1, 2):
+        k = lib.ipsr_profile_read_region(region, ctypes.cast(buf, ctypes.c_void_p), n)
+        if k > 0:
+            out.append(statistics.median(list(buf[:k])))
+    lib.ipsr_profile_enable(0)
+    return out[0] if out else float("nan")
 
-f = ops.forward(x, rf, mpi)
-print("stand-alone on these tensors: forward %.4f ms, backward %.4f ms" % (timed(lambda: ops.forward(x, rf, mpi)), timed(lambda: ops.backward(g, f.bwd_index, cap["tw"], M))))
+fw = lambda xx, rr: ops.forward(xx, rr, mpi, *cap["args"], **cap["kw"])      # same index / counts / options as the step's own call
+f = fw(x, rf)
+print("stand-alone on these tensors: forward %.4f ms, backward %.4f ms" % (timed(lambda: fw(x, rf)), timed(lambda: ops.backward(g, f.bwd_index, cap["tw"], M))))
 gs = torch.randn_like(x).abs()
-fs = ops.forward(gs, torch.relu(torch.randn_like(x)), mpi)
-print("synthetic non-negative features: forward %.4f ms, backward %.4f ms" % (timed(lambda: ops.forward(gs, rf.abs(), mpi)), timed(lambda: ops.backward(g, fs.bwd_index, 1.0, M))))
+fs = fw(gs, torch.relu(torch.randn_like(x)))
+print("synthetic non-negative features: forward %.4f ms, backward %.4f ms" % (timed(lambda: fw(gs, rf.abs())), timed(lambda: ops.backward(g, fs.bwd_index, 1.0, M))))
 if len(sys.argv) > 2:
     torch.save({"x": x.cpu(), "ref": rf.cpu(), "mpi": mpi.cpu(), "g": g.cpu()}, sys.argv[2])
+
