@@ -327,6 +327,10 @@ def main():
     gms, gwork = (ctypes.c_float * ncap)(), (ctypes.c_double * ncap)()
     ng = lib.ipsr_profile_read_region_work(3, ctypes.cast(gms, ctypes.c_void_p), ctypes.cast(gwork, ctypes.c_void_p), ncap)
     gemm_ms, gemm_flops = sum(gms[i] for i in range(ng)), sum(gwork[i] for i in range(ng))
+    if os.environ.get("IPSR_BENCH_GEMM_DUMP"):          # one line per launch: ms, flops, TFLOP/s (for tuning the tile/split choice)
+        with open(os.environ["IPSR_BENCH_GEMM_DUMP"], "w") as fh:
+            for i in range(ng):
+                fh.write("%d %.4f %.0f %.1f\n" % (i, gms[i], gwork[i], gwork[i] / max(gms[i], 1e-6) / 1e9))
     lib.ipsr_profile_enable(0)
 
     # the reference's exact sequence (strict_reference), same model and inputs, timed the same way after the headline loop

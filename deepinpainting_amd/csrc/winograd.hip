@@ -808,15 +808,20 @@ __global__ void __launch_bounds__(256) wino_wrw_output4_kernel(const float* __re
     for (int i = 0; i < 4; ++i) dst[i] = make_float4(o[i][0], o[i][1], o[i][2], o[i][3]);
 }
 
-struct DilPlan { int TY, TX, T, Tp, Kp, Cp, nsplit, sps; size_t a_floats, b_floats, m_floats, total_bytes; };
+struct DilPlan { int Ho, Wo, Gy, Gx, TY, TX, T, Tp, Kp, Cp, nsplit, sps; size_t a_floats, b_floats, m_floats, total_bytes; };
 
-// mode 0: forward (grid = output Ho x Wo, reduce C=Cin, produce K=Cout); 1: backward-data (grid = H/2 x W/2 odd positions of dx,
-// reduce Cout, produce Cin); 2: weight gradient (tiles of dy, reduction over tiles)
-static int dil_plan(int mode, int B, int Cin, int H, int W, int Cout, DilPlan* p)
+// mode 0: forward (grid = output Ho x Wo, reduce C=Cin, produce K=Cout); 1: backward-data (geom 0: grid = H/2 x W/2 odd positions
+// of dx; geom 1: grid = H x W; reduce Cout, produce Cin); 2: weight gradient (tiles of dy, reduction over tiles).
+// geom 0: Conv2d(k4 s2 p3 d2), output H/2 x W/2.   geom 1: Conv2d(k4 s1 p1) — netD's fourth convolution, models/networks.py:483-489
+// — output (H-1) x (W-1): the same 4-tap stride-1 correlation, on the image itself (X[i] = x[i - 1]).
+static int dil_plan(int geom, int mode, int B, int Cin, int H, int W, int Cout, DilPlan* p)
 {
-    if ((H | W) & 1) return fail(IPSR_ERR_UNSUPPORTED, "dilated winograd: odd extent %dx%d", H, W);
-    const int Ho = H / 2, Wo = W / 2;
-    p->TY = (Ho + 2) / 3; p->TX = (Wo + 2) / 3;
+    if (geom != 0 && geom != 1) return fail(IPSR_ERR_INVALID, "4x4 winograd: geometry %d", geom);
+    if (geom == 0 && ((H | W) & 1)) return fail(IPSR_ERR_UNSUPPORTED, "dilated winograd: odd extent %dx%d", H, W);
+    if (geom == 1 && (H < 4 || W < 4)) return fail(IPSR_ERR_UNSUPPORTED, "4x4 winograd: extent %dx%d below the kernel", H, W);
+    p->Ho = geom == 0 ? H / 2 : H - 1; p->Wo = geom == 0 ? W / 2 : W - 1;
+    p->Gy = (geom == 1 && mode == 1) ? H : p->Ho; p->Gx = (geom == 1 && mode == 1) ? W : p->Wo;
+    p->TY = (p->Gy + 2) / 3; p->TX = (p->Gx + 2) / 3;
     p->T = B * p->TY * p->TX;
     p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;
     if (mode == 2) {
@@ -829,7 +834,7 @@ static int dil_plan(int mode, int B, int Cin, int H, int W, int Cout, DilPlan* p
         p->m_floats = m1 * p->nsplit;
     } else {
         const int red = mode == 0 ? Cin : Cout, prod = mode == 0 ? Cout : Cin;
-        if (red % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "dilated winograd: %d reduction channels are not a multiple of %d", red, WG_BK);
+        if (red % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "4x4 winograd: %d reduction channels are not a multiple of %d", red, WG_BK);
         p->Kp = (prod + WG_BM - 1) / WG_BM * WG_BM;
         p->Cp = red;
         p->a_floats = (size_t)36 * red * p->Kp;
@@ -842,28 +847,36 @@ static int dil_plan(int mode, int B, int Cin, int H, int W, int Cout, DilPlan* p
     return IPSR_OK;
 }
 
-size_t winograd_dil_ws_bytes(int mode, int B, int Cin, int H, int W, int Cout)
+size_t winograd_dil_ws_bytes(int geom, int mode, int B, int Cin, int H, int W, int Cout)
 {
     DilPlan p;
-    if (dil_plan(mode, B, Cin, H, W, Cout, &p) != IPSR_OK) return 0;
+    if (dil_plan(geom, mode, B, Cin, H, W, Cout, &p) != IPSR_OK) return 0;
     return p.total_bytes;
 }
 
-// x [B,Cin,H,W], w [Cout,Cin,4,4], y / dy [B,Cout,H/2,W/2]
-int launch_winograd_dil(int mode, const float* a, const float* b2, float* out, int B, int Cin, int H, int W, int Cout,
+template <bool TMAJOR>
+static void launch_window3(int is, dim3 grid, hipStream_t st, const float* x, int B, int C, int H, int W, int off, const DilPlan& p, int Cp, float* V)
+{
+    if (is == 2) wino_window_kernel<3, 2, TMAJOR><<<grid, 256, 0, st>>>(x, B, C, H, W, off, p.TY, p.TX, p.Tp, Cp, V);
+    else wino_window_kernel<3, 1, TMAJOR><<<grid, 256, 0, st>>>(x, B, C, H, W, off, p.TY, p.TX, p.Tp, Cp, V);
+}
+
+// x [B,Cin,H,W], w [Cout,Cin,4,4], y / dy [B,Cout,Ho,Wo]
+int launch_winograd_dil(int geom, int mode, const float* a, const float* b2, float* out, int B, int Cin, int H, int W, int Cout,
                         void* ws, size_t ws_bytes, hipStream_t st)
 {
     DilPlan p;
-    if (int rc = dil_plan(mode, B, Cin, H, W, Cout, &p)) return rc;
-    if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "dilated winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
-    const int Ho = H / 2, Wo = W / 2;
+    if (int rc = dil_plan(geom, mode, B, Cin, H, W, Cout, &p)) return rc;
+    if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "4x4 winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    const int Ho = p.Ho, Wo = p.Wo;
+    const int xis = geom == 0 ? 2 : 1, xoff = geom == 0 ? -3 : -1;        // X[i] = x[xis * i + xoff]
     Carver cv(ws, ws_bytes);
     float* A = cv.take<float>(p.a_floats);
     float* Bv = cv.take<float>(p.b_floats);
     float* Mo = cv.take<float>(p.m_floats);
     if (mode == 0) {            // a = x, b2 = w, out = y
         wino4_filter_kernel<<<dim3(cdiv(p.Kp, 256), Cin), 256, 0, st>>>(b2, Cin, Cout, p.Kp, 16, (long)Cin * 16, 0, A);
-        wino_window_kernel<3, 2, false><<<dim3(cdiv(p.Tp, 256), Cin), 256, 0, st>>>(a, B, Cin, H, W, -3, p.TY, p.TX, p.Tp, 0, Bv);
+        launch_window3<false>(xis, dim3(cdiv(p.Tp, 256), Cin), st, a, B, Cin, H, W, xoff, p, 0, Bv);
         if (int rc = check_launch("wino_window_kernel")) return rc;
         const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
         profile_mark_start(st, 3);
@@ -873,23 +886,27 @@ int launch_winograd_dil(int mode, const float* a, const float* b2, float* out, i
         wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cout), 256, 0, st>>>(Mo, p.nsplit, B, Cout, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, Ho, Wo, 1, 0, out);
         return check_launch("wino3_output_kernel");
     }
-    if (mode == 1) {            // a = dy, b2 = w, out = dx: only the odd rows / columns receive gradient
-        if (hipMemsetAsync(out, 0, (size_t)B * Cin * H * W * sizeof(float), st) != hipSuccess) return fail(IPSR_ERR_LAUNCH, "dilated winograd: hipMemsetAsync failed");
+    if (mode == 1) {            // a = dy, b2 = w, out = dx
+        // geom 0: only the odd rows / columns receive gradient, dx[2q+1] = sum_r' w[3-r'] dy[q - 1 + r']
+        // geom 1: dx[i] = sum_r' w[3-r'] dy[i - 2 + r'] at every position
+        if (geom == 0 && hipMemsetAsync(out, 0, (size_t)B * Cin * H * W * sizeof(float), st) != hipSuccess)
+            return fail(IPSR_ERR_LAUNCH, "dilated winograd: hipMemsetAsync failed");
         // reduction over Cout: element (c = co, k = ci) of w[co][ci][r][s] at co*Cin*16 + ci*16, taps flipped
         wino4_filter_kernel<<<dim3(cdiv(p.Kp, 256), Cout), 256, 0, st>>>(b2, Cout, Cin, p.Kp, (long)Cin * 16, 16, 1, A);
-        wino_window_kernel<3, 1, false><<<dim3(cdiv(p.Tp, 256), Cout), 256, 0, st>>>(a, B, Cout, Ho, Wo, -1, p.TY, p.TX, p.Tp, 0, Bv);
+        launch_window3<false>(1, dim3(cdiv(p.Tp, 256), Cout), st, a, B, Cout, Ho, Wo, geom == 0 ? -1 : -2, p, 0, Bv);
         if (int rc = check_launch("wino_window_kernel")) return rc;
         const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
         profile_mark_start(st, 3);
         wino_gemm_kernel<<<36 * kt * tt * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, Cout, p.Kp, p.Tp, kt, tt, p.nsplit, p.sps, Mo);
         profile_mark_stop(st, 3, 72.0 * Cout * p.Kp * p.Tp);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
-        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cin), 256, 0, st>>>(Mo, p.nsplit, B, Cin, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, H, W, 2, 1, out);
+        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cin), 256, 0, st>>>(Mo, p.nsplit, B, Cin, p.Kp, p.Gy, p.Gx, p.TY, p.TX, p.Tp, H, W,
+                                                                         geom == 0 ? 2 : 1, geom == 0 ? 1 : 0, out);
         return check_launch("wino3_output_kernel");
     }
     // mode 2: a = x, b2 = dy, out = dW [Cout][Cin][4][4]
     wino_wrw_tile3_kernel<<<dim3(p.Tp / 16, p.Kp / 16), 256, 0, st>>>(b2, B, Cout, Ho, Wo, p.TY, p.TX, p.Tp, p.Kp, A);
-    wino_window_kernel<3, 2, true><<<dim3(p.Tp / 16, p.Cp / 16), 256, 0, st>>>(a, B, Cin, H, W, -3, p.TY, p.TX, p.Tp, p.Cp, Bv);
+    launch_window3<true>(xis, dim3(p.Tp / 16, p.Cp / 16), st, a, B, Cin, H, W, xoff, p, p.Cp, Bv);
     if (int rc = check_launch("wino_window_kernel")) return rc;
     const int kt = p.Kp / WG_BM, ct = p.Cp / WG_BN;
     profile_mark_start(st, 3);
@@ -958,20 +975,32 @@ int ipsr_conv3x3_winograd_ex(int op, const float* in, const float* weight, const
     }
 }
 
+size_t ipsr_conv4x4_winograd_workspace_bytes(int geom, int mode, int B, int Cin, int H, int W, int Cout)
+{
+    if (geom < 0 || geom > 1 || mode < 0 || mode > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return 0;
+    return winograd_dil_ws_bytes(geom, mode, B, Cin, H, W, Cout);
+}
+
+int ipsr_conv4x4_winograd(int geom, int mode, const float* a, const float* b, float* out, int B, int Cin, int H, int W, int Cout,
+                          void* ws, size_t ws_bytes, void* stream)
+{
+    if (!a || !b || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_winograd: null pointer");
+    if (geom < 0 || geom > 1 || mode < 0 || mode > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2)
+        return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_winograd: bad argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_winograd: out / workspace must be 16-byte aligned");
+    return launch_winograd_dil(geom, mode, a, b, out, B, Cin, H, W, Cout, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
 size_t ipsr_conv4x4_dilated_winograd_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout)
 {
-    if (mode < 0 || mode > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return 0;
-    return winograd_dil_ws_bytes(mode, B, Cin, H, W, Cout);
+    return ipsr_conv4x4_winograd_workspace_bytes(0, mode, B, Cin, H, W, Cout);
 }
 
 int ipsr_conv4x4_dilated_winograd(int mode, const float* a, const float* b, float* out, int B, int Cin, int H, int W, int Cout,
                                   void* ws, size_t ws_bytes, void* stream)
 {
-    if (!a || !b || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_dilated_winograd: null pointer");
-    if (mode < 0 || mode > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_dilated_winograd: bad argument");
-    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
-        return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_dilated_winograd: out / workspace must be 16-byte aligned");
-    return launch_winograd_dil(mode, a, b, out, B, Cin, H, W, Cout, ws, ws_bytes, static_cast<hipStream_t>(stream));
+    return ipsr_conv4x4_winograd(0, mode, a, b, out, B, Cin, H, W, Cout, ws, ws_bytes, stream);
 }
 
 size_t ipsr_conv3x3_winograd_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout)

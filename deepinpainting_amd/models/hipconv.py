@@ -7,8 +7,8 @@ Three engines per (operation, geometry), chosen by `select()` from measurements 
 
   "winograd"  csrc/winograd.hip   k3 s1 p1 forward / backward-data of Conv2d and ConvTranspose2d, F(4x4,3x3) on fp32 MFMA:
                                   2.0-2.4x MIOpen's F(2x2,3x3) assembly from 16x16 maps and 128 channels up
-  "wino_dil"  csrc/winograd.hip   netG's dilated down convolution Conv2d(k4 s2 p3 d2) by F(3x3,4x4) — forward, input and weight
-                                  gradient, 1.4-2.0x MIOpen at 128..512 channels on 32x32..128x128 inputs
+  "wino_dil"  csrc/winograd.hip   netG's dilated down convolution Conv2d(k4 s2 p3 d2) and netD's Conv2d(k4 s1 p1) by F(3x3,4x4) —
+                                  forward, input and weight gradient, 1.4-2.0x MIOpen at 128..512 channels on 32x32..128x128 inputs
   "direct"    csrc/conv_gemm.hip  one-launch implicit GEMM, NCHW in/out (every k3/k4, stride 1/2, dilated and transposed
                                   geometry of the nets, forward and backward-data): at parity with MIOpen (~100 TF), used
                                   where it measured >= 7 % faster
@@ -50,6 +50,9 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil):
     if mode == "auto" and _is_dilated4(k, stride, pad, dil) and op in (ops.CONV_FWD, ops.CONV_BWD_DATA) \
             and cred % 16 == 0 and min(Cin, Cout) >= 128 and 32 <= H <= 128 and H % 2 == 0 and W % 2 == 0:
         return "wino_dil"        # netG's dilated down convolution: F(3x3,4x4), 1.4-2.0x MIOpen (profiles/r02_hipconv_k3_v3.txt)
+    if mode == "auto" and _is_k4s1(k, stride, pad, dil) and op in (ops.CONV_FWD, ops.CONV_BWD_DATA) \
+            and cred % 16 == 0 and min(Cin, Cout) >= 128 and 16 <= H <= 128:
+        return "wino_dil"        # netD's 4x4 stride-1 convolution: the same F(3x3,4x4) pipeline on the image itself
     # auto: measured rules (MI355X, batch 8; profiles/r02_hipconv_k3.txt, r02_hipconv_all.txt)
     if wino_ok and H * W >= 256 and max(cred, kout) >= 128 and min(cred, kout) >= 64:
         return "winograd"
@@ -62,12 +65,18 @@ def _is_dilated4(k, stride, pad, dil):
     return k == 4 and stride == 2 and pad == 3 and dil == 2
 
 
+def _is_k4s1(k, stride, pad, dil):
+    return k == 4 and stride == 1 and pad == 1 and dil == 1
+
+
 def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
     """-> "winograd" | "miopen" for the weight gradient of one layer (profiles/r02_hipconv_k3_wrw.txt: F(3x3,4x4) is 2.0-2.4x
     MIOpen from 256 channels up on maps of 16x16..64x64; on larger maps its tile-major transforms lose to MIOpen)."""
     mode = _mode()
     if mode == "auto" and not transposed and _is_dilated4(k, stride, pad, dil) and min(Cin, Cout) >= 128 and 32 <= H <= 128 \
             and H % 2 == 0 and W % 2 == 0:
+        return "wino_dil"
+    if mode == "auto" and not transposed and _is_k4s1(k, stride, pad, dil) and min(Cin, Cout) >= 128 and 16 <= H <= 128:
         return "wino_dil"
     ok = k == 3 and stride == 1 and pad == 1 and dil == 1
     if mode in ("miopen", "direct") or not ok:
@@ -93,7 +102,7 @@ class _HipConv(torch.autograd.Function):
         elif eng_fwd == "direct":
             y = ops.conv2d(op, xc, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng_fwd == "wino_dil":
-            y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout)
+            y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
         else:
             y = (F.conv_transpose2d(xc, w, None, stride, pad, 0, 1, dil) if transposed else F.conv2d(xc, w, None, stride, pad, dil))
         ctx.save_for_backward(xc, w)
@@ -115,7 +124,7 @@ class _HipConv(torch.autograd.Function):
             elif eng == "direct":
                 dx = ops.conv2d(op, dy, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
             elif eng == "wino_dil":
-                dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout)
+                dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
                                                          [True, False, False])[0]
@@ -125,7 +134,7 @@ class _HipConv(torch.autograd.Function):
         if weng == "winograd":
             dw = ops.conv3x3_winograd_wrw(transposed, x, dy, Cout, out=sink)
         elif weng == "wino_dil":
-            dw = ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, W), Cout, out=sink)
+            dw = ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, W), Cout, out=sink, geom=ops.conv4x4_geometry(k, stride, pad, dil))
         elif ctx.needs_input_grad[1]:
             dw = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
                                                      [False, True, False])[1]
@@ -169,7 +178,7 @@ def conv_nobias(m, x, weight=None):
         elif eng == "direct":
             return ops.conv2d(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng == "wino_dil":
-            return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout)
+            return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
     if transposed:
         return F.conv_transpose2d(x, w, None, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
     return F.conv2d(x, w, None, m.stride, m.padding, m.dilation, m.groups)

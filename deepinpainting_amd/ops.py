@@ -413,31 +413,46 @@ def conv3x3_winograd(op, inp, weight, in_shape, Cout, bias=None, epilogue=None, 
     return out
 
 
-def dilated_winograd_supported(mode, B, Cin, H, W, Cout):
-    return _lib.lib().ipsr_conv4x4_dilated_winograd_workspace_bytes(mode, B, Cin, H, W, Cout) > 0
+GEOM_K4_S2_P3_D2 = 0       # Conv2d(k4, stride 2, pad 3, dilation 2): netG's down convolution
+GEOM_K4_S1_P1 = 1          # Conv2d(k4, stride 1, pad 1): netD's fourth convolution
 
 
-def conv4x4_dilated_winograd(mode, a, b, in_shape, Cout, out=None):
-    """Conv2d(k4, stride 2, pad 3, dilation 2) by Winograd F(3x3,4x4) (ipsr_conv4x4_dilated_winograd): mode 0 forward (a = x,
-    b = weight -> y), 1 backward-data (a = dy, b = weight -> dx), 2 weight gradient (a = x, b = dy -> dw)."""
+def conv4x4_geometry(k, stride, pad, dil):
+    """-> the `geom` of ipsr_conv4x4_winograd for a Conv2d, or None."""
+    if (k, stride, pad, dil) == (4, 2, 3, 2):
+        return GEOM_K4_S2_P3_D2
+    if (k, stride, pad, dil) == (4, 1, 1, 1):
+        return GEOM_K4_S1_P1
+    return None
+
+
+def dilated_winograd_supported(mode, B, Cin, H, W, Cout, geom=GEOM_K4_S2_P3_D2):
+    return _lib.lib().ipsr_conv4x4_winograd_workspace_bytes(geom, mode, B, Cin, H, W, Cout) > 0
+
+
+def conv4x4_dilated_winograd(mode, a, b, in_shape, Cout, out=None, geom=GEOM_K4_S2_P3_D2):
+    """Conv2d(k4, stride 2, pad 3, dilation 2) (geom 0) or Conv2d(k4, stride 1, pad 1) (geom 1) by Winograd F(3x3,4x4)
+    (ipsr_conv4x4_winograd): mode 0 forward (a = x, b = weight -> y), 1 backward-data (a = dy, b = weight -> dx), 2 weight
+    gradient (a = x, b = dy -> dw)."""
     B, Cin, H, W = in_shape
     a = _req(a, torch.float32, "operand a")
     b = _req(b, torch.float32, "operand b")
-    xs, ys, wsh = (B, Cin, H, W), (B, Cout, H // 2, W // 2), (Cout, Cin, 4, 4)
+    Ho, Wo = (H // 2, W // 2) if geom == GEOM_K4_S2_P3_D2 else (H - 1, W - 1)
+    xs, ys, wsh = (B, Cin, H, W), (B, Cout, Ho, Wo), (Cout, Cin, 4, 4)
     want = {0: (xs, wsh, ys), 1: (ys, wsh, xs), 2: (xs, ys, wsh)}[mode]
     if tuple(a.shape) != want[0] or tuple(b.shape) != want[1]:
-        raise RuntimeError("conv4x4_dilated_winograd mode %d: operands %s / %s do not match %s / %s" % (mode, tuple(a.shape), tuple(b.shape), want[0], want[1]))
+        raise RuntimeError("conv4x4_winograd mode %d: operands %s / %s do not match %s / %s" % (mode, tuple(a.shape), tuple(b.shape), want[0], want[1]))
     if out is not None and (tuple(out.shape) != tuple(want[2]) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device):
-        raise RuntimeError("conv4x4_dilated_winograd: `out` must be a contiguous fp32 %s tensor on %s" % (tuple(want[2]), a.device))
+        raise RuntimeError("conv4x4_winograd: `out` must be a contiguous fp32 %s tensor on %s" % (tuple(want[2]), a.device))
     if out is None:
         out = torch.empty(want[2], dtype=torch.float32, device=a.device)
     L = _lib.lib()
-    nbytes = L.ipsr_conv4x4_dilated_winograd_workspace_bytes(mode, B, Cin, H, W, Cout)
+    nbytes = L.ipsr_conv4x4_winograd_workspace_bytes(geom, mode, B, Cin, H, W, Cout)
     if nbytes == 0:
-        raise NotImplementedError("ipsr_conv4x4_dilated_winograd: mode %d Cin=%d Cout=%d %dx%d is not implemented" % (mode, Cin, Cout, H, W))
+        raise NotImplementedError("ipsr_conv4x4_winograd: geometry %d mode %d Cin=%d Cout=%d %dx%d is not implemented" % (geom, mode, Cin, Cout, H, W))
     ws = _workspace(nbytes, a.device)
-    _lib.check(L.ipsr_conv4x4_dilated_winograd(mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout,
-                                               ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv4x4_dilated_winograd")
+    _lib.check(L.ipsr_conv4x4_winograd(geom, mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout,
+                                       ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv4x4_winograd")
     return out
 
 

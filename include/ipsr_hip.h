@@ -249,6 +249,15 @@ size_t ipsr_conv4x4_dilated_winograd_workspace_bytes(int mode, int B, int Cin, i
 int ipsr_conv4x4_dilated_winograd(int mode, const float* a, const float* b, float* out, int B, int Cin, int H, int W, int Cout,
                                   void* ws, size_t ws_bytes, void* stream);
 
+/* The same F(3x3,4x4) pipeline for either 4x4 geometry of the nets that is a 4-tap stride-1 correlation:
+ *   geom 0  Conv2d(k4, stride 2, pad 3, dilation 2)  (== the two entry points above)
+ *   geom 1  Conv2d(k4, stride 1, pad 1) — netD's fourth convolution 256 -> 512 on 32x32, models/networks.py:483-489 —
+ *           y / dy are [B,Cout,H-1,W-1]; every position of dx is written.
+ * Modes and operand roles as above. */
+size_t ipsr_conv4x4_winograd_workspace_bytes(int geom, int mode, int B, int Cin, int H, int W, int Cout);
+int ipsr_conv4x4_winograd(int geom, int mode, const float* a, const float* b, float* out, int B, int Cin, int H, int W, int Cout,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
  * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.

@@ -162,6 +162,34 @@ def test_dilated_4x4_winograd_f3x3_4x4_vs_fp64(Cin, H, W, Cout, B):
         assert not ops.dilated_winograd_supported(1, B, Cin, H, W, Cout)
 
 
+@pytest.mark.parametrize("Cin,H,W,Cout,B", [(32, 16, 16, 48, 2), (256, 32, 32, 128, 2), (16, 7, 10, 32, 3), (64, 4, 4, 64, 4), (48, 13, 21, 20, 1)])
+def test_k4_s1_p1_winograd_f3x3_4x4_vs_fp64(Cin, H, W, Cout, B):
+    """netD's fourth convolution Conv2d(k4, stride 1, pad 1) (models/networks.py:483-489; 256 -> 512 on 32x32 -> 31x31) through
+    the same F(3x3,4x4) pipeline (geometry 1 of ipsr_conv4x4_winograd): forward, input gradient (every position) and weight
+    gradient within 1e-4 of fp64, on odd and even extents and grids that are not multiples of the 3x3 tile."""
+    from deepinpainting_amd import ops
+    g = torch.Generator().manual_seed(Cin * 5 + H)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1).cuda()
+    dy = torch.randn(B, Cout, H - 1, W - 1, generator=g).cuda()
+    xd, wd = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True)
+    y64 = F.conv2d(xd, wd, None, 1, 1, 1)
+    dx64, dw64 = torch.autograd.grad(y64, (xd, wd), dy.double().cpu())
+    G1 = ops.GEOM_K4_S1_P1
+    assert ops.conv4x4_geometry(4, 1, 1, 1) == G1 and ops.conv4x4_geometry(4, 2, 3, 2) == ops.GEOM_K4_S2_P3_D2 and ops.conv4x4_geometry(4, 2, 1, 1) is None
+    y = ops.conv4x4_dilated_winograd(0, x, w, (B, Cin, H, W), Cout, geom=G1)
+    dw = ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, W), Cout, geom=G1)
+    assert tuple(y.shape) == (B, Cout, H - 1, W - 1)
+    assert _rel(y, y64.detach()) <= 1e-4
+    assert _rel(dw, dw64) <= 1e-4
+    if Cout % 16 == 0:
+        dx = torch.full((B, Cin, H, W), float("nan"), device="cuda")          # every element must be overwritten
+        ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, out=dx, geom=G1)
+        assert _rel(dx, dx64) <= 1e-4
+    else:
+        assert not ops.dilated_winograd_supported(1, B, Cin, H, W, Cout, geom=G1)
+
+
 @pytest.mark.parametrize("engine", ["direct", "winograd", "auto"])
 def test_module_path_forward_and_gradients(engine):
     """models/hipconv.py: Conv2d / ConvTranspose2d modules through the dispatcher with one engine forced — output, input
@@ -207,6 +235,10 @@ def test_dispatcher_rules_and_refusals():
     assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 4, 2, 3, 2) == "miopen"
     assert sel(ops.CONV_BWD_DATA, 8, 512, 16, 16, 512, 4, 2, 3, 2) == "direct"
     assert hipconv.select_wrw(False, 8, 256, 64, 64, 256, 4, 2, 3, 2) == "wino_dil"
+    assert sel(ops.CONV_FWD, 8, 256, 32, 32, 512, 4, 1, 1, 1) == "wino_dil"              # netD's 4x4 stride-1 convolution
+    assert sel(ops.CONV_BWD_DATA, 8, 256, 32, 32, 512, 4, 1, 1, 1) == "wino_dil"
+    assert hipconv.select_wrw(False, 8, 256, 32, 32, 512, 4, 1, 1, 1) == "wino_dil"
+    assert sel(ops.CONV_FWD, 8, 512, 31, 31, 1, 4, 1, 1, 1) == "miopen"                  # its one-channel head
     assert hipconv.select_wrw(False, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd"
     assert hipconv.select_wrw(False, 8, 128, 128, 128, 128, 3, 1, 1, 1) == "miopen"
     assert sel(ops.CONV_FWD, 8, 256, 32, 32, 512, 4, 2, 1, 1) == "miopen"

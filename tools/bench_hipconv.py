@@ -68,12 +68,13 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--k3", action="store_true", help="only the 3x3 stride-1 shapes (the Winograd candidates)")
+    ap.add_argument("--k4s1", action="store_true", help="only netD's 4x4 stride-1 convolution")
     args = ap.parse_args()
     B = args.batch
     torch.manual_seed(0)
     print("%-5s %-16s %-14s %-7s | %-4s %9s %9s %7s %7s | %9s %9s  %s" % ("kind", "input", "weight", "s/p/d", "op", "hip ms", "miopen ms", "hip TF", "mio TF", "hip err", "mio err", "use"))
     tot_h = tot_m = tot_best = 0.0
-    for kind, Cin, H, Cout, k, st, pad, dil in (QUICK if args.quick else (K3 if args.k3 else SHAPES)):
+    for kind, Cin, H, Cout, k, st, pad, dil in ([] if args.k4s1 else QUICK if args.quick else (K3 if args.k3 else SHAPES)):
         tr = kind == "convT"
         x = torch.randn(B, Cin, H, H, device="cuda")
         w = torch.randn((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device="cuda") * 0.05
@@ -162,6 +163,26 @@ def main():
                     err = float((a - b2).abs().max() / b2.abs().max())
                     tw, tm = timed(hipf), timed(miof)
                     print("dil   %-16s %-14s | %-4s wino %9.4f ms %7.1f TF   miopen %9.4f ms %7.1f TF   |diff| %9.2e  %s" % (
+                        "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), name, tw, flops / tw / 1e9, tm, flops / tm / 1e9, err,
+                        "WINO" if tw < tm else ""), flush=True)
+    if args.k3 or args.k4s1:
+        print("\n4x4 stride-1 pad-1 (netD's fourth convolution), Winograd F(3x3,4x4) vs MIOpen:")
+        for Cin, H, Cout in ((256, 32, 512), (128, 64, 256), (512, 16, 512)):
+            x = torch.randn(B, Cin, H, H, device="cuda")
+            w = torch.randn(Cout, Cin, 4, 4, device="cuda") * 0.05
+            dy = torch.randn(B, Cout, H - 1, H - 1, device="cuda")
+            cb = torch.ops.aten.convolution_backward
+            cargs = (dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+            flops = 2.0 * B * Cin * Cout * 16 * (H - 1) ** 2
+            G1 = ops.GEOM_K4_S1_P1
+            with torch.no_grad():
+                for name, hipf, miof in (("fwd", lambda: ops.conv4x4_dilated_winograd(0, x, w, (B, Cin, H, H), Cout, geom=G1), lambda: F.conv2d(x, w, None, 1, 1, 1)),
+                                         ("bwdD", lambda: ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, H), Cout, geom=G1), lambda: cb(*cargs, [True, False, False])[0]),
+                                         ("wrw", lambda: ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, H), Cout, geom=G1), lambda: cb(*cargs, [False, True, False])[1])):
+                    a, b2 = hipf(), miof()
+                    err = float((a - b2).abs().max() / b2.abs().max())
+                    tw, tm = timed(hipf), timed(miof)
+                    print("k4s1  %-16s %-14s | %-4s wino %9.4f ms %7.1f TF   miopen %9.4f ms %7.1f TF   |diff| %9.2e  %s" % (
                         "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), name, tw, flops / tw / 1e9, tm, flops / tm / 1e9, err,
                         "WINO" if tw < tm else ""), flush=True)
     print("sum over shapes (one call each): hip %.3f ms, miopen %.3f ms, best-of %.3f ms" % (tot_h, tot_m, tot_best))
