@@ -32,6 +32,42 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int WG_BM = 128, WG_BN = 128, WG_BK = 16, WG_NBUF = 4, WG_THREADS = 256;
 
+// How the reduction of the 36 GEMMs is cut (wino_choose_split): the GEMMs xi < xi_split ("head") in `nsplit` ranges of `sps`
+// stages, the others ("tail") in `nsplit_t` ranges of `sps_t`.  Range ks of GEMM xi writes slab ks of M
+// (M + (ks*36 + xi) * plane); the output transforms add the slabs of each xi in ascending order (deterministic).
+struct WinoSplit {
+    int nsplit, sps, xi_split, nsplit_t, sps_t;
+    __host__ __device__ int slabs() const { return xi_split >= 36 ? nsplit : (xi_split <= 0 ? nsplit_t : (nsplit > nsplit_t ? nsplit : nsplit_t)); }
+    __host__ __device__ int of(int xi) const { return xi < xi_split ? nsplit : nsplit_t; }
+    __host__ int workgroups(int tiles_per_xi) const { return tiles_per_xi * (xi_split * nsplit + (36 - xi_split) * nsplit_t); }
+};
+
+// m[i][j] = sum over the slabs of GEMM xi = 6i+j of M[slab][xi][off]
+__device__ __forceinline__ void wino_load_sum(const float* __restrict__ M, const WinoSplit sp, size_t plane, size_t off, float m[6][6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[i][j] = M[(size_t)(i * 6 + j) * plane + off];
+    // slabs every GEMM has: straight-line adds; the slabs only the finer-cut group has: predicated
+    const int nmin = sp.xi_split >= 36 ? sp.nsplit : (sp.nsplit < sp.nsplit_t ? sp.nsplit : sp.nsplit_t), nmax = sp.slabs();
+    for (int s = 1; s < nmin; ++s) {
+        const float* Ms = M + (size_t)s * 36 * plane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + off];
+    }
+    for (int s = nmin < 1 ? 1 : nmin; s < nmax; ++s) {
+        const float* Ms = M + (size_t)s * 36 * plane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (s < sp.of(i * 6 + j)) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + off];
+    }
+}
+
 // ---- 1-D transforms --------------------------------------------------------------------------------
 __device__ __forceinline__ void wino_bt(const float d[6], float v[6])        // B^T d
 {
@@ -174,7 +210,7 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
 // Conv2d(bias) -> ReLU(inplace) [-> MaxPool2d(2,2)] (models/vgg16.py:9-21) without a second pass over the activations.
 // NaN-propagating like torch's relu / max_pool2d.
 template <int EPI>
-__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mo, int nsplit, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mo, WinoSplit split, const float* __restrict__ bias,
                                                           int B, int K, int Kp, int H, int Wd, int TY, int TX, int Tp, float* __restrict__ y)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
@@ -182,17 +218,7 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
     if (t >= T) return;
     float m[6][6];
     const size_t plane = (size_t)Kp * Tp;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) m[i][j] = Mo[(size_t)(i * 6 + j) * plane + (size_t)k * Tp + t];
-    for (int sp = 1; sp < nsplit; ++sp) {
-        const float* Ms = Mo + (size_t)sp * 36 * plane;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + (size_t)k * Tp + t];
-    }
+    wino_load_sum(Mo, split, plane, (size_t)k * Tp + t, m);
     float w[4][6], o[4][4];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {                 // columns: w[:,j] = A^T m[:,j]
@@ -332,24 +358,14 @@ __global__ void __launch_bounds__(256) wino_wrw_tile_kernel(const float* __restr
 }
 
 // dW[k][c][r][s] = (A'^T Mw[:][k][c] A')[r][s]
-__global__ void __launch_bounds__(256) wino_wrw_output_kernel(const float* __restrict__ Mw, int nsplit, int K, int C, int Kp, int Cp,
+__global__ void __launch_bounds__(256) wino_wrw_output_kernel(const float* __restrict__ Mw, WinoSplit split, int K, int C, int Kp, int Cp,
                                                               float* __restrict__ dW)
 {
     const int c = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
     if (c >= C) return;
     float m[6][6];
     const size_t plane = (size_t)Kp * Cp;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) m[i][j] = Mw[(size_t)(i * 6 + j) * plane + (size_t)k * Cp + c];
-    for (int sp = 1; sp < nsplit; ++sp) {
-        const float* Ms = Mw + (size_t)sp * 36 * plane;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + (size_t)k * Cp + c];
-    }
+    wino_load_sum(Mw, split, plane, (size_t)k * Cp + c, m);
     float w[3][6], o[3][3];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -377,7 +393,7 @@ __global__ void __launch_bounds__(256) wino_wrw_output_kernel(const float* __res
 // in order, by the output transform).  Small layers have too few 128x128 tiles to fill 256 CUs x 2 otherwise (36 x 4 x 1 = 144
 // workgroups for a 512-channel 16x16 map), and tile counts just above a multiple of 512 leave a nearly empty second round.
 __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* __restrict__ U, const float* __restrict__ V, int C, int Kp, int Tp,
-                                                                  int ktiles, int ttiles, int nsplit, int sps, float* __restrict__ Mo)
+                                                                  int ktiles, int ttiles, WinoSplit split, float* __restrict__ Mo)
 {
     __shared__ __attribute__((aligned(16))) float lds[WG_NBUF * 2 * WG_BK * WG_BM];
     const int tid = threadIdx.x;
@@ -386,9 +402,16 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
     const int r = lane & 31, h = lane >> 5;
 
     // all tiles of one xi (they share U[xi] and V[xi]) get consecutive logical ids -> one XCD's L2
-    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_xi = ktiles * ttiles * nsplit;
-    const int xi = L / per_xi, rem = L - xi * per_xi;
+    // head workgroups (the long ones) are dispatched first, the tail's short ones fill the last round; each group is spread
+    // over the XCDs on its own
+    const int tiles = ktiles * ttiles;
+    const unsigned head = (unsigned)(split.xi_split * tiles * split.nsplit);
+    const bool is_tail = blockIdx.x >= head;
+    const unsigned L = is_tail ? xcd_remap(blockIdx.x - head, gridDim.x - head) : xcd_remap(blockIdx.x, head);
+    const int nsplit = is_tail ? split.nsplit_t : split.nsplit, sps = is_tail ? split.sps_t : split.sps;
+    const int per_xi = tiles * nsplit;
+    const int xi0 = L / per_xi, rem = L - xi0 * per_xi;
+    const int xi = xi0 + (is_tail ? split.xi_split : 0);
     const int ks = rem % nsplit, kt = (rem / nsplit) % ktiles, tt = rem / (nsplit * ktiles);
     const int k0 = kt * WG_BM, t0 = tt * WG_BN;
     const int s_lo = ks * sps;
@@ -474,12 +497,32 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------
-// how to cut the reduction of the 36 GEMMs: estimated time = rounds of 512 resident workgroups x (stages + pipeline fill) plus
-// the extra pass over the partial results; the candidate with the lowest estimate wins
-static void wino_choose_split(int tiles36, int stages, size_t m_bytes, int* nsplit, int* sps)
+// how to cut the reduction of the 36 GEMMs (measurements: tools/sweep_wino_split.py -> profiles/r02_sweep_wino_split.txt).
+//  * uniform cut (weight gradients: thousands of stages, a handful of output tiles): estimated time = rounds of 512 resident
+//    workgroups x (stages + pipeline fill) plus the extra pass over the partial results; the lowest estimate wins.
+//  * head / tail: a grid of 36 x 8 or 36 x 16 tiles is 288 / 576 workgroups — one round of the chip plus an eighth, i.e. a
+//    second round that is nearly empty (56 % of the matrix cores busy on a 512-channel 32x32 map).  There the GEMMs of the
+//    first 32 points run uncut and fill the round exactly, and the last 4 are cut 2-4 ways so that their short workgroups
+//    fill the tail evenly: whole convolution -14 % (512@32x32), -23 % (1024 -> 256 @32x32), -10 % (512 -> 128 @64x64).
+//  * small grids with short reductions (<= 144 workgroups, <= 32 stages) stay uncut: the cut shortens the GEMM by 3-8 us and
+//    costs the output transform 10 us per extra slab on a map with that few tiles.
+static WinoSplit wino_choose_split(int tiles36, int stages, size_t m_bytes)
 {
-    double best = -1.0;
-    *nsplit = 1; *sps = stages;
+    const int tiles = tiles36 / 36;
+    WinoSplit best{1, stages, 36, 1, stages};
+    if (const char* f = getenv("IPSR_WINO_SPLIT")) {         // tuning aid: "nsplit,xi_split,nsplit_t"
+        int a = 1, x = 36, b = 1;
+        if (sscanf(f, "%d,%d,%d", &a, &x, &b) == 3 && a >= 1 && b >= 1 && x >= 1 && x <= 36 && a <= stages && b <= stages) {
+            const int pa = cdiv(stages, a), pb = cdiv(stages, b);
+            return WinoSplit{cdiv(stages, pa), pa, x, cdiv(stages, pb), pb};
+        }
+    }
+    if (tiles36 <= 144 && stages <= 32) return best;
+    if ((tiles == 8 || tiles == 16) && stages >= 16 && stages <= 128) {
+        const int nt = stages >= 32 ? 4 : 2, per = cdiv(stages, nt);
+        return WinoSplit{1, stages, 32, cdiv(stages, per), per};
+    }
+    double best_t = -1.0;
     const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
     for (int ns : cand) {
         if (ns > 1 && stages / ns < 4) break;
@@ -491,11 +534,12 @@ static void wino_choose_split(int tiles36, int stages, size_t m_bytes, int* nspl
         const long tail = wgs - (rounds - 1) * 512;
         double t = (rounds - 1) * (per + 3) * 1.7 + (per + 3) * (tail <= 256 ? 1.15 : 1.7);
         t += (real - 1) * (double)m_bytes * 2.0 / 4.0e6;              // partials written + read at ~4 TB/s, in us
-        if (best < 0.0 || t < best) { best = t; *nsplit = real; *sps = per; }
+        if (best_t < 0.0 || t < best_t) { best_t = t; best = WinoSplit{real, per, 36, real, per}; }
     }
+    return best;
 }
 
-struct WinoPlan { int TY, TX, T, Tp, Kp, nsplit, sps; size_t u_floats, v_floats, m_floats, total_bytes; };
+struct WinoPlan { int TY, TX, T, Tp, Kp; WinoSplit sp; size_t u_floats, v_floats, m_floats, total_bytes; };
 
 static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p)
 {
@@ -507,8 +551,8 @@ static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p)
     p->u_floats = (size_t)36 * C * p->Kp;
     p->v_floats = (size_t)36 * C * p->Tp;
     const size_t m1 = (size_t)36 * p->Kp * p->Tp;
-    wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), C / WG_BK, m1 * 4, &p->nsplit, &p->sps);
-    p->m_floats = m1 * p->nsplit;
+    p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), C / WG_BK, m1 * 4);
+    p->m_floats = m1 * p->sp.slabs();
     p->total_bytes = align_up(p->u_floats * 4, 256) + align_up(p->v_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
     return IPSR_OK;
 }
@@ -544,17 +588,17 @@ int launch_winograd(const float* x, const float* w, float* y, int B, int C, int 
     if (int rc = check_launch("wino_input_kernel")) return rc;
     const int ktiles = p.Kp / WG_BM, ttiles = p.Tp / WG_BN;
     profile_mark_start(st, 3);
-    wino_gemm_kernel<<<36 * ktiles * ttiles * p.nsplit, WG_THREADS, 0, st>>>(U, V, C, p.Kp, p.Tp, ktiles, ttiles, p.nsplit, p.sps, Mo);
+    wino_gemm_kernel<<<p.sp.workgroups(ktiles * ttiles), WG_THREADS, 0, st>>>(U, V, C, p.Kp, p.Tp, ktiles, ttiles, p.sp, Mo);
     profile_mark_stop(st, 3, 72.0 * C * p.Kp * p.Tp);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     const dim3 og(cdiv(p.T, 256), K);
-    if (epilogue == 2) wino_output_kernel<2><<<og, 256, 0, st>>>(Mo, p.nsplit, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
-    else if (epilogue == 1) wino_output_kernel<1><<<og, 256, 0, st>>>(Mo, p.nsplit, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
-    else wino_output_kernel<0><<<og, 256, 0, st>>>(Mo, p.nsplit, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
+    if (epilogue == 2) wino_output_kernel<2><<<og, 256, 0, st>>>(Mo, p.sp, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
+    else if (epilogue == 1) wino_output_kernel<1><<<og, 256, 0, st>>>(Mo, p.sp, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
+    else wino_output_kernel<0><<<og, 256, 0, st>>>(Mo, p.sp, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
     return check_launch("wino_output_kernel");
 }
 
-struct WinoWrwPlan { int TY, TX, T, Tp, Kp, Cp, nsplit, sps; size_t e_floats, v_floats, m_floats, total_bytes; };
+struct WinoWrwPlan { int TY, TX, T, Tp, Kp, Cp; WinoSplit sp; size_t e_floats, v_floats, m_floats, total_bytes; };
 
 static int wino_wrw_plan(int B, int K, int C, int H, int W, WinoWrwPlan* p)
 {
@@ -566,8 +610,8 @@ static int wino_wrw_plan(int B, int K, int C, int H, int W, WinoWrwPlan* p)
     p->e_floats = (size_t)36 * p->Tp * p->Kp;
     p->v_floats = (size_t)36 * p->Tp * p->Cp;
     const size_t m1 = (size_t)36 * p->Kp * p->Cp;
-    wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4, &p->nsplit, &p->sps);
-    p->m_floats = m1 * p->nsplit;
+    p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
+    p->m_floats = m1 * p->sp.slabs();
     p->total_bytes = align_up(p->e_floats * 4, 256) + align_up(p->v_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
     return IPSR_OK;
 }
@@ -595,10 +639,10 @@ int launch_winograd_wrw(const float* et, const float* dt, float* dW, int B, int 
     const int ktiles = p.Kp / WG_BM, ctiles = p.Cp / WG_BN;
     // M[xi][k][c] = sum_t Et[xi][t][k] * Vt[xi][t][c]: the same GEMM with the tiles as the reduction
     profile_mark_start(st, 3);
-    wino_gemm_kernel<<<36 * ktiles * ctiles * p.nsplit, WG_THREADS, 0, st>>>(Et, Vt, p.Tp, p.Kp, p.Cp, ktiles, ctiles, p.nsplit, p.sps, Mw);
+    wino_gemm_kernel<<<p.sp.workgroups(ktiles * ctiles), WG_THREADS, 0, st>>>(Et, Vt, p.Tp, p.Kp, p.Cp, ktiles, ctiles, p.sp, Mw);
     profile_mark_stop(st, 3, 72.0 * p.Tp * p.Kp * p.Cp);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
-    wino_wrw_output_kernel<<<dim3(cdiv(C, 256), K), 256, 0, st>>>(Mw, p.nsplit, K, C, p.Kp, p.Cp, dW);
+    wino_wrw_output_kernel<<<dim3(cdiv(C, 256), K), 256, 0, st>>>(Mw, p.sp, K, C, p.Kp, p.Cp, dW);
     return check_launch("wino_wrw_output_kernel");
 }
 
@@ -697,7 +741,7 @@ __global__ void __launch_bounds__(256) wino4_filter_kernel(const float* __restri
 }
 
 // y[b][k][os*(3ty+i)+oo][os*(3tx+j)+oo] = (A'^T M A')[i][j] for 3ty+i < Ho, 3tx+j < Wo  (y is [B,K,Hy,Wy])
-__global__ void __launch_bounds__(256) wino3_output_kernel(const float* __restrict__ Mo, int nsplit, int B, int K, int Kp, int Ho, int Wo,
+__global__ void __launch_bounds__(256) wino3_output_kernel(const float* __restrict__ Mo, WinoSplit split, int B, int K, int Kp, int Ho, int Wo,
                                                            int TY, int TX, int Tp, int Hy, int Wy, int os, int oo, float* __restrict__ y)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
@@ -705,17 +749,7 @@ __global__ void __launch_bounds__(256) wino3_output_kernel(const float* __restri
     if (t >= T) return;
     float m[6][6];
     const size_t plane = (size_t)Kp * Tp;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) m[i][j] = Mo[(size_t)(i * 6 + j) * plane + (size_t)k * Tp + t];
-    for (int sp = 1; sp < nsplit; ++sp) {
-        const float* Ms = Mo + (size_t)sp * 36 * plane;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + (size_t)k * Tp + t];
-    }
+    wino_load_sum(Mo, split, plane, (size_t)k * Tp + t, m);
     float w[3][6], o[3][3];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -774,24 +808,14 @@ __global__ void __launch_bounds__(256) wino_wrw_tile3_kernel(const float* __rest
 }
 
 // dW[k][c][r][s] (4x4) = (A^T Mw[:][k][c] A)[r][s]
-__global__ void __launch_bounds__(256) wino_wrw_output4_kernel(const float* __restrict__ Mw, int nsplit, int K, int C, int Kp, int Cp,
+__global__ void __launch_bounds__(256) wino_wrw_output4_kernel(const float* __restrict__ Mw, WinoSplit split, int K, int C, int Kp, int Cp,
                                                                float* __restrict__ dW)
 {
     const int c = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
     if (c >= C) return;
     float m[6][6];
     const size_t plane = (size_t)Kp * Cp;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) m[i][j] = Mw[(size_t)(i * 6 + j) * plane + (size_t)k * Cp + c];
-    for (int sp = 1; sp < nsplit; ++sp) {
-        const float* Ms = Mw + (size_t)sp * 36 * plane;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) m[i][j] += Ms[(size_t)(i * 6 + j) * plane + (size_t)k * Cp + c];
-    }
+    wino_load_sum(Mw, split, plane, (size_t)k * Cp + c, m);
     float w[4][6], o[4][4];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -808,7 +832,7 @@ __global__ void __launch_bounds__(256) wino_wrw_output4_kernel(const float* __re
     for (int i = 0; i < 4; ++i) dst[i] = make_float4(o[i][0], o[i][1], o[i][2], o[i][3]);
 }
 
-struct DilPlan { int Ho, Wo, Gy, Gx, TY, TX, T, Tp, Kp, Cp, nsplit, sps; size_t a_floats, b_floats, m_floats, total_bytes; };
+struct DilPlan { int Ho, Wo, Gy, Gx, TY, TX, T, Tp, Kp, Cp; WinoSplit sp; size_t a_floats, b_floats, m_floats, total_bytes; };
 
 // mode 0: forward (grid = output Ho x Wo, reduce C=Cin, produce K=Cout); 1: backward-data (geom 0: grid = H/2 x W/2 odd positions
 // of dx; geom 1: grid = H x W; reduce Cout, produce Cin); 2: weight gradient (tiles of dy, reduction over tiles).
@@ -830,8 +854,8 @@ static int dil_plan(int geom, int mode, int B, int Cin, int H, int W, int Cout, 
         p->a_floats = (size_t)36 * p->Tp * p->Kp;
         p->b_floats = (size_t)36 * p->Tp * p->Cp;
         const size_t m1 = (size_t)36 * p->Kp * p->Cp;
-        wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4, &p->nsplit, &p->sps);
-        p->m_floats = m1 * p->nsplit;
+        p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
+        p->m_floats = m1 * p->sp.slabs();
     } else {
         const int red = mode == 0 ? Cin : Cout, prod = mode == 0 ? Cout : Cin;
         if (red % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "4x4 winograd: %d reduction channels are not a multiple of %d", red, WG_BK);
@@ -840,8 +864,8 @@ static int dil_plan(int geom, int mode, int B, int Cin, int H, int W, int Cout, 
         p->a_floats = (size_t)36 * red * p->Kp;
         p->b_floats = (size_t)36 * red * p->Tp;
         const size_t m1 = (size_t)36 * p->Kp * p->Tp;
-        wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), red / WG_BK, m1 * 4, &p->nsplit, &p->sps);
-        p->m_floats = m1 * p->nsplit;
+        p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), red / WG_BK, m1 * 4);
+        p->m_floats = m1 * p->sp.slabs();
     }
     p->total_bytes = align_up(p->a_floats * 4, 256) + align_up(p->b_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
     return IPSR_OK;
@@ -880,10 +904,10 @@ int launch_winograd_dil(int geom, int mode, const float* a, const float* b2, flo
         if (int rc = check_launch("wino_window_kernel")) return rc;
         const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
         profile_mark_start(st, 3);
-        wino_gemm_kernel<<<36 * kt * tt * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, Cin, p.Kp, p.Tp, kt, tt, p.nsplit, p.sps, Mo);
+        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, Cin, p.Kp, p.Tp, kt, tt, p.sp, Mo);
         profile_mark_stop(st, 3, 72.0 * Cin * p.Kp * p.Tp);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
-        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cout), 256, 0, st>>>(Mo, p.nsplit, B, Cout, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, Ho, Wo, 1, 0, out);
+        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cout), 256, 0, st>>>(Mo, p.sp, B, Cout, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, Ho, Wo, 1, 0, out);
         return check_launch("wino3_output_kernel");
     }
     if (mode == 1) {            // a = dy, b2 = w, out = dx
@@ -897,10 +921,10 @@ int launch_winograd_dil(int geom, int mode, const float* a, const float* b2, flo
         if (int rc = check_launch("wino_window_kernel")) return rc;
         const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
         profile_mark_start(st, 3);
-        wino_gemm_kernel<<<36 * kt * tt * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, Cout, p.Kp, p.Tp, kt, tt, p.nsplit, p.sps, Mo);
+        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, Cout, p.Kp, p.Tp, kt, tt, p.sp, Mo);
         profile_mark_stop(st, 3, 72.0 * Cout * p.Kp * p.Tp);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
-        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cin), 256, 0, st>>>(Mo, p.nsplit, B, Cin, p.Kp, p.Gy, p.Gx, p.TY, p.TX, p.Tp, H, W,
+        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cin), 256, 0, st>>>(Mo, p.sp, B, Cin, p.Kp, p.Gy, p.Gx, p.TY, p.TX, p.Tp, H, W,
                                                                          geom == 0 ? 2 : 1, geom == 0 ? 1 : 0, out);
         return check_launch("wino3_output_kernel");
     }
@@ -910,10 +934,10 @@ int launch_winograd_dil(int geom, int mode, const float* a, const float* b2, flo
     if (int rc = check_launch("wino_window_kernel")) return rc;
     const int kt = p.Kp / WG_BM, ct = p.Cp / WG_BN;
     profile_mark_start(st, 3);
-    wino_gemm_kernel<<<36 * kt * ct * p.nsplit, WG_THREADS, 0, st>>>(A, Bv, p.Tp, p.Kp, p.Cp, kt, ct, p.nsplit, p.sps, Mo);
+    wino_gemm_kernel<<<p.sp.workgroups(kt * ct), WG_THREADS, 0, st>>>(A, Bv, p.Tp, p.Kp, p.Cp, kt, ct, p.sp, Mo);
     profile_mark_stop(st, 3, 72.0 * p.Tp * p.Kp * p.Cp);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
-    wino_wrw_output4_kernel<<<dim3(cdiv(Cin, 256), Cout), 256, 0, st>>>(Mo, p.nsplit, Cout, Cin, p.Kp, p.Cp, out);
+    wino_wrw_output4_kernel<<<dim3(cdiv(Cin, 256), Cout), 256, 0, st>>>(Mo, p.sp, Cout, Cin, p.Kp, p.Cp, out);
     return check_launch("wino_wrw_output4_kernel");
 }
 
