@@ -323,7 +323,7 @@ def main():
     for _ in range(gsteps):
         train_step(model, img, mask, ref)
     torch.cuda.synchronize()
-    ncap = 64 * gsteps
+    ncap = 256 * gsteps
     gms, gwork = (ctypes.c_float * ncap)(), (ctypes.c_double * ncap)()
     ng = lib.ipsr_profile_read_region_work(3, ctypes.cast(gms, ctypes.c_void_p), ctypes.cast(gwork, ctypes.c_void_p), ncap)
     gemm_ms, gemm_flops = sum(gms[i] for i in range(ng)), sum(gwork[i] for i in range(ng))

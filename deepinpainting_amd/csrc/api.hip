@@ -127,7 +127,7 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 6; }
+int ipsr_abi_version(void) { return 7; }
 
 const char* ipsr_last_error(void) { return g_err; }
 
@@ -143,7 +143,7 @@ int ipsr_profile_enable_mask(int capacity, unsigned region_mask)
     for (int ri = 0; ri < N_REGIONS; ++ri) {
         if (!((region_mask >> ri) & 1u)) continue;
         EvRing& r = g_ring[ri];
-        const int cap_r = ri == 3 ? 64 * capacity : capacity;        // tens of GEMM launches per training step
+        const int cap_r = ri == 3 ? 256 * capacity : capacity;        // tens of GEMM launches per training step
         r.work = new double[(size_t)cap_r];
         r.ev = new hipEvent_t[2 * (size_t)cap_r];
         for (int i = 0; i < 2 * cap_r; ++i)

@@ -941,6 +941,384 @@ int launch_winograd_dil(int geom, int mode, const float* a, const float* b2, flo
     return check_launch("wino_wrw_output4_kernel");
 }
 
+// ===================================================================================================
+// The 4x4 STRIDE-2 pad-1 layers — every down convolution of netP / netD / netF (Conv2d, models/networks.py:404-432, 470-495,
+// 510-515) and every up convolution of netP / netG (ConvTranspose2d, :235-243, 420-428): a third of the training step — by
+// Winograd F(5x5, 2x2) on the two polyphase components of the fine grid.
+//
+// One geometry serves both modules.  "fine" = the 2n-grid tensor (x of Conv2d, y of ConvTranspose2d), "coarse" = the n-grid
+// one; a fine position f and a coarse position o meet through tap r when f = 2o + r - 1; the weight is [coarse ch][fine ch][4][4]
+// for both modules (Conv2d: [Cout][Cin], ConvTranspose2d: [Cin][Cout]).  In 1-D:
+//   mode 0  fine -> coarse  (Conv2d forward, ConvTranspose2d backward-data)
+//           out[o] = sum_e sum_a w[2a+e+1] P_e[o+a],  P_e[i] = fine[2i+e], e in {-1,0}: a 2-tap stride-1 correlation on each of the
+//           two phases (four in 2-D), reduced over 4 x channels.  F(5,2): 5 outputs from a 6-wide window, 6 multiplies instead of 10.
+//   mode 1  coarse -> fine  (ConvTranspose2d forward, Conv2d backward-data)
+//           fine[2i]   = w[3] in[i-1] + w[1] in[i]       both phases read the SAME window in[5t-1 .. 5t+4]: one input transform,
+//           fine[2i+1] = w[2] in[i]   + w[0] in[i+1]     four filter sets (the GEMM produces 4 x channels), phase e of tile t
+//                                                          holds the outputs i = 5t + m - e, m = 0..4
+//   mode 2  weight gradient  dW[2a+e+1] = sum_o coarse[o] P_e[o+a]: F(2x2, 5x5) — 5x5 tiles of the coarse tensor through G5,
+//           the windows of mode 0 (tile-major), reduced over all tiles by the GEMM, A2^T back to the 2x2 taps of each phase.
+// 100 multiply-adds per 5x5 tile, channel pair and phase become 36: 2.8x fewer matrix-core flops than the direct form, through
+// the same 36 GEMMs (same interpolation points 0, +-1, +-2, inf, hence the same B^T) as everything above.
+__device__ __forceinline__ void wino_g2(const float g[2], float u[6])        // G2 g   (6x2)
+{
+    u[0] = 0.25f * g[0];
+    u[1] = (-1.0f / 6.0f) * (g[0] + g[1]);
+    u[2] = (-1.0f / 6.0f) * (g[0] - g[1]);
+    u[3] = (1.0f / 24.0f) * g[0] + (1.0f / 12.0f) * g[1];
+    u[4] = (1.0f / 24.0f) * g[0] - (1.0f / 12.0f) * g[1];
+    u[5] = g[1];
+}
+__device__ __forceinline__ void wino_at5(const float m[6], float y[5])       // A5^T m (5x6)
+{
+    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    y[1] = m[1] - m[2] + 2.0f * m[3] - 2.0f * m[4];
+    y[2] = m[1] + m[2] + 4.0f * m[3] + 4.0f * m[4];
+    y[3] = m[1] - m[2] + 8.0f * m[3] - 8.0f * m[4];
+    y[4] = m[1] + m[2] + 16.0f * m[3] + 16.0f * m[4] + m[5];
+}
+__device__ __forceinline__ void wino_g5(const float e[5], float u[6])        // G5 e   (6x5)
+{
+    u[0] = 0.25f * e[0];
+    u[1] = (-1.0f / 6.0f) * (e[0] + e[1] + e[2] + e[3] + e[4]);
+    u[2] = (-1.0f / 6.0f) * (e[0] - e[1] + e[2] - e[3] + e[4]);
+    u[3] = (1.0f / 24.0f) * e[0] + (1.0f / 12.0f) * e[1] + (1.0f / 6.0f) * e[2] + (1.0f / 3.0f) * e[3] + (2.0f / 3.0f) * e[4];
+    u[4] = (1.0f / 24.0f) * e[0] - (1.0f / 12.0f) * e[1] + (1.0f / 6.0f) * e[2] - (1.0f / 3.0f) * e[3] + (2.0f / 3.0f) * e[4];
+    u[5] = e[4];
+}
+__device__ __forceinline__ void wino_at2(const float m[6], float y[2])       // A2^T m (2x6)
+{
+    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    y[1] = m[1] - m[2] + 2.0f * m[3] - 2.0f * m[4] + m[5];
+}
+
+// U[xi][r][q] = (G2 g G2^T)[xi] of the 2x2 sub-filter of each phase.  W = [coarse ch kc][fine ch cf][4][4].
+//   form 0 (mode 0): reduction row r = (phase, cf) of 4*Cf, produced column q = kc < Kc;   g[a][b] = w[2a+ey][2b+ex]
+//   form 1 (mode 1): reduction row r = kc,              produced column q = (phase, cf) of 4*Cf; g[a][b] = w[3-ey-2a][3-ex-2b]
+// One thread per (kc, cf): its 16 taps are one 64-byte read, the four phases' 4 x 36 numbers go out with the q index
+// fastest across the threads (form 0: kc, form 1: cf), i.e. coalesced.  Columns q in [Q, Qp) are zero-filled by the same threads.
+__global__ void __launch_bounds__(256) wino52_filter_kernel(const float* __restrict__ W, int Kc, int Cf, int Qp, int form, float* __restrict__ U)
+{
+    const int fast = blockIdx.x * 256 + threadIdx.x, slow = blockIdx.y;
+    const int nfast = form == 0 ? Kc : Cf;
+    const int R = form == 0 ? 4 * Cf : Kc, Q = form == 0 ? Kc : 4 * Cf;
+    const size_t plane = (size_t)R * Qp;
+    if (fast >= nfast) {
+        // padding columns: form 0: q = fast in [Kc, Qp) of rows (ph, slow); form 1: the tail [4*Cf, Qp) of row kc = slow, once
+        if (form == 0) {
+            if (fast < Qp)
+                for (int ph = 0; ph < 4; ++ph)
+                    for (int xi = 0; xi < 36; ++xi) U[(size_t)xi * plane + (size_t)(ph * Cf + slow) * Qp + fast] = 0.0f;
+        } else {
+            const int q = Q + (fast - nfast);
+            if (q < Qp)
+                for (int xi = 0; xi < 36; ++xi) U[(size_t)xi * plane + (size_t)slow * Qp + q] = 0.0f;
+        }
+        return;
+    }
+    const int kc = form == 0 ? fast : slow, cf = form == 0 ? slow : fast;
+    float w[4][4];
+    const float4* wp = reinterpret_cast<const float4*>(W + ((size_t)kc * Cf + cf) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float4 v = wp[i]; w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w; }
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const int ey = ph >> 1, ex = ph & 1;
+        float g[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) g[a][b] = form == 0 ? w[2 * a + ey][2 * b + ex] : w[3 - ey - 2 * a][3 - ex - 2 * b];
+        float t[6][2], u[6][6];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float col[2] = {g[0][b], g[1][b]};
+            float o[6];
+            wino_g2(col, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][b] = o[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wino_g2(t[i], u[i]);
+        const size_t r = form == 0 ? (size_t)ph * Cf + cf : kc, q = form == 0 ? kc : (size_t)ph * Cf + cf;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) U[(size_t)(i * 6 + j) * plane + r * Qp + q] = u[i][j];
+    }
+}
+
+// windows at tile stride 5: V[xi][cc][t] (TMAJOR = false) or V[xi][t][cc] (true), cc = (phase, c) of nphase*C.
+//   nphase = 4, IS = 2: P_e[5t + i] = x[2(5t+i) + e], e = (ey-1, ex-1)  (modes 0 and 2, x = the fine tensor)
+//   nphase = 1, IS = 1: x[5t + i - 1]                                    (mode 1, x = the coarse tensor)
+template <int IS, bool TMAJOR>
+__global__ void __launch_bounds__(256) wino5_window_kernel(const float* __restrict__ x, int B, int C, int H, int Wd, int nphase, int TY, int TX,
+                                                           int Tp, int Cp, float* __restrict__ V)
+{
+    __shared__ float stage[TMAJOR ? 36 : 1][16][17];
+    const int Ctot = nphase * C;
+    int t, cc, tl = 0, cl = 0, t0 = 0, c0 = 0;
+    if (TMAJOR) { tl = threadIdx.x & 15; cl = threadIdx.x >> 4; t0 = blockIdx.x * 16; c0 = blockIdx.y * 16; t = t0 + tl; cc = c0 + cl; }
+    else { t = blockIdx.x * 256 + threadIdx.x; cc = blockIdx.y; if (t >= Tp) return; }
+    const int T = B * TY * TX;
+    const bool live = t < T && cc < Ctot;
+    int b = 0, ty = 0, tx = 0, ph = 0, c = 0;
+    if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; ph = cc / C; c = cc - ph * C; }
+    const int offy = nphase == 4 ? (ph >> 1) - 1 : -1, offx = nphase == 4 ? (ph & 1) - 1 : -1;
+    const float* xp = x + ((size_t)b * C + c) * H * Wd;
+    float d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int yy = IS * (5 * ty + i) + offy;
+        const bool yok = live && (unsigned)yy < (unsigned)H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int xx = IS * (5 * tx + j) + offx;
+            d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+        }
+    }
+    float w[6][6], v[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float o[6];
+        wino_bt(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino_bt(w[i], v[i]);
+    if (TMAJOR) {
+        wino_store_tmajor(stage, v, tl, cl, V, t0, c0, Tp, Cp);
+    } else {
+        const size_t plane = (size_t)Ctot * Tp;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) V[(size_t)(i * 6 + j) * plane + (size_t)cc * Tp + t] = v[i][j];
+    }
+}
+
+__device__ __forceinline__ void wino_at5_2d(const float m[6][6], float o[5][5])
+{
+    float w[5][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
+        float r5[5];
+        wino_at5(col, r5);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) w[i][j] = r5[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wino_at5(w[i], o[i]);
+}
+
+// mode 0: y[b][k][5ty+i][5tx+j] = (A5^T M A5)[i][j]
+__global__ void __launch_bounds__(256) wino5_output_kernel(const float* __restrict__ Mo, WinoSplit split, int B, int K, int Kp, int Ho, int Wo,
+                                                           int TY, int TX, int Tp, float* __restrict__ y)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    const int T = B * TY * TX;
+    if (t >= T) return;
+    float m[6][6], o[5][5];
+    wino_load_sum(Mo, split, (size_t)Kp * Tp, (size_t)k * Tp + t, m);
+    wino_at5_2d(m, o);
+    const int b = t / (TY * TX), rem = t - b * TY * TX;
+    const int ty = rem / TX, tx = rem - ty * TX;
+    float* yp = y + ((size_t)b * K + k) * Ho * Wo;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int oy = 5 * ty + i, ox = 5 * tx + j;
+            if (oy < Ho && ox < Wo) yp[(size_t)oy * Wo + ox] = o[i][j];
+        }
+}
+
+// mode 1: the four phases of tile t and fine channel k (GEMM rows ph*K + k) -> the 10x10 block of y [B,K,2n_h,2n_w] around it:
+// y[2(5ty+m) - ey][2(5tx+m') - ex] = (A5^T M_ph A5)[m][m']  wherever the coarse index 5t + m - e lies in [0, n)
+__global__ void __launch_bounds__(256) wino5_output_phase_kernel(const float* __restrict__ Mo, WinoSplit split, int B, int K, int Kp, int nh, int nw,
+                                                                 int TY, int TX, int Tp, float* __restrict__ y)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    const int T = B * TY * TX;
+    if (t >= T) return;
+    const int b = t / (TY * TX), rem = t - b * TY * TX;
+    const int ty = rem / TX, tx = rem - ty * TX;
+    const int Wy = 2 * nw;
+    float* yp = y + ((size_t)b * K + k) * (size_t)(2 * nh) * Wy;
+    const size_t plane = (size_t)Kp * Tp;
+    const int ey = blockIdx.z;
+    float m[6][6], o0[5][5], o1[5][5];
+    wino_load_sum(Mo, split, plane, (size_t)((2 * ey) * K + k) * Tp + t, m);
+    wino_at5_2d(m, o0);
+    wino_load_sum(Mo, split, plane, (size_t)((2 * ey + 1) * K + k) * Tp + t, m);
+    wino_at5_2d(m, o1);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int iy = 5 * ty + i - ey;
+        if (iy < 0 || iy >= nh) continue;
+        float* row = yp + (size_t)(2 * iy + ey) * Wy;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int ix0 = 5 * tx + j, ix1 = ix0 - 1;
+            if (ix0 < nw) row[2 * ix0] = o0[i][j];
+            if (ix1 >= 0 && ix1 < nw) row[2 * ix1 + 1] = o1[i][j];
+        }
+    }
+}
+
+// mode 2: 5x5 tiles of the coarse tensor -> Et[xi][t][k] = (G5 e G5^T)[xi]
+__global__ void __launch_bounds__(256) wino_wrw_tile5_kernel(const float* __restrict__ dy, int B, int K, int Ho, int Wo, int TY, int TX,
+                                                             int Tp, int Kp, float* __restrict__ Et)
+{
+    __shared__ float stage[36][16][17];
+    const int tl = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int t0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
+    const int t = t0 + tl, k = k0 + cl, T = B * TY * TX;
+    const bool live = t < T && k < K;
+    int b = 0, ty = 0, tx = 0;
+    if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
+    const float* dp = dy + ((size_t)b * K + (live ? k : 0)) * Ho * Wo;
+    float e[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int yy = 5 * ty + i, xx = 5 * tx + j;
+            e[i][j] = (live && yy < Ho && xx < Wo) ? dp[(size_t)yy * Wo + xx] : 0.0f;
+        }
+    float w[6][5], v[6][6];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float col[5] = {e[0][j], e[1][j], e[2][j], e[3][j], e[4][j]};
+        float o[6];
+        wino_g5(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino_g5(w[i], v[i]);
+    wino_store_tmajor(stage, v, tl, cl, Et, t0, k0, Tp, Kp);
+}
+
+// mode 2: dW[kc][cf][2a+ey][2b+ex] = (A2^T Mw[:][kc][(ph, cf)] A2)[a][b]; one phase per blockIdx.z
+__global__ void __launch_bounds__(256) wino_wrw_output2_kernel(const float* __restrict__ Mw, WinoSplit split, int Kc, int Cf, int Kp, int Cp,
+                                                               float* __restrict__ dW)
+{
+    const int cf = blockIdx.x * 256 + threadIdx.x, kc = blockIdx.y, ph = blockIdx.z;
+    if (cf >= Cf) return;
+    float m[6][6], w[2][6], o[2][2];
+    wino_load_sum(Mw, split, (size_t)Kp * Cp, (size_t)kc * Cp + (size_t)ph * Cf + cf, m);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
+        float r2[2];
+        wino_at2(col, r2);
+        w[0][j] = r2[0]; w[1][j] = r2[1];
+    }
+    wino_at2(w[0], o[0]);
+    wino_at2(w[1], o[1]);
+    const int ey = ph >> 1, ex = ph & 1;
+    float* dst = dW + ((size_t)kc * Cf + cf) * 16;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) dst[(2 * a + ey) * 4 + 2 * b + ex] = o[a][b];
+}
+
+struct S2Plan { int TY, TX, T, Tp, Kp, Cp, red; WinoSplit sp; size_t a_floats, b_floats, m_floats, total_bytes; };
+
+static int s2_plan(int mode, int B, int Kc, int Cf, int nh, int nw, S2Plan* p)
+{
+    if (mode < 0 || mode > 2) return fail(IPSR_ERR_INVALID, "4x4 stride-2 winograd: mode %d", mode);
+    p->TY = mode == 1 ? (nh + 5) / 5 : (nh + 4) / 5;
+    p->TX = mode == 1 ? (nw + 5) / 5 : (nw + 4) / 5;
+    p->T = B * p->TY * p->TX;
+    p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;
+    size_t m1;
+    if (mode == 2) {
+        p->Kp = (Kc + WG_BM - 1) / WG_BM * WG_BM;
+        p->Cp = (4 * Cf + WG_BN - 1) / WG_BN * WG_BN;
+        p->red = p->Tp;
+        p->a_floats = (size_t)36 * p->Tp * p->Kp;
+        p->b_floats = (size_t)36 * p->Tp * p->Cp;
+        m1 = (size_t)36 * p->Kp * p->Cp;
+        p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
+    } else {
+        p->red = mode == 0 ? 4 * Cf : Kc;
+        if (p->red % WG_BK != 0)
+            return fail(IPSR_ERR_UNSUPPORTED, "4x4 stride-2 winograd: reduction length %d is not a multiple of %d", p->red, WG_BK);
+        const int prod = mode == 0 ? Kc : 4 * Cf;
+        p->Kp = (prod + WG_BM - 1) / WG_BM * WG_BM;
+        p->Cp = p->red;
+        p->a_floats = (size_t)36 * p->red * p->Kp;
+        p->b_floats = (size_t)36 * p->red * p->Tp;
+        m1 = (size_t)36 * p->Kp * p->Tp;
+        p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), p->red / WG_BK, m1 * 4);
+    }
+    p->m_floats = m1 * p->sp.slabs();
+    p->total_bytes = align_up(p->a_floats * 4, 256) + align_up(p->b_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
+    return IPSR_OK;
+}
+
+size_t winograd_s2_ws_bytes(int mode, int B, int Kc, int Cf, int nh, int nw)
+{
+    S2Plan p;
+    if (s2_plan(mode, B, Kc, Cf, nh, nw, &p) != IPSR_OK) return 0;
+    return p.total_bytes;
+}
+
+// fine [B,Cf,2nh,2nw], coarse [B,Kc,nh,nw], w / dW [Kc][Cf][4][4].
+// mode 0: a = fine, b2 = w, out = coarse.   mode 1: a = coarse, b2 = w, out = fine.   mode 2: a = fine, b2 = coarse, out = dW.
+int launch_winograd_s2(int mode, const float* a, const float* b2, float* out, int B, int Kc, int Cf, int nh, int nw,
+                       void* ws, size_t ws_bytes, hipStream_t st)
+{
+    S2Plan p;
+    if (int rc = s2_plan(mode, B, Kc, Cf, nh, nw, &p)) return rc;
+    if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "4x4 stride-2 winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    Carver cv(ws, ws_bytes);
+    float* A = cv.take<float>(p.a_floats);
+    float* Bv = cv.take<float>(p.b_floats);
+    float* Mo = cv.take<float>(p.m_floats);
+    const int kt = p.Kp / WG_BM;
+    if (mode == 0) {
+        wino52_filter_kernel<<<dim3(cdiv(p.Kp, 256), Cf), 256, 0, st>>>(b2, Kc, Cf, p.Kp, 0, A);
+        wino5_window_kernel<2, false><<<dim3(cdiv(p.Tp, 256), p.red), 256, 0, st>>>(a, B, Cf, 2 * nh, 2 * nw, 4, p.TY, p.TX, p.Tp, 0, Bv);
+        if (int rc = check_launch("wino5_window_kernel")) return rc;
+        const int tt = p.Tp / WG_BN;
+        profile_mark_start(st, 3);
+        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, p.red, p.Kp, p.Tp, kt, tt, p.sp, Mo);
+        profile_mark_stop(st, 3, 72.0 * p.red * p.Kp * p.Tp);
+        if (int rc = check_launch("wino_gemm_kernel")) return rc;
+        wino5_output_kernel<<<dim3(cdiv(p.T, 256), Kc), 256, 0, st>>>(Mo, p.sp, B, Kc, p.Kp, nh, nw, p.TY, p.TX, p.Tp, out);
+        return check_launch("wino5_output_kernel");
+    }
+    if (mode == 1) {
+        wino52_filter_kernel<<<dim3(cdiv(Cf + (p.Kp - 4 * Cf), 256), Kc), 256, 0, st>>>(b2, Kc, Cf, p.Kp, 1, A);
+        wino5_window_kernel<1, false><<<dim3(cdiv(p.Tp, 256), p.red), 256, 0, st>>>(a, B, Kc, nh, nw, 1, p.TY, p.TX, p.Tp, 0, Bv);
+        if (int rc = check_launch("wino5_window_kernel")) return rc;
+        const int tt = p.Tp / WG_BN;
+        profile_mark_start(st, 3);
+        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, p.red, p.Kp, p.Tp, kt, tt, p.sp, Mo);
+        profile_mark_stop(st, 3, 72.0 * p.red * p.Kp * p.Tp);
+        if (int rc = check_launch("wino_gemm_kernel")) return rc;
+        wino5_output_phase_kernel<<<dim3(cdiv(p.T, 256), Cf, 2), 256, 0, st>>>(Mo, p.sp, B, Cf, p.Kp, nh, nw, p.TY, p.TX, p.Tp, out);
+        return check_launch("wino5_output_phase_kernel");
+    }
+    wino_wrw_tile5_kernel<<<dim3(p.Tp / 16, p.Kp / 16), 256, 0, st>>>(b2, B, Kc, nh, nw, p.TY, p.TX, p.Tp, p.Kp, A);
+    wino5_window_kernel<2, true><<<dim3(p.Tp / 16, p.Cp / 16), 256, 0, st>>>(a, B, Cf, 2 * nh, 2 * nw, 4, p.TY, p.TX, p.Tp, p.Cp, Bv);
+    if (int rc = check_launch("wino5_window_kernel")) return rc;
+    const int ct = p.Cp / WG_BN;
+    profile_mark_start(st, 3);
+    wino_gemm_kernel<<<p.sp.workgroups(kt * ct), WG_THREADS, 0, st>>>(A, Bv, p.Tp, p.Kp, p.Cp, kt, ct, p.sp, Mo);
+    profile_mark_stop(st, 3, 72.0 * p.Tp * p.Kp * p.Cp);
+    if (int rc = check_launch("wino_gemm_kernel")) return rc;
+    wino_wrw_output2_kernel<<<dim3(cdiv(Cf, 256), Kc, 4), 256, 0, st>>>(Mo, p.sp, Kc, Cf, p.Kp, p.Cp, out);
+    return check_launch("wino_wrw_output2_kernel");
+}
+
 }  // namespace ipsr
 
 using namespace ipsr;
@@ -1025,6 +1403,22 @@ int ipsr_conv4x4_dilated_winograd(int mode, const float* a, const float* b, floa
                                   void* ws, size_t ws_bytes, void* stream)
 {
     return ipsr_conv4x4_winograd(0, mode, a, b, out, B, Cin, H, W, Cout, ws, ws_bytes, stream);
+}
+
+size_t ipsr_conv4x4s2_winograd_workspace_bytes(int mode, int B, int Kc, int Cf, int nh, int nw)
+{
+    if (mode < 0 || mode > 2 || B < 1 || Kc < 1 || Cf < 1 || nh < 1 || nw < 1) return 0;
+    return winograd_s2_ws_bytes(mode, B, Kc, Cf, nh, nw);
+}
+
+int ipsr_conv4x4s2_winograd(int mode, const float* a, const float* b, float* out, int B, int Kc, int Cf, int nh, int nw,
+                            void* ws, size_t ws_bytes, void* stream)
+{
+    if (!a || !b || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_winograd: null pointer");
+    if (mode < 0 || mode > 2 || B < 1 || Kc < 1 || Cf < 1 || nh < 1 || nw < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_winograd: bad argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_winograd: out / workspace must be 16-byte aligned");
+    return launch_winograd_s2(mode, a, b, out, B, Kc, Cf, nh, nw, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t ipsr_conv3x3_winograd_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout)

@@ -9,6 +9,9 @@ Three engines per (operation, geometry), chosen by `select()` from measurements 
                                   2.0-2.4x MIOpen's F(2x2,3x3) assembly from 16x16 maps and 128 channels up
   "wino_dil"  csrc/winograd.hip   netG's dilated down convolution Conv2d(k4 s2 p3 d2) and netD's Conv2d(k4 s1 p1) by F(3x3,4x4) —
                                   forward, input and weight gradient, 1.4-2.0x MIOpen at 128..512 channels on 32x32..128x128 inputs
+  "wino_s2"   csrc/winograd.hip   the 4x4 stride-2 pad-1 layers (Conv2d of netP/netD/netF, ConvTranspose2d of netP/netG) by F(5x5,2x2) on
+                                  the polyphase components — forward, input and weight gradient, 5-30 % faster than MIOpen at
+                                  >= 128 / 64 channels on coarse grids of 16..64
   "direct"    csrc/conv_gemm.hip  one-launch implicit GEMM, NCHW in/out (every k3/k4, stride 1/2, dilated and transposed
                                   geometry of the nets, forward and backward-data): at parity with MIOpen (~100 TF), used
                                   where it measured >= 7 % faster
@@ -53,6 +56,10 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil):
     if mode == "auto" and _is_k4s1(k, stride, pad, dil) and op in (ops.CONV_FWD, ops.CONV_BWD_DATA) \
             and cred % 16 == 0 and min(Cin, Cout) >= 128 and 16 <= H <= 128:
         return "wino_dil"        # netD's 4x4 stride-1 convolution: the same F(3x3,4x4) pipeline on the image itself
+    if mode == "auto":
+        g = _s2_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
+        if g is not None and _s2_wins(g) and ops.s2_winograd_supported(_s2_mode(op), B, *g):
+            return "wino_s2"     # 4x4 stride-2 layers: polyphase Winograd F(5x5,2x2)
     # auto: measured rules (MI355X, batch 8; profiles/r02_hipconv_k3.txt, r02_hipconv_all.txt)
     if wino_ok and H * W >= 256 and max(cred, kout) >= 128 and min(cred, kout) >= 64:
         return "winograd"
@@ -63,6 +70,28 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil):
 
 def _is_dilated4(k, stride, pad, dil):
     return k == 4 and stride == 2 and pad == 3 and dil == 2
+
+
+def _s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """(Kc, Cf, nh, nw) of a k4 s2 p1 layer in the coarse / fine terms of ipsr_conv4x4s2_winograd, or None."""
+    if not (k == 4 and stride == 2 and pad == 1 and dil == 1):
+        return None
+    if transposed:
+        return Cin, Cout, H, W
+    if H % 2 or W % 2:
+        return None
+    return Cout, Cin, H // 2, W // 2
+
+
+def _s2_wins(geom):
+    """Measured (profiles/r02_hipconv_k4s2.txt, batch 8): F(5x5,2x2) beats MIOpen by 5-30 % from 128 coarse / 64 fine channels up
+    on coarse grids of 16..64; it loses on 8x8 and below (too few tiles) and on the 64-channel 128x128 layer (transform bound)."""
+    Kc, Cf, nh, nw = geom
+    return Kc >= 128 and Cf >= 64 and 16 <= min(nh, nw) and max(nh, nw) <= 64
+
+
+def _s2_mode(op):
+    return ops.S2_FINE_TO_COARSE if op in (ops.CONV_FWD, ops.CONVT_BWD_DATA) else ops.S2_COARSE_TO_FINE
 
 
 def _is_k4s1(k, stride, pad, dil):
@@ -78,6 +107,10 @@ def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
         return "wino_dil"
     if mode == "auto" and not transposed and _is_k4s1(k, stride, pad, dil) and min(Cin, Cout) >= 128 and 16 <= H <= 128:
         return "wino_dil"
+    if mode == "auto":
+        g = _s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+        if g is not None and _s2_wins(g):
+            return "wino_s2"
     ok = k == 3 and stride == 1 and pad == 1 and dil == 1
     if mode in ("miopen", "direct") or not ok:
         return "miopen"
@@ -103,6 +136,8 @@ class _HipConv(torch.autograd.Function):
             y = ops.conv2d(op, xc, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng_fwd == "wino_dil":
             y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+        elif eng_fwd == "wino_s2":
+            y = ops.conv4x4s2_winograd(_s2_mode(op), xc, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         else:
             y = (F.conv_transpose2d(xc, w, None, stride, pad, 0, 1, dil) if transposed else F.conv2d(xc, w, None, stride, pad, dil))
         ctx.save_for_backward(xc, w)
@@ -125,16 +160,21 @@ class _HipConv(torch.autograd.Function):
                 dx = ops.conv2d(op, dy, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
             elif eng == "wino_dil":
                 dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+            elif eng == "wino_s2":
+                dx = ops.conv4x4s2_winograd(_s2_mode(op), dy, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
                                                          [True, False, False])[0]
         weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil) if ctx.needs_input_grad[1] else None
         # data parallel: write the weight gradient straight into its slice of the armed gradient bucket (dist.py)
-        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil") else None
+        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2") else None
         if weng == "winograd":
             dw = ops.conv3x3_winograd_wrw(transposed, x, dy, Cout, out=sink)
         elif weng == "wino_dil":
             dw = ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, W), Cout, out=sink, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+        elif weng == "wino_s2":
+            fine, coarse = (dy, x) if transposed else (x, dy)
+            dw = ops.conv4x4s2_winograd(ops.S2_WEIGHT_GRAD, fine, coarse, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out=sink)
         elif ctx.needs_input_grad[1]:
             dw = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
                                                      [False, True, False])[1]
@@ -179,6 +219,8 @@ def conv_nobias(m, x, weight=None):
             return ops.conv2d(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng == "wino_dil":
             return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+        elif eng == "wino_s2":
+            return ops.conv4x4s2_winograd(_s2_mode(op), x.contiguous(), w.detach(), B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
     if transposed:
         return F.conv_transpose2d(x, w, None, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
     return F.conv2d(x, w, None, m.stride, m.padding, m.dilation, m.groups)

@@ -456,6 +456,37 @@ def conv4x4_dilated_winograd(mode, a, b, in_shape, Cout, out=None, geom=GEOM_K4_
     return out
 
 
+S2_FINE_TO_COARSE, S2_COARSE_TO_FINE, S2_WEIGHT_GRAD = 0, 1, 2
+
+
+def s2_winograd_supported(mode, B, Kc, Cf, nh, nw):
+    return _lib.lib().ipsr_conv4x4s2_winograd_workspace_bytes(mode, B, Kc, Cf, nh, nw) > 0
+
+
+def conv4x4s2_winograd(mode, a, b, B, Kc, Cf, nh, nw, out=None):
+    """The k4 stride-2 pad-1 layers by Winograd F(5x5,2x2) on the polyphase components (ipsr_conv4x4s2_winograd).
+    fine = [B,Cf,2nh,2nw] (x of Conv2d, y of ConvTranspose2d), coarse = [B,Kc,nh,nw], weight = [Kc,Cf,4,4].
+    mode 0 fine -> coarse (a = fine, b = weight), 1 coarse -> fine (a = coarse, b = weight), 2 weight gradient (a = fine, b = coarse)."""
+    a = _req(a, torch.float32, "operand a")
+    b = _req(b, torch.float32, "operand b")
+    fine, coarse, wsh = (B, Cf, 2 * nh, 2 * nw), (B, Kc, nh, nw), (Kc, Cf, 4, 4)
+    want = {0: (fine, wsh, coarse), 1: (coarse, wsh, fine), 2: (fine, coarse, wsh)}[mode]
+    if tuple(a.shape) != want[0] or tuple(b.shape) != want[1]:
+        raise RuntimeError("conv4x4s2_winograd mode %d: operands %s / %s do not match %s / %s" % (mode, tuple(a.shape), tuple(b.shape), want[0], want[1]))
+    if out is not None and (tuple(out.shape) != tuple(want[2]) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device):
+        raise RuntimeError("conv4x4s2_winograd: `out` must be a contiguous fp32 %s tensor on %s" % (tuple(want[2]), a.device))
+    if out is None:
+        out = torch.empty(want[2], dtype=torch.float32, device=a.device)
+    L = _lib.lib()
+    nbytes = L.ipsr_conv4x4s2_winograd_workspace_bytes(mode, B, Kc, Cf, nh, nw)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv4x4s2_winograd: mode %d Kc=%d Cf=%d %dx%d is not implemented" % (mode, Kc, Cf, nh, nw))
+    ws = _workspace(nbytes, a.device)
+    _lib.check(L.ipsr_conv4x4s2_winograd(mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, Kc, Cf, nh, nw,
+                                         ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv4x4s2_winograd")
+    return out
+
+
 def conv3x3_winograd_wrw(transposed, x, dy, Cout, out=None):
     """Weight gradient of a k3 s1 p1 Conv2d (transposed=False -> [Cout,Cin,3,3]) / ConvTranspose2d (True -> [Cin,Cout,3,3]).
     out: optional contiguous fp32 tensor of that shape to write into (e.g. a slice of a gradient bucket)."""

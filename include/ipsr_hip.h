@@ -258,6 +258,19 @@ size_t ipsr_conv4x4_winograd_workspace_bytes(int geom, int mode, int B, int Cin,
 int ipsr_conv4x4_winograd(int geom, int mode, const float* a, const float* b, float* out, int B, int Cin, int H, int W, int Cout,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* The 4x4 stride-2 pad-1 layers — the down convolutions of netP / netD / netF (Conv2d, models/networks.py:404-432, 470-495,
+ * 510-515) and the up convolutions of netP / netG (ConvTranspose2d, models/networks.py:235-243, 420-428) — by Winograd
+ * F(5x5,2x2) on the polyphase components of the fine grid (2.8x fewer matrix-core flops than the direct form; same 36 GEMMs).
+ * One geometry for both modules: fine = the 2n-grid tensor [B,Cf,2nh,2nw] (x of Conv2d, y of ConvTranspose2d), coarse = the
+ * n-grid tensor [B,Kc,nh,nw]; weight = [Kc][Cf][4][4] (Conv2d [Cout][Cin], ConvTranspose2d [Cin][Cout]).
+ *   mode 0  fine -> coarse   a = fine    b = weight   out = coarse   Conv2d forward / ConvTranspose2d backward-data; Cf % 4 == 0
+ *   mode 1  coarse -> fine   a = coarse  b = weight   out = fine     ConvTranspose2d forward / Conv2d backward-data; Kc % 16 == 0
+ *   mode 2  weight gradient  a = fine    b = coarse   out = dW [Kc][Cf][4][4]
+ * Every element of `out` is written. */
+size_t ipsr_conv4x4s2_winograd_workspace_bytes(int mode, int B, int Kc, int Cf, int nh, int nw);
+int ipsr_conv4x4s2_winograd(int mode, const float* a, const float* b, float* out, int B, int Kc, int Cf, int nh, int nw,
+                            void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
  * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.
@@ -290,7 +303,7 @@ int ipsr_profile_enable_mask(int capacity, unsigned region_mask);   /* bit r = r
 int ipsr_profile_read(float* ms /*[host]*/, int max_n);
 int ipsr_profile_read_region(int region, float* ms /*[host]*/, int max_n);
 /* region 3 = every launch of the Winograd GEMM kernel (csrc/winograd.hip, the convolutions' matrix-core kernel; its ring holds
- * 64 x capacity launches); `work` receives the flop count (2 x 36 x rows x columns x reduction, padded sizes) of each launch. */
+ * 256 x capacity launches); `work` receives the flop count (2 x 36 x rows x columns x reduction, padded sizes) of each launch. */
 int ipsr_profile_read_region_work(int region, float* ms /*[host]*/, double* work /*[host]*/, int max_n);
 
 #ifdef __cplusplus

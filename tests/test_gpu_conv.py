@@ -190,6 +190,40 @@ def test_k4_s1_p1_winograd_f3x3_4x4_vs_fp64(Cin, H, W, Cout, B):
         assert not ops.dilated_winograd_supported(1, B, Cin, H, W, Cout, geom=G1)
 
 
+@pytest.mark.parametrize("Kc,Cf,nh,nw,B", [(32, 16, 8, 8, 2), (128, 64, 16, 16, 2), (16, 32, 5, 7, 3), (64, 64, 1, 1, 4), (48, 20, 11, 6, 1), (256, 128, 32, 32, 1)])
+def test_k4_s2_p1_polyphase_winograd_f5x5_2x2_vs_fp64(Kc, Cf, nh, nw, B):
+    """The 4x4 stride-2 pad-1 layers (Conv2d of netP/netD/netF, ConvTranspose2d of netP/netG; models/networks.py:235-243,
+    404-432) by Winograd F(5x5,2x2) on the polyphase components: all three modes against fp64, read both as a Conv2d
+    (fine = x, coarse = y) and as a ConvTranspose2d (coarse = x, fine = y), on grids that are and are not multiples of the
+    5x5 tile, down to the 1x1 bottleneck."""
+    from deepinpainting_amd import ops
+    g = torch.Generator().manual_seed(Kc * 7 + nh)
+    fine = torch.randn(B, Cf, 2 * nh, 2 * nw, generator=g).cuda()
+    coarse = torch.randn(B, Kc, nh, nw, generator=g).cuda()
+    w = (torch.randn(Kc, Cf, 4, 4, generator=g) * 0.1).cuda()
+    fd, cd, wd = fine.double().cpu().requires_grad_(True), coarse.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True)
+    # as a Conv2d: y = conv(fine, w); as a ConvTranspose2d: y = convT(coarse, w)
+    y64 = F.conv2d(fd, wd, None, 2, 1)
+    dx64, dw64 = torch.autograd.grad(y64, (fd, wd), cd.detach())
+    z64 = F.conv_transpose2d(cd, wd, None, 2, 1)
+    dc64, dwt64 = torch.autograd.grad(z64, (cd, wd), fd.detach())
+    dw = ops.conv4x4s2_winograd(ops.S2_WEIGHT_GRAD, fine, coarse, B, Kc, Cf, nh, nw)
+    assert _rel(dw, dw64) <= 1e-4 and _rel(dw, dwt64) <= 1e-4          # the same tensor in both readings
+    if Cf % 4 == 0:
+        y = ops.conv4x4s2_winograd(ops.S2_FINE_TO_COARSE, fine, w, B, Kc, Cf, nh, nw)
+        assert _rel(y, y64.detach()) <= 1e-4                           # Conv2d forward
+        assert _rel(y, dc64) <= 1e-4                                   # == ConvTranspose2d backward-data of `fine`
+    else:
+        assert not ops.s2_winograd_supported(ops.S2_FINE_TO_COARSE, B, Kc, Cf, nh, nw)
+    if Kc % 16 == 0:
+        z = torch.full((B, Cf, 2 * nh, 2 * nw), float("nan"), device="cuda")      # every element must be overwritten
+        ops.conv4x4s2_winograd(ops.S2_COARSE_TO_FINE, coarse, w, B, Kc, Cf, nh, nw, out=z)
+        assert _rel(z, z64.detach()) <= 1e-4                           # ConvTranspose2d forward
+        assert _rel(z, dx64) <= 1e-4                                   # == Conv2d backward-data of `coarse`
+    else:
+        assert not ops.s2_winograd_supported(ops.S2_COARSE_TO_FINE, B, Kc, Cf, nh, nw)
+
+
 @pytest.mark.parametrize("engine", ["direct", "winograd", "auto"])
 def test_module_path_forward_and_gradients(engine):
     """models/hipconv.py: Conv2d / ConvTranspose2d modules through the dispatcher with one engine forced — output, input
@@ -198,7 +232,8 @@ def test_module_path_forward_and_gradients(engine):
     from deepinpainting_amd.models import hipconv
     torch.manual_seed(3)
     cases = [(nn.Conv2d(128, 128, 4, 2, 3, dilation=2), 32, 32), (nn.Conv2d(64, 128, 3, 1, 1), 16, 16), (nn.ConvTranspose2d(128, 64, 3, 1, 1), 16, 16),
-             (nn.Conv2d(32, 32, 4, 2, 3, dilation=2), 16, 16), (nn.ConvTranspose2d(32, 16, 4, 2, 1), 8, 8), (nn.Conv2d(16, 32, 4, 2, 1), 16, 16)]
+             (nn.Conv2d(32, 32, 4, 2, 3, dilation=2), 16, 16), (nn.ConvTranspose2d(32, 16, 4, 2, 1), 8, 8), (nn.Conv2d(16, 32, 4, 2, 1), 16, 16),
+             (nn.Conv2d(64, 128, 4, 2, 1), 32, 32), (nn.ConvTranspose2d(128, 64, 4, 2, 1), 16, 16), (nn.Conv2d(128, 256, 4, 1, 1), 16, 16)]
     hipconv._FORCE = engine
     try:
         for m, H, W in cases:
@@ -241,7 +276,16 @@ def test_dispatcher_rules_and_refusals():
     assert sel(ops.CONV_FWD, 8, 512, 31, 31, 1, 4, 1, 1, 1) == "miopen"                  # its one-channel head
     assert hipconv.select_wrw(False, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd"
     assert hipconv.select_wrw(False, 8, 128, 128, 128, 128, 3, 1, 1, 1) == "miopen"
-    assert sel(ops.CONV_FWD, 8, 256, 32, 32, 512, 4, 2, 1, 1) == "miopen"
+    # 4x4 stride-2 pad-1: polyphase Winograd from 128 coarse / 64 fine channels up on coarse grids of 16..64
+    assert sel(ops.CONV_FWD, 8, 256, 32, 32, 512, 4, 2, 1, 1) == "wino_s2"               # netP / netF down 256 -> 512 @32 -> 16
+    assert sel(ops.CONV_BWD_DATA, 8, 64, 128, 128, 128, 4, 2, 1, 1) == "wino_s2"         # netD 64 -> 128 @128 -> 64
+    assert sel(ops.CONVT_FWD, 8, 512, 32, 32, 128, 4, 2, 1, 1) == "wino_s2"              # netP up 512 -> 128 @32 -> 64
+    assert sel(ops.CONVT_BWD_DATA, 8, 1024, 16, 16, 256, 4, 2, 1, 1) == "wino_s2"
+    assert hipconv.select_wrw(True, 8, 256, 32, 32, 256, 4, 2, 1, 1) == "wino_s2"
+    assert hipconv.select_wrw(False, 8, 128, 64, 64, 256, 4, 2, 1, 1) == "wino_s2"
+    assert sel(ops.CONVT_FWD, 8, 64, 128, 128, 64, 4, 2, 1, 1) == "miopen"               # 64 channels at 128x128: transform bound
+    assert sel(ops.CONV_FWD, 8, 512, 16, 16, 512, 4, 2, 1, 1) == "miopen"                # 8x8 coarse grid: too few tiles
+    assert sel(ops.CONV_FWD, 8, 3, 256, 256, 64, 4, 2, 1, 1) == "miopen"                 # 3 input channels
     with pytest.raises(NotImplementedError):
         ops.conv2d(ops.CONV_FWD, torch.zeros(1, 3, 8, 8, device="cuda"), torch.zeros(4, 3, 3, 3, device="cuda"), (1, 3, 8, 8), 4, 3, 1, 1, 1)
     with pytest.raises(RuntimeError):

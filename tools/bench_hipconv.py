@@ -69,12 +69,13 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--k3", action="store_true", help="only the 3x3 stride-1 shapes (the Winograd candidates)")
     ap.add_argument("--k4s1", action="store_true", help="only netD's 4x4 stride-1 convolution")
+    ap.add_argument("--k4s2", action="store_true", help="only the 4x4 stride-2 pad-1 layers (polyphase Winograd F(5x5,2x2))")
     args = ap.parse_args()
     B = args.batch
     torch.manual_seed(0)
     print("%-5s %-16s %-14s %-7s | %-4s %9s %9s %7s %7s | %9s %9s  %s" % ("kind", "input", "weight", "s/p/d", "op", "hip ms", "miopen ms", "hip TF", "mio TF", "hip err", "mio err", "use"))
     tot_h = tot_m = tot_best = 0.0
-    for kind, Cin, H, Cout, k, st, pad, dil in ([] if args.k4s1 else QUICK if args.quick else (K3 if args.k3 else SHAPES)):
+    for kind, Cin, H, Cout, k, st, pad, dil in ([] if (args.k4s1 or args.k4s2) else QUICK if args.quick else (K3 if args.k3 else SHAPES)):
         tr = kind == "convT"
         x = torch.randn(B, Cin, H, H, device="cuda")
         w = torch.randn((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device="cuda") * 0.05
@@ -165,6 +166,38 @@ def main():
                     print("dil   %-16s %-14s | %-4s wino %9.4f ms %7.1f TF   miopen %9.4f ms %7.1f TF   |diff| %9.2e  %s" % (
                         "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), name, tw, flops / tw / 1e9, tm, flops / tm / 1e9, err,
                         "WINO" if tw < tm else ""), flush=True)
+    if args.k4s2:
+        print("\n4x4 stride-2 pad-1 (Conv2d of netP/netD/netF, ConvTranspose2d of netP/netG), polyphase Winograd F(5x5,2x2) vs MIOpen:")
+        cb = torch.ops.aten.convolution_backward
+        LAYERS = [("conv", 128, 64, 64), ("conv", 256, 128, 32), ("conv", 512, 256, 16), ("conv", 512, 512, 8), ("conv", 512, 512, 4),
+                  ("convT", 64, 64, 128), ("convT", 128, 128, 64), ("convT", 256, 256, 32), ("convT", 512, 512, 16), ("convT", 256, 64, 64),
+                  ("convT", 512, 128, 32), ("convT", 1024, 256, 16), ("convT", 1024, 512, 8), ("convT", 512, 512, 8)]
+        for kind, Kc, Cf, n in LAYERS:
+            fine = torch.randn(B, Cf, 2 * n, 2 * n, device="cuda")
+            coarse = torch.randn(B, Kc, n, n, device="cuda")
+            w = torch.randn(Kc, Cf, 4, 4, device="cuda") * 0.05
+            flops = 2.0 * B * Kc * Cf * 16 * n * n
+            tr = kind == "convT"
+            if not tr:      # Conv2d: x = fine, dy = coarse
+                cargs = (coarse, fine, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
+                rows = (("fwd", 0, fine, w, lambda: F.conv2d(fine, w, None, 2, 1)),
+                        ("bwdD", 1, coarse, w, lambda: cb(*cargs, [True, False, False])[0]),
+                        ("wrw", 2, fine, coarse, lambda: cb(*cargs, [False, True, False])[1]))
+            else:           # ConvTranspose2d: x = coarse, dy = fine
+                cargs = (fine, coarse, w, None, [2, 2], [1, 1], [1, 1], True, [0, 0], 1)
+                rows = (("fwd", 1, coarse, w, lambda: F.conv_transpose2d(coarse, w, None, 2, 1)),
+                        ("bwdD", 0, fine, w, lambda: cb(*cargs, [True, False, False])[0]),
+                        ("wrw", 2, fine, coarse, lambda: cb(*cargs, [False, True, False])[1]))
+            with torch.no_grad():
+                for name, mode, a_, b_, miof in rows:
+                    if not ops.s2_winograd_supported(mode, B, Kc, Cf, n, n):
+                        continue
+                    hipf = lambda: ops.conv4x4s2_winograd(mode, a_, b_, B, Kc, Cf, n, n)
+                    r1, r2 = hipf(), miof()
+                    err = float((r1 - r2).abs().max() / r2.abs().max())
+                    tw, tm = timed(hipf), timed(miof)
+                    print("k4s2  %-5s Kc=%4d Cf=%4d n=%3d | %-4s wino %9.4f ms %7.1f TF   miopen %9.4f ms %7.1f TF   |diff| %9.2e  %s" % (
+                        kind, Kc, Cf, n, name, tw, flops / tw / 1e9, tm, flops / tm / 1e9, err, "WINO" if tw < tm else ""), flush=True)
     if args.k3 or args.k4s1:
         print("\n4x4 stride-1 pad-1 (netD's fourth convolution), Winograd F(3x3,4x4) vs MIOpen:")
         for Cin, H, Cout in ((256, 32, 512), (128, 64, 256), (512, 16, 512)):

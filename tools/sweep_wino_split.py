@@ -44,7 +44,7 @@ def main():
                 ops.conv3x3_winograd(ops.CONV_FWD, x, w, (B, Cin, H, H), Cout)
             e1.record()
             torch.cuda.synchronize()
-            n = 64 * a.iters
+            n = 256 * a.iters
             ms, work = (ctypes.c_float * n)(), (ctypes.c_double * n)()
             k = lib.ipsr_profile_read_region_work(3, ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(work, ctypes.c_void_p), n)
             lib.ipsr_profile_enable(0)
