@@ -83,6 +83,14 @@ def grad_sink_for(param_data_ptr, shape):
     return v if (v is not None and tuple(v.shape) == tuple(shape)) else None
 
 
+_SLOT_ALIGN = 64        # floats: every parameter's slice of a bucket starts on a 256-byte boundary (the weight-gradient kernels
+                        # that write straight into it store 16-byte vectors)
+
+
+def _slot(p):
+    return (p.numel() + _SLOT_ALIGN - 1) // _SLOT_ALIGN * _SLOT_ALIGN
+
+
 class GradBucketReducer(object):
     """Bucketed, overlapped all-reduce(mean) of the gradients of a fixed set of modules."""
 
@@ -95,11 +103,11 @@ class GradBucketReducer(object):
         cur, cur_n = [], 0
         cap = max(1, bucket_bytes // 4)
         for p in params:
-            if cur and cur_n + p.numel() > cap:
+            if cur and cur_n + _slot(p) > cap:
                 self.buckets.append({"params": cur, "numel": cur_n})
                 cur, cur_n = [], 0
             cur.append(p)
-            cur_n += p.numel()
+            cur_n += _slot(p)
         if cur:
             self.buckets.append({"params": cur, "numel": cur_n})
         self._bucket_of = {}
@@ -123,14 +131,17 @@ class GradBucketReducer(object):
             # publish the bucket slices of parameters that have no gradient yet (a fresh .grad can be produced in place)
             for b in self.buckets:
                 dev = b["params"][0].device
-                if b["flat"] is None or b["flat"].device != dev:
+                fresh = b["flat"] is None or b["flat"].device != dev
+                if fresh:
                     b["flat"] = torch.empty(b["numel"], dtype=torch.float32, device=dev)
+                if fresh:
+                    b["flat"].zero_()                    # the padding between slices is summed too: keep it finite
                 off = 0
                 for p in b["params"]:
                     n = p.numel()
                     if p.grad is None:
                         _GRAD_SINKS[p.data_ptr()] = b["flat"][off:off + n].view_as(p)
-                    off += n
+                    off += _slot(p)
         self._pending = [len(b["params"]) for b in self.buckets]
         self._seen = set()
         self._launched = set()
@@ -158,13 +169,13 @@ class GradBucketReducer(object):
         b = self.buckets[bi]
         dev = b["params"][0].device
         if b["flat"] is None or b["flat"].device != dev:
-            b["flat"] = torch.empty(b["numel"], dtype=torch.float32, device=dev)
+            b["flat"] = torch.zeros(b["numel"], dtype=torch.float32, device=dev)
         flat = b["flat"]
         views, off = [], 0
         for p in b["params"]:
             n = p.numel()
             views.append(flat[off:off + n].view_as(p))
-            off += n
+            off += _slot(p)
         # a parameter whose gradient already LIVES in its bucket slice (a kernel that wrote it there, or .grad left as
         # the view by the previous finish() and accumulated in place) needs no copy; a parameter without a gradient on
         # this rank contributes zeros (another rank may have one: every rank must issue the same collective)

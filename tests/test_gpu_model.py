@@ -321,8 +321,12 @@ def test_trainer_step_on_gpu_all_gradients_and_weights_vs_reference(tmp_path):
     m.set_gt_latent()
     m.optimize_parameters()
     e2 = m.get_current_errors()
-    # second iteration: every weight moved by +-lr, sign flips of ~zero gradients make it chaotic at the percent level
-    np.testing.assert_allclose([e2['G_GAN'], e2['G_L1'], e2['D'], e2['F']], d["errors_iter2"], rtol=0.1)
+    # second iteration: every weight moved by +-lr with the SIGN of its gradient (Adam's first step), so an element whose
+    # gradient is ~0 lands 2*lr away when fp32 noise flips it.  The L1 / D / F errors average that out (measured 1e-3 / 1e-2 /
+    # 1e-4); G_GAN — the relativistic logit difference through the just-updated netD — amplifies it: 4.70 in the reference
+    # run, 4.4-5.4 here across MIOpen solver choices and the Winograd engines (2e-5 relative noise per convolution).
+    np.testing.assert_allclose([e2['G_L1'], e2['D'], e2['F']], d["errors_iter2"][1:], rtol=0.05)
+    np.testing.assert_allclose(e2['G_GAN'], d["errors_iter2"][0], rtol=0.25)
 
 
 def test_trainer_batch8_dropout_runs(tmp_path):
