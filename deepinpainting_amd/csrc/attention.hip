@@ -578,14 +578,12 @@ __global__ void __launch_bounds__(256) attention_stage_kernel(AttnArgs a, int nr
 }
 
 constexpr int AC_MAXT = 1024;   // threads per workgroup: one active column each (columns beyond 1024 loop)
-constexpr int AC_KEEP = 4;      // survivors per column remembered in registers during the single replay
 
 // Compressed attention rows + the survivor CSR, one workgroup per sample.
 //   replay: thread per active column j runs  a = a*wn_l (+ wo_l if jq_l == j)  from an LDS copy of the steps, writes
-//           Ac[l][j] (coalesced over j), counts the entries with |a| >= 1 that survive the LongTensor truncation and
-//           remembers the first AC_KEEP of them (in practice a column has 0 or 1);
+//           Ac[l][j] (coalesced over j) and counts the entries with |a| >= 1 that survive the LongTensor truncation;
 //   scan  : survivor counts over the active columns (ascending j == ascending k) -> offB for EVERY k;
-//   fill  : remembered survivors are written straight out; a column with more than AC_KEEP replays once more.
+//   fill  : a column with survivors replays once more and writes them in ascending l.
 template <bool WITH_INDEX>
 __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __restrict__ wn, const float* __restrict__ wo,
                                                                 const int32_t* __restrict__ jq, const int32_t* __restrict__ mprime,
@@ -617,14 +615,18 @@ __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __r
     int32_t* entB_q = WITH_INDEX ? offB + N + 1 : nullptr;
     float* entB_w = reinterpret_cast<float*>(entB_q + capB);
 
+    int* mq = offj + Mc + 1;                                  // [M] position q of masked step l (survivor entries name it)
+    if (WITH_INDEX) {
+        for (int l = tid; l < M; l += nthr) mq[l] = mpi_at(mpi, l, N);
+        __syncthreads();
+    }
     for (int j0 = 0; j0 < Mce; j0 += nthr) {                 // one pass for Mc <= 1024
         const int j = j0 + tid;
+        // pass 1: the chain itself (mul, conditional add), the compressed row, and the NUMBER of survivors — nothing else rides
+        // on the 256 dependent steps (remembering survivors in registers tripled the per-step cost, and on training features a
+        // dozen columns hold 130-220 of them each, far beyond any register budget)
         float a = 0.0f;
         int cnt = 0;
-        int keep_l[AC_KEEP];
-        float keep_w[AC_KEEP];
-#pragma unroll
-        for (int i = 0; i < AC_KEEP; ++i) { keep_l[i] = 0; keep_w[i] = 0.0f; }
         if (j < Mce) {
 #pragma unroll 8
             for (int l = 0; l < M; ++l) {
@@ -632,15 +634,7 @@ __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __r
                 a = a * s.x;                                            // (:123)
                 a = (__float_as_int(s.z) == j) ? a + s.y : a;           // (:124)
                 acb[(size_t)l * Mc + j] = a;                            // (:125) compressed row l
-                if (WITH_INDEX) {
-                    const float t = truncf(a);
-                    if (t != 0.0f) {
-#pragma unroll
-                        for (int i = 0; i < AC_KEEP; ++i)
-                            if (cnt == i) { keep_l[i] = l; keep_w[i] = t; }
-                        ++cnt;
-                    }
-                }
+                if (WITH_INDEX) cnt += !(fabsf(a) < 1.0f) ? 1 : 0;      // trunc(a) != 0 (NaN counts, as in the LongTensor cast's input)
             }
         }
         if (!WITH_INDEX) continue;
@@ -664,21 +658,16 @@ __global__ void __launch_bounds__(AC_MAXT) attn_compress_kernel(const float* __r
             for (int w = 0; w < nwave; ++w) tot += wave_tot[w];
             offj[Mc] = tot;
         }
+        // pass 2, columns with survivors only: the same chain again (same bits), entries written in ascending l
         if (j < Mce && cnt > 0) {
-            if (cnt <= AC_KEEP) {
-#pragma unroll
-                for (int i = 0; i < AC_KEEP; ++i)
-                    if (i < cnt) { entB_q[off + i] = mpi_at(mpi, keep_l[i], N); entB_w[off + i] = keep_w[i]; }
-            } else {                                          // rare: many survivors in one column -> replay it
-                float a2 = 0.0f;
-                int e = off;
-                for (int l = 0; l < M; ++l) {
-                    const float4 s = step[l];
-                    a2 = a2 * s.x;
-                    a2 = (__float_as_int(s.z) == j) ? a2 + s.y : a2;
-                    const float t = truncf(a2);
-                    if (t != 0.0f) { entB_q[e] = mpi_at(mpi, l, N); entB_w[e] = t; ++e; }
-                }
+            float a2 = 0.0f;
+            int e = off;
+#pragma unroll 8
+            for (int l = 0; l < M; ++l) {
+                const float4 s = step[l];
+                a2 = a2 * s.x;
+                a2 = (__float_as_int(s.z) == j) ? a2 + s.y : a2;
+                if (!(fabsf(a2) < 1.0f)) { entB_q[e] = mq[l]; entB_w[e] = truncf(a2); ++e; }
             }
         }
         __syncthreads();
@@ -846,7 +835,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
     }
     const bool need_index = a.bwd_index != nullptr;
     if (M > 0) {
-        const size_t lds_c = ((size_t)4 * M + Mc + 1) * sizeof(int);
+        const size_t lds_c = ((size_t)4 * M + Mc + 1 + M) * sizeof(int);
         if (lds_c > 150 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_forward: M=%d too large for attn_compress_kernel", M);
         if (lds_c > 48 * 1024) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_compress_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
