@@ -37,9 +37,11 @@ constexpr int WG_BM = 128, WG_BN = 128, WG_BK = 16, WG_NBUF = 4, WG_THREADS = 25
 // (M + (ks*36 + xi) * plane); the output transforms add the slabs of each xi in ascending order (deterministic).
 struct WinoSplit {
     int nsplit, sps, xi_split, nsplit_t, sps_t;
-    __host__ __device__ int slabs() const { return xi_split >= 36 ? nsplit : (xi_split <= 0 ? nsplit_t : (nsplit > nsplit_t ? nsplit : nsplit_t)); }
+    int nxi = 36;           // GEMMs in the launch (36 Winograd points; 1 for the plain GEMMs of the small-map convolutions)
+    __host__ __device__ int slabs() const { return xi_split >= nxi ? nsplit : (xi_split <= 0 ? nsplit_t : (nsplit > nsplit_t ? nsplit : nsplit_t)); }
     __host__ __device__ int of(int xi) const { return xi < xi_split ? nsplit : nsplit_t; }
-    __host__ int workgroups(int tiles_per_xi) const { return tiles_per_xi * (xi_split * nsplit + (36 - xi_split) * nsplit_t); }
+    __host__ __device__ int head_xi() const { return xi_split < nxi ? xi_split : nxi; }
+    __host__ int workgroups(int tiles_per_xi) const { return tiles_per_xi * (head_xi() * nsplit + (nxi - head_xi()) * nsplit_t); }
 };
 
 // m[i][j] = sum over the slabs of GEMM xi = 6i+j of M[slab][xi][off]
@@ -405,7 +407,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
     // head workgroups (the long ones) are dispatched first, the tail's short ones fill the last round; each group is spread
     // over the XCDs on its own
     const int tiles = ktiles * ttiles;
-    const unsigned head = (unsigned)(split.xi_split * tiles * split.nsplit);
+    const unsigned head = (unsigned)(split.head_xi() * tiles * split.nsplit);
     const bool is_tail = blockIdx.x >= head;
     const unsigned L = is_tail ? xcd_remap(blockIdx.x - head, gridDim.x - head) : xcd_remap(blockIdx.x, head);
     const int nsplit = is_tail ? split.nsplit_t : split.nsplit, sps = is_tail ? split.sps_t : split.sps;
@@ -482,7 +484,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
         __builtin_amdgcn_s_barrier();
     }
 
-    float* out = Mo + ((size_t)ks * 36 + xi) * Kp * Tp;
+    float* out = Mo + ((size_t)ks * split.nxi + xi) * Kp * Tp;
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) {
         const int t = t0 + wn * 32 + jn * 64 + r;
@@ -1319,6 +1321,156 @@ int launch_winograd_s2(int mode, const float* a, const float* b2, float* out, in
     return check_launch("wino_wrw_output2_kernel");
 }
 
+// ===================================================================================================
+// Small maps.  The inner levels of both U-Nets and netF (512-1024 channels on 8x8 ... 1x1: models/networks.py:220-259, 404-432,
+// 510-515) are ~85 convolution calls per training step whose arithmetic is a skinny GEMM over a 9-33 MB weight tensor: MIOpen
+// spends 45-150 us on each (layout transposes, zero fills, a tile shape made for large maps).  Here the weight tensor is the
+// GEMM operand AS IT LIES IN MEMORY — no packing, no transform — and the handful of activations is rearranged instead:
+//   DATA  (Conv2d backward-data, ConvTranspose2d forward):   W = [R][(Cq,t)] is reduction-major already
+//           Mcol[(cq,t)][n] = sum_r W[r][(cq,t)] * in[r][n]          wino_gemm_kernel with one "point": U = W, V = in as [R][n]
+//           out[b][cq][f]   = sum over the (o,t) with f = o*stride - pad + t*dil of Mcol[(cq,t)][(b,o)]      (col2im)
+//   WRW   (weight gradient of either):  dW[a][(cq,t)] = sum_n coarse[a][n] * col(fine)[(cq,t)][n]
+//           U = coarse as [n][a], V = im2col(fine) as [n][(cq,t)], reduction over the B*Ho*Wo <= 512 positions: the GEMM's output
+//           IS dW in its native layout (written once, no second pass).
+// n = (b, oy, ox) runs over the COARSE grid (the conv's output side); "fine" is the conv's input side.
+__global__ void __launch_bounds__(256) sm_to_cn_kernel(const float* __restrict__ x, int B, int C, int HW, int Tp, float* __restrict__ out)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (n >= Tp) return;
+    float v = 0.0f;
+    if (n < B * HW) { const int b = n / HW, p = n - b * HW; v = x[((size_t)b * C + c) * HW + p]; }
+    out[(size_t)c * Tp + n] = v;
+}
+
+__global__ void __launch_bounds__(256) sm_to_nc_kernel(const float* __restrict__ x, int B, int C, int HW, float* __restrict__ out)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;              // rows n >= B*HW are zero padding of the reduction
+    if (c >= C) return;
+    float v = 0.0f;
+    if (n < B * HW) { const int b = n / HW, p = n - b * HW; v = x[((size_t)b * C + c) * HW + p]; }
+    out[(size_t)n * C + c] = v;
+}
+
+// V[n][(c,t)] = fine[b][c][oy*s - pad + r*dil][ox*s - pad + q*dil]  (0 outside; rows n >= B*Ho*Wo zero)
+__global__ void __launch_bounds__(256) sm_im2col_nt_kernel(const float* __restrict__ f, int B, int C, int Hf, int Wf, int Ho, int Wo,
+                                                           int k, int st, int pad, int dil, float* __restrict__ out)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    const int kk = k * k, ncol = C * kk;
+    if (col >= ncol) return;
+    float v = 0.0f;
+    if (n < B * Ho * Wo) {
+        const int c = col / kk, t = col - c * kk, r = t / k, q = t - r * k;
+        const int b = n / (Ho * Wo), o = n - b * Ho * Wo, oy = o / Wo, ox = o - oy * Wo;
+        const int fy = oy * st - pad + r * dil, fx = ox * st - pad + q * dil;
+        if ((unsigned)fy < (unsigned)Hf && (unsigned)fx < (unsigned)Wf) v = f[(((size_t)b * C + c) * Hf + fy) * Wf + fx];
+    }
+    out[(size_t)n * ncol + col] = v;
+}
+
+// out[b][c][fy][fx] = sum_{slabs} sum_{(r,q): fy = oy*s - pad + r*dil, fx = ox*s - pad + q*dil} M[(c,t)][(b,oy,ox)]
+__global__ void __launch_bounds__(256) sm_col2im_kernel(const float* __restrict__ M, int nslab, size_t slab_stride, int B, int C, int Hf, int Wf,
+                                                        int Ho, int Wo, int k, int st, int pad, int dil, int Tp, float* __restrict__ out)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)B * C * Hf * Wf;
+    if (idx >= total) return;
+    const int fx = (int)(idx % Wf), fy = (int)((idx / Wf) % Hf), c = (int)((idx / ((size_t)Wf * Hf)) % C), b = (int)(idx / ((size_t)Wf * Hf * C));
+    float acc = 0.0f;
+    for (int r = 0; r < k; ++r) {
+        const int ny = fy + pad - r * dil;
+        if (ny < 0 || ny % st) continue;
+        const int oy = ny / st;
+        if (oy >= Ho) continue;
+        for (int q = 0; q < k; ++q) {
+            const int nx = fx + pad - q * dil;
+            if (nx < 0 || nx % st) continue;
+            const int ox = nx / st;
+            if (ox >= Wo) continue;
+            const size_t off = (size_t)(c * k * k + r * k + q) * Tp + ((size_t)b * Ho + oy) * Wo + ox;
+            for (int sl = 0; sl < nslab; ++sl) acc += M[(size_t)sl * slab_stride + off];
+        }
+    }
+    out[idx] = acc;
+}
+
+struct SmPlan { int P, Tp, Rp, Kp, ncol; WinoSplit sp; size_t a_floats, b_floats, m_floats, total_bytes; };
+
+// op 0 (DATA): in [B][R][Ho][Wo], W [R][Cq][k][k] -> out [B][Cq][Hf][Wf].   op 1 (WRW): coarse [B][R][Ho][Wo], fine [B][Cq][Hf][Wf]
+// -> dW [R][Cq][k][k]  (R = the weight's first channel dimension in both).
+static int sm_plan(int op, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf, int k, int st, int pad, int dil, SmPlan* p)
+{
+    if (op < 0 || op > 1) return fail(IPSR_ERR_INVALID, "small-map convolution: op %d", op);
+    if (k < 1 || k > 4 || st < 1 || st > 2 || dil < 1 || pad < 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: k%d s%d p%d d%d", k, st, pad, dil);
+    if (Ho != (Hf + 2 * pad - dil * (k - 1) - 1) / st + 1 || Wo != (Wf + 2 * pad - dil * (k - 1) - 1) / st + 1)
+        return fail(IPSR_ERR_INVALID, "small-map convolution: %dx%d is not the output grid of %dx%d under k%d s%d p%d d%d", Ho, Wo, Hf, Wf, k, st, pad, dil);
+    p->P = B * Ho * Wo;
+    p->ncol = Cq * k * k;
+    if (p->ncol % WG_BN != 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d x %d taps is not a multiple of %d", Cq, k * k, WG_BN);
+    if (p->P > 1024) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d output positions (made for <= 1024)", p->P);
+    if (op == 0) {
+        if (R % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d reduction channels are not a multiple of %d", R, WG_BK);
+        p->Tp = (p->P + WG_BN - 1) / WG_BN * WG_BN;
+        p->Kp = p->ncol; p->Rp = R;
+        const int tiles = (p->Kp / WG_BM) * (p->Tp / WG_BN), stages = R / WG_BK;
+        int ns = std::max(1, std::min(stages / 8, 384 / std::max(tiles, 1)));
+        const int per = cdiv(stages, ns);
+        ns = cdiv(stages, per);
+        p->sp = WinoSplit{ns, per, 1, ns, per, 1};
+        p->a_floats = 0;
+        p->b_floats = (size_t)R * p->Tp;
+        p->m_floats = (size_t)ns * p->Kp * p->Tp;
+    } else {
+        if (R % WG_BM != 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d weight rows are not a multiple of %d", R, WG_BM);
+        p->Rp = (p->P + WG_BK - 1) / WG_BK * WG_BK;
+        p->Kp = R; p->Tp = p->ncol;
+        p->sp = WinoSplit{1, p->Rp / WG_BK, 1, 1, p->Rp / WG_BK, 1};
+        p->a_floats = (size_t)p->Rp * R;
+        p->b_floats = (size_t)p->Rp * p->ncol;
+        p->m_floats = 0;
+    }
+    p->total_bytes = align_up(p->a_floats * 4, 256) + align_up(p->b_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
+    return IPSR_OK;
+}
+
+size_t smallmap_ws_bytes(int op, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf, int k, int st, int pad, int dil)
+{
+    SmPlan p;
+    if (sm_plan(op, B, R, Cq, Ho, Wo, Hf, Wf, k, st, pad, dil, &p) != IPSR_OK) return 0;
+    return p.total_bytes;
+}
+
+int launch_smallmap(int op, const float* a, const float* b2, float* out, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf,
+                    int k, int st_, int pad, int dil, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    SmPlan p;
+    if (int rc = sm_plan(op, B, R, Cq, Ho, Wo, Hf, Wf, k, st_, pad, dil, &p)) return rc;
+    if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "small-map convolution: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    Carver cv(ws, ws_bytes);
+    float* A = cv.take<float>(p.a_floats);
+    float* Bv = cv.take<float>(p.b_floats);
+    float* Mo = cv.take<float>(p.m_floats);
+    const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
+    if (op == 0) {
+        sm_to_cn_kernel<<<dim3(cdiv(p.Tp, 256), R), 256, 0, st>>>(a, B, R, Ho * Wo, p.Tp, Bv);
+        if (int rc = check_launch("sm_to_cn_kernel")) return rc;
+        profile_mark_start(st, 3);
+        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(b2, Bv, R, p.Kp, p.Tp, kt, tt, p.sp, Mo);
+        profile_mark_stop(st, 3, 2.0 * R * p.Kp * p.Tp);
+        if (int rc = check_launch("wino_gemm_kernel")) return rc;
+        const size_t total = (size_t)B * Cq * Hf * Wf;
+        sm_col2im_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Mo, p.sp.nsplit, (size_t)p.Kp * p.Tp, B, Cq, Hf, Wf, Ho, Wo, k, st_, pad, dil, p.Tp, out);
+        return check_launch("sm_col2im_kernel");
+    }
+    sm_to_nc_kernel<<<dim3(cdiv(R, 256), p.Rp), 256, 0, st>>>(a, B, R, Ho * Wo, A);
+    sm_im2col_nt_kernel<<<dim3(cdiv(p.ncol, 256), p.Rp), 256, 0, st>>>(b2, B, Cq, Hf, Wf, Ho, Wo, k, st_, pad, dil, Bv);
+    if (int rc = check_launch("sm_im2col_nt_kernel")) return rc;
+    profile_mark_start(st, 3);
+    wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, p.Rp, p.Kp, p.Tp, kt, tt, p.sp, out);
+    profile_mark_stop(st, 3, 2.0 * p.Rp * p.Kp * p.Tp);
+    return check_launch("wino_gemm_kernel");
+}
+
 }  // namespace ipsr
 
 using namespace ipsr;
@@ -1419,6 +1571,23 @@ int ipsr_conv4x4s2_winograd(int mode, const float* a, const float* b, float* out
     if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
         return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_winograd: out / workspace must be 16-byte aligned");
     return launch_winograd_s2(mode, a, b, out, B, Kc, Cf, nh, nw, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t ipsr_conv_smallmap_workspace_bytes(int op, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf, int k, int stride, int pad, int dil)
+{
+    if (B < 1 || R < 1 || Cq < 1 || Ho < 1 || Wo < 1 || Hf < 1 || Wf < 1) return 0;
+    return smallmap_ws_bytes(op, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil);
+}
+
+int ipsr_conv_smallmap(int op, const float* a, const float* b, float* out, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf,
+                       int k, int stride, int pad, int dil, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!a || !b || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv_smallmap: null pointer");
+    if (B < 1 || R < 1 || Cq < 1 || Ho < 1 || Wo < 1 || Hf < 1 || Wf < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv_smallmap: bad argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u) || (reinterpret_cast<uintptr_t>(a) & 15u) ||
+        (reinterpret_cast<uintptr_t>(b) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv_smallmap: operands / workspace must be 16-byte aligned");
+    return launch_smallmap(op, a, b, out, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t ipsr_conv3x3_winograd_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout)

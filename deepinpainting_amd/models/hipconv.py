@@ -12,6 +12,8 @@ Three engines per (operation, geometry), chosen by `select()` from measurements 
   "wino_s2"   csrc/winograd.hip   the 4x4 stride-2 pad-1 layers (Conv2d of netP/netD/netF, ConvTranspose2d of netP/netG) by F(5x5,2x2) on
                                   the polyphase components — forward, input and weight gradient, 5-30 % faster than MIOpen at
                                   >= 128 / 64 channels on coarse grids of 16..64
+  "smallmap"  csrc/winograd.hip   weight gradients of the 4x4 stride-2 layers on the innermost levels (<= 256 positions per batch): one GEMM
+                                  over the positions that writes dW in its native layout
   "direct"    csrc/conv_gemm.hip  one-launch implicit GEMM, NCHW in/out (every k3/k4, stride 1/2, dilated and transposed
                                   geometry of the nets, forward and backward-data): at parity with MIOpen (~100 TF), used
                                   where it measured >= 7 % faster
@@ -94,6 +96,25 @@ def _s2_mode(op):
     return ops.S2_FINE_TO_COARSE if op in (ops.CONV_FWD, ops.CONVT_BWD_DATA) else ops.S2_COARSE_TO_FINE
 
 
+def _smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """(B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil) of ipsr_conv_smallmap for this module call: R / (Ho, Wo) = the weight's first
+    channel dimension and its grid, Cq / (Hf, Wf) = the second."""
+    if transposed:
+        Hy, Wy = (H - 1) * stride - 2 * pad + dil * (k - 1) + 1, (W - 1) * stride - 2 * pad + dil * (k - 1) + 1
+        return B, Cin, Cout, H, W, Hy, Wy, k, stride, pad, dil
+    Hy, Wy = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    return B, Cout, Cin, Hy, Wy, H, W, k, stride, pad, dil
+
+
+def _smallmap_wrw_wins(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """Weight gradients of the 4x4 layers on grids of <= 256 positions per batch (the four innermost levels at batch 8): the GEMM
+    writes dW in place, 27-39 us against MIOpen's 41-57 (profiles/r02_hipconv_small.txt)."""
+    if k != 4 or stride != 2 or os.environ.get("IPSR_NO_SMALLMAP", "0") == "1":        # the switch is for A/B timing
+        return False
+    g = _smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+    return g[3] >= 1 and g[4] >= 1 and g[0] * g[3] * g[4] <= 256 and min(Cin, Cout) >= 256 and ops.smallmap_supported(ops.SM_WRW, *g)
+
+
 def _is_k4s1(k, stride, pad, dil):
     return k == 4 and stride == 1 and pad == 1 and dil == 1
 
@@ -111,6 +132,8 @@ def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
         g = _s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
         if g is not None and _s2_wins(g):
             return "wino_s2"
+    if mode == "auto" and _smallmap_wrw_wins(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
+        return "smallmap"
     ok = k == 3 and stride == 1 and pad == 1 and dil == 1
     if mode in ("miopen", "direct") or not ok:
         return "miopen"
@@ -167,11 +190,14 @@ class _HipConv(torch.autograd.Function):
                                                          [True, False, False])[0]
         weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil) if ctx.needs_input_grad[1] else None
         # data parallel: write the weight gradient straight into its slice of the armed gradient bucket (dist.py)
-        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2") else None
+        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2", "smallmap") else None
         if weng == "winograd":
             dw = ops.conv3x3_winograd_wrw(transposed, x, dy, Cout, out=sink)
         elif weng == "wino_dil":
             dw = ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, W), Cout, out=sink, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+        elif weng == "smallmap":
+            coarse, fine = (x, dy) if transposed else (dy, x)
+            dw = ops.conv_smallmap(ops.SM_WRW, coarse, fine, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out=sink)
         elif weng == "wino_s2":
             fine, coarse = (dy, x) if transposed else (x, dy)
             dw = ops.conv4x4s2_winograd(ops.S2_WEIGHT_GRAD, fine, coarse, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out=sink)

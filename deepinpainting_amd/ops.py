@@ -487,6 +487,37 @@ def conv4x4s2_winograd(mode, a, b, B, Kc, Cf, nh, nw, out=None):
     return out
 
 
+SM_DATA, SM_WRW = 0, 1
+
+
+def smallmap_supported(op, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil):
+    return _lib.lib().ipsr_conv_smallmap_workspace_bytes(op, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil) > 0
+
+
+def conv_smallmap(op, a, b, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil, out=None):
+    """Small-map convolutions with the weight tensor [R,Cq,k,k] as the GEMM operand in place (ipsr_conv_smallmap):
+    op SM_DATA: a = in [B,R,Ho,Wo], b = weight -> [B,Cq,Hf,Wf] (Conv2d backward-data / ConvTranspose2d forward);
+    op SM_WRW:  a = coarse [B,R,Ho,Wo], b = fine [B,Cq,Hf,Wf] -> dW [R,Cq,k,k]."""
+    a = _req(a, torch.float32, "operand a")
+    b = _req(b, torch.float32, "operand b")
+    coarse, fine, wsh = (B, R, Ho, Wo), (B, Cq, Hf, Wf), (R, Cq, k, k)
+    want = {SM_DATA: (coarse, wsh, fine), SM_WRW: (coarse, fine, wsh)}[op]
+    if tuple(a.shape) != want[0] or tuple(b.shape) != want[1]:
+        raise RuntimeError("conv_smallmap op %d: operands %s / %s do not match %s / %s" % (op, tuple(a.shape), tuple(b.shape), want[0], want[1]))
+    if out is not None and (tuple(out.shape) != tuple(want[2]) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device):
+        raise RuntimeError("conv_smallmap: `out` must be a contiguous fp32 %s tensor on %s" % (tuple(want[2]), a.device))
+    if out is None:
+        out = torch.empty(want[2], dtype=torch.float32, device=a.device)
+    L = _lib.lib()
+    nbytes = L.ipsr_conv_smallmap_workspace_bytes(op, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv_smallmap: op %d R=%d Cq=%d %dx%d -> %dx%d k%d s%d p%d d%d is not implemented" % (op, R, Cq, Hf, Wf, Ho, Wo, k, stride, pad, dil))
+    ws = _workspace(nbytes, a.device)
+    _lib.check(L.ipsr_conv_smallmap(op, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil,
+                                    ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv_smallmap")
+    return out
+
+
 def conv3x3_winograd_wrw(transposed, x, dy, Cout, out=None):
     """Weight gradient of a k3 s1 p1 Conv2d (transposed=False -> [Cout,Cin,3,3]) / ConvTranspose2d (True -> [Cin,Cout,3,3]).
     out: optional contiguous fp32 tensor of that shape to write into (e.g. a slice of a gradient bucket)."""

@@ -271,6 +271,17 @@ size_t ipsr_conv4x4s2_winograd_workspace_bytes(int mode, int B, int Kc, int Cf, 
 int ipsr_conv4x4s2_winograd(int mode, const float* a, const float* b, float* out, int B, int Kc, int Cf, int nh, int nw,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* Small maps: the inner levels of the U-Nets and netF (512-1024 channels on 8x8 ... 1x1; models/networks.py:220-259, 404-432,
+ * 510-515).  The weight tensor [R][Cq][k][k] (Conv2d: [Cout][Cin], ConvTranspose2d: [Cin][Cout]) is the GEMM operand as it lies
+ * in memory; (k, stride, pad, dil) are the module's own parameters, Hf x Wf the grid on the weight's SECOND-channel side
+ * (Conv2d input / ConvTranspose2d output), Ho x Wo the grid on its first-channel side.
+ *   op 0  a = in [B,R,Ho,Wo]       b = weight        out = [B,Cq,Hf,Wf]    Conv2d backward-data / ConvTranspose2d forward
+ *   op 1  a = coarse [B,R,Ho,Wo]   b = fine [B,Cq,Hf,Wf]   out = dW [R,Cq,k,k]   weight gradient of either module
+ * R % 16 == 0 (op 0) / R % 128 == 0 (op 1), Cq*k*k % 128 == 0, B*Ho*Wo <= 1024. */
+size_t ipsr_conv_smallmap_workspace_bytes(int op, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf, int k, int stride, int pad, int dil);
+int ipsr_conv_smallmap(int op, const float* a, const float* b, float* out, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf,
+                       int k, int stride, int pad, int dil, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
  * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.

@@ -224,6 +224,37 @@ def test_k4_s2_p1_polyphase_winograd_f5x5_2x2_vs_fp64(Kc, Cf, nh, nw, B):
         assert not ops.s2_winograd_supported(ops.S2_COARSE_TO_FINE, B, Kc, Cf, nh, nw)
 
 
+@pytest.mark.parametrize("kind,Ci,Co,H,W,k,st,pad,dil,B", [
+    ("conv", 128, 128, 8, 8, 4, 2, 1, 1, 3), ("conv", 128, 256, 4, 6, 3, 1, 1, 1, 2), ("conv", 128, 256, 8, 8, 4, 2, 3, 2, 2), ("conv", 128, 128, 2, 2, 4, 2, 1, 1, 8),
+    ("convT", 128, 64, 4, 4, 4, 2, 1, 1, 2), ("convT", 256, 128, 1, 1, 4, 2, 1, 1, 8), ("convT", 128, 128, 5, 3, 3, 1, 1, 1, 2), ("convT", 256, 32, 8, 8, 4, 2, 1, 1, 1)])
+def test_smallmap_engine_vs_fp64(kind, Ci, Co, H, W, k, st, pad, dil, B):
+    """ipsr_conv_smallmap: the inner levels of the U-Nets / netF (models/networks.py:220-259, 404-432, 510-515) — input gradient of
+    a Conv2d, forward of a ConvTranspose2d and the weight gradient of either, with the weight tensor read in place as the GEMM
+    operand: within 2e-5 of fp64 on 1x1 ... 8x8 grids, k3 / k4, stride 1 / 2, dilated."""
+    from deepinpainting_amd import ops
+    g = torch.Generator().manual_seed(Ci + 3 * H + k)
+    tr = kind == "convT"
+    x = torch.randn(B, Ci, H, W, generator=g).cuda()
+    w = (torch.randn((Ci, Co, k, k) if tr else (Co, Ci, k, k), generator=g) * 0.1).cuda()
+    xd, wd = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True)
+    y64 = F.conv_transpose2d(xd, wd, None, st, pad, 0, 1, dil) if tr else F.conv2d(xd, wd, None, st, pad, dil)
+    dy = torch.randn(y64.shape, generator=g).cuda()
+    dx64, dw64 = torch.autograd.grad(y64, (xd, wd), dy.double().cpu())
+    Hy, Wy = y64.shape[2:]
+    if tr:       # weight [Ci][Co]: R = Ci on the x grid (Ho x Wo), Cq = Co on the y grid (Hf x Wf)
+        geo = (B, Ci, Co, H, W, Hy, Wy, k, st, pad, dil)
+        y = ops.conv_smallmap(ops.SM_DATA, x, w, *geo)
+        assert _rel(y, y64.detach()) <= 2e-5
+        dw = ops.conv_smallmap(ops.SM_WRW, x, dy, *geo)
+    else:        # weight [Co][Ci]: R = Co on the y grid, Cq = Ci on the x grid
+        geo = (B, Co, Ci, Hy, Wy, H, W, k, st, pad, dil)
+        dx = torch.full((B, Ci, H, W), float("nan"), device="cuda")
+        ops.conv_smallmap(ops.SM_DATA, dy, w, *geo, out=dx)
+        assert _rel(dx, dx64) <= 2e-5
+        dw = ops.conv_smallmap(ops.SM_WRW, dy, x, *geo)
+    assert tuple(dw.shape) == tuple(w.shape) and _rel(dw, dw64) <= 2e-5
+
+
 @pytest.mark.parametrize("engine", ["direct", "winograd", "auto"])
 def test_module_path_forward_and_gradients(engine):
     """models/hipconv.py: Conv2d / ConvTranspose2d modules through the dispatcher with one engine forced — output, input
@@ -233,7 +264,8 @@ def test_module_path_forward_and_gradients(engine):
     torch.manual_seed(3)
     cases = [(nn.Conv2d(128, 128, 4, 2, 3, dilation=2), 32, 32), (nn.Conv2d(64, 128, 3, 1, 1), 16, 16), (nn.ConvTranspose2d(128, 64, 3, 1, 1), 16, 16),
              (nn.Conv2d(32, 32, 4, 2, 3, dilation=2), 16, 16), (nn.ConvTranspose2d(32, 16, 4, 2, 1), 8, 8), (nn.Conv2d(16, 32, 4, 2, 1), 16, 16),
-             (nn.Conv2d(64, 128, 4, 2, 1), 32, 32), (nn.ConvTranspose2d(128, 64, 4, 2, 1), 16, 16), (nn.Conv2d(128, 256, 4, 1, 1), 16, 16)]
+             (nn.Conv2d(64, 128, 4, 2, 1), 32, 32), (nn.ConvTranspose2d(128, 64, 4, 2, 1), 16, 16), (nn.Conv2d(128, 256, 4, 1, 1), 16, 16),
+             (nn.Conv2d(256, 256, 4, 2, 1), 4, 4), (nn.ConvTranspose2d(256, 256, 4, 2, 1), 2, 2)]
     hipconv._FORCE = engine
     try:
         for m, H, W in cases:
@@ -286,6 +318,12 @@ def test_dispatcher_rules_and_refusals():
     assert sel(ops.CONVT_FWD, 8, 64, 128, 128, 64, 4, 2, 1, 1) == "miopen"               # 64 channels at 128x128: transform bound
     assert sel(ops.CONV_FWD, 8, 512, 16, 16, 512, 4, 2, 1, 1) == "miopen"                # 8x8 coarse grid: too few tiles
     assert sel(ops.CONV_FWD, 8, 3, 256, 256, 64, 4, 2, 1, 1) == "miopen"                 # 3 input channels
+    # innermost levels: the weight gradient of the 4x4 stride-2 layers as one GEMM that writes dW in place
+    assert hipconv.select_wrw(False, 8, 512, 8, 8, 512, 4, 2, 1, 1) == "smallmap"        # netP down 512 -> 512 @8 -> 4
+    assert hipconv.select_wrw(True, 8, 1024, 4, 4, 512, 4, 2, 1, 1) == "smallmap"        # netP up 1024 -> 512 @4 -> 8
+    assert hipconv.select_wrw(False, 8, 512, 8, 8, 512, 4, 2, 3, 2) == "smallmap"        # netG dilated down @8 -> 4
+    assert hipconv.select_wrw(True, 8, 512, 8, 8, 512, 4, 2, 1, 1) == "miopen"           # 512 positions: no gain measured
+    assert hipconv.select_wrw(False, 8, 512, 4, 4, 512, 3, 1, 1, 1) == "miopen"          # 3x3: MIOpen ties or wins
     with pytest.raises(NotImplementedError):
         ops.conv2d(ops.CONV_FWD, torch.zeros(1, 3, 8, 8, device="cuda"), torch.zeros(4, 3, 3, 3, device="cuda"), (1, 3, 8, 8), 4, 3, 1, 1, 1)
     with pytest.raises(RuntimeError):

@@ -69,13 +69,14 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--k3", action="store_true", help="only the 3x3 stride-1 shapes (the Winograd candidates)")
     ap.add_argument("--k4s1", action="store_true", help="only netD's 4x4 stride-1 convolution")
+    ap.add_argument("--small", action="store_true", help="only the small-map layers (inner U-Net levels, netF) on ipsr_conv_smallmap")
     ap.add_argument("--k4s2", action="store_true", help="only the 4x4 stride-2 pad-1 layers (polyphase Winograd F(5x5,2x2))")
     args = ap.parse_args()
     B = args.batch
     torch.manual_seed(0)
     print("%-5s %-16s %-14s %-7s | %-4s %9s %9s %7s %7s | %9s %9s  %s" % ("kind", "input", "weight", "s/p/d", "op", "hip ms", "miopen ms", "hip TF", "mio TF", "hip err", "mio err", "use"))
     tot_h = tot_m = tot_best = 0.0
-    for kind, Cin, H, Cout, k, st, pad, dil in ([] if (args.k4s1 or args.k4s2) else QUICK if args.quick else (K3 if args.k3 else SHAPES)):
+    for kind, Cin, H, Cout, k, st, pad, dil in ([] if (args.k4s1 or args.k4s2 or args.small) else QUICK if args.quick else (K3 if args.k3 else SHAPES)):
         tr = kind == "convT"
         x = torch.randn(B, Cin, H, H, device="cuda")
         w = torch.randn((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device="cuda") * 0.05
@@ -166,6 +167,43 @@ def main():
                     print("dil   %-16s %-14s | %-4s wino %9.4f ms %7.1f TF   miopen %9.4f ms %7.1f TF   |diff| %9.2e  %s" % (
                         "%dx%dx%dx%d" % (B, Cin, H, H), "x".join(map(str, w.shape)), name, tw, flops / tw / 1e9, tm, flops / tm / 1e9, err,
                         "WINO" if tw < tm else ""), flush=True)
+    if args.small:
+        print("\nsmall maps (inner U-Net levels, netF): ipsr_conv_smallmap vs MIOpen")
+        cb = torch.ops.aten.convolution_backward
+        SMALL = [("conv", 512, 512, 8, 3, 1, 1, 1), ("conv", 512, 512, 4, 3, 1, 1, 1), ("conv", 512, 512, 2, 3, 1, 1, 1),
+                 ("conv", 512, 512, 16, 4, 2, 3, 2), ("conv", 512, 512, 8, 4, 2, 3, 2), ("conv", 512, 512, 4, 4, 2, 3, 2), ("conv", 512, 512, 2, 4, 2, 3, 2),
+                 ("conv", 512, 512, 16, 4, 2, 1, 1), ("conv", 512, 512, 8, 4, 2, 1, 1), ("conv", 512, 512, 4, 4, 2, 1, 1), ("conv", 512, 512, 2, 4, 2, 1, 1),
+                 ("convT", 1024, 512, 8, 3, 1, 1, 1), ("convT", 1024, 512, 4, 3, 1, 1, 1), ("convT", 1024, 512, 2, 3, 1, 1, 1),
+                 ("convT", 512, 512, 1, 4, 2, 1, 1), ("convT", 512, 512, 2, 4, 2, 1, 1), ("convT", 512, 512, 4, 4, 2, 1, 1), ("convT", 512, 512, 8, 4, 2, 1, 1),
+                 ("convT", 1024, 512, 2, 4, 2, 1, 1), ("convT", 1024, 512, 4, 4, 2, 1, 1), ("convT", 1024, 512, 8, 4, 2, 1, 1)]
+        tot_h = tot_m = 0.0
+        for kind, Ci, Co, H, k, st, pad, dil in SMALL:
+            tr = kind == "convT"
+            x = torch.randn(B, Ci, H, H, device="cuda")
+            w = torch.randn((Ci, Co, k, k) if tr else (Co, Ci, k, k), device="cuda") * 0.05
+            with torch.no_grad():
+                y0 = F.conv_transpose2d(x, w, None, st, pad, 0, 1, dil) if tr else F.conv2d(x, w, None, st, pad, dil)
+            Hy = y0.shape[2]
+            dy = torch.randn_like(y0)
+            cargs = (dy, x, w, None, [st, st], [pad, pad], [dil, dil], tr, [0, 0], 1)
+            flops = 2.0 * B * Ci * Co * k * k * (H * H if tr else Hy * Hy)
+            if tr:
+                geo = (B, Ci, Co, H, H, Hy, Hy, k, st, pad, dil)
+                rows = (("fwd", lambda: ops.conv_smallmap(ops.SM_DATA, x, w, *geo), lambda: F.conv_transpose2d(x, w, None, st, pad, 0, 1, dil)),
+                        ("wrw", lambda: ops.conv_smallmap(ops.SM_WRW, x, dy, *geo), lambda: cb(*cargs, [False, True, False])[1]))
+            else:
+                geo = (B, Co, Ci, Hy, Hy, H, H, k, st, pad, dil)
+                rows = (("bwdD", lambda: ops.conv_smallmap(ops.SM_DATA, dy, w, *geo), lambda: cb(*cargs, [True, False, False])[0]),
+                        ("wrw", lambda: ops.conv_smallmap(ops.SM_WRW, dy, x, *geo), lambda: cb(*cargs, [False, True, False])[1]))
+            with torch.no_grad():
+                for name, hipf, miof in rows:
+                    r1, r2 = hipf(), miof()
+                    err = float((r1 - r2).abs().max() / r2.abs().max())
+                    tw, tm = timed(hipf), timed(miof)
+                    tot_h += tw; tot_m += tm
+                    print("small %-5s %4d->%4d @%2d k%d s%d p%d d%d | %-4s here %9.4f ms %6.1f TF   miopen %9.4f ms %6.1f TF   |diff| %9.2e  %s" % (
+                        kind, Ci, Co, H, k, st, pad, dil, name, tw, flops / tw / 1e9, tm, flops / tm / 1e9, err, "HERE" if tw < tm else ""), flush=True)
+        print("small-map total (one call each): here %.3f ms, miopen %.3f ms" % (tot_h, tot_m))
     if args.k4s2:
         print("\n4x4 stride-2 pad-1 (Conv2d of netP/netD/netF, ConvTranspose2d of netP/netG), polyphase Winograd F(5x5,2x2) vs MIOpen:")
         cb = torch.ops.aten.convolution_backward
