@@ -1323,16 +1323,21 @@ int launch_winograd_s2(int mode, const float* a, const float* b2, float* out, in
 
 // ===================================================================================================
 // Small maps.  The inner levels of both U-Nets and netF (512-1024 channels on 8x8 ... 1x1: models/networks.py:220-259, 404-432,
-// 510-515) are ~85 convolution calls per training step whose arithmetic is a skinny GEMM over a 9-33 MB weight tensor: MIOpen
-// spends 45-150 us on each (layout transposes, zero fills, a tile shape made for large maps).  Here the weight tensor is the
-// GEMM operand AS IT LIES IN MEMORY — no packing, no transform — and the handful of activations is rearranged instead:
-//   DATA  (Conv2d backward-data, ConvTranspose2d forward):   W = [R][(Cq,t)] is reduction-major already
-//           Mcol[(cq,t)][n] = sum_r W[r][(cq,t)] * in[r][n]          wino_gemm_kernel with one "point": U = W, V = in as [R][n]
-//           out[b][cq][f]   = sum over the (o,t) with f = o*stride - pad + t*dil of Mcol[(cq,t)][(b,o)]      (col2im)
-//   WRW   (weight gradient of either):  dW[a][(cq,t)] = sum_n coarse[a][n] * col(fine)[(cq,t)][n]
-//           U = coarse as [n][a], V = im2col(fine) as [n][(cq,t)], reduction over the B*Ho*Wo <= 512 positions: the GEMM's output
-//           IS dW in its native layout (written once, no second pass).
-// n = (b, oy, ox) runs over the COARSE grid (the conv's output side); "fine" is the conv's input side.
+// 510-515) are ~85 convolution calls per training step whose arithmetic is a skinny GEMM between a 9-33 MB weight tensor and
+// a handful of activations: MIOpen spends 45-150 us on each (layout transposes, zero fills, tiles made for large maps).
+// Here the weight tensor Wm = [R][Q] (R = its first channel dimension, Q = second channel dimension x taps, contiguous: Conv2d
+// [Cout][(Cin,t)], ConvTranspose2d [Cin][(Cout,t)]) is STREAMED ONCE from where it lies, 16 bytes per lane straight into
+// MFMA operands — no LDS, no packing — and the P = B*Ho*Wo <= 512 positions ride on the 32-wide N side of 32x32x2 MFMAs:
+//   DATA (Conv2d backward-data, ConvTranspose2d forward)   Mcol[q][p] = sum_r Wm[r][q] * in[r][p],  then col2im over the taps
+//   FWD  (Conv2d forward, ConvTranspose2d backward-data)    y[r][p]    = sum_q Wm[r][q] * col(fine)[q][p]
+//   WRW  (weight gradient of either)                        dW[r][q]   = sum_p coarse[r][p] * col(fine)[q][p]   (native layout, one pass)
+// p runs over the grid on R's side ("coarse": the conv's output side), "fine" is the grid on Q's side.  The row / column labels
+// of an MFMA tile are free, so a lane's float4 of four consecutive q feeds four MFMAs whose tiles are q = q0 + 4m + j: every
+// weight byte is fetched by exactly one coalesced 16-byte load.  The streams are bandwidth bound (16.8 MB in ~5 us); the
+// reduction is cut over workgroups into slabs that the tiny post-pass (col2im / layout) adds in order (deterministic).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+
 __global__ void __launch_bounds__(256) sm_to_cn_kernel(const float* __restrict__ x, int B, int C, int HW, int Tp, float* __restrict__ out)
 {
     const int n = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
@@ -1351,21 +1356,34 @@ __global__ void __launch_bounds__(256) sm_to_nc_kernel(const float* __restrict__
     out[(size_t)n * C + c] = v;
 }
 
+__device__ __forceinline__ float sm_tap(const float* __restrict__ f, int B, int C, int Hf, int Wf, int Ho, int Wo, int k, int st, int pad, int dil,
+                                        int n, int col)
+{
+    if (n >= B * Ho * Wo) return 0.0f;
+    const int kk = k * k;
+    const int c = col / kk, t = col - c * kk, r = t / k, q = t - r * k;
+    const int b = n / (Ho * Wo), o = n - b * Ho * Wo, oy = o / Wo, ox = o - oy * Wo;
+    const int fy = oy * st - pad + r * dil, fx = ox * st - pad + q * dil;
+    return ((unsigned)fy < (unsigned)Hf && (unsigned)fx < (unsigned)Wf) ? f[(((size_t)b * C + c) * Hf + fy) * Wf + fx] : 0.0f;
+}
+
 // V[n][(c,t)] = fine[b][c][oy*s - pad + r*dil][ox*s - pad + q*dil]  (0 outside; rows n >= B*Ho*Wo zero)
 __global__ void __launch_bounds__(256) sm_im2col_nt_kernel(const float* __restrict__ f, int B, int C, int Hf, int Wf, int Ho, int Wo,
                                                            int k, int st, int pad, int dil, float* __restrict__ out)
 {
     const int col = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    const int kk = k * k, ncol = C * kk;
+    const int ncol = C * k * k;
     if (col >= ncol) return;
-    float v = 0.0f;
-    if (n < B * Ho * Wo) {
-        const int c = col / kk, t = col - c * kk, r = t / k, q = t - r * k;
-        const int b = n / (Ho * Wo), o = n - b * Ho * Wo, oy = o / Wo, ox = o - oy * Wo;
-        const int fy = oy * st - pad + r * dil, fx = ox * st - pad + q * dil;
-        if ((unsigned)fy < (unsigned)Hf && (unsigned)fx < (unsigned)Wf) v = f[(((size_t)b * C + c) * Hf + fy) * Wf + fx];
-    }
-    out[(size_t)n * ncol + col] = v;
+    out[(size_t)n * ncol + col] = sm_tap(f, B, C, Hf, Wf, Ho, Wo, k, st, pad, dil, n, col);
+}
+
+// the same as [(c,t)][n] with row length Tp (columns n >= B*Ho*Wo zero)
+__global__ void __launch_bounds__(256) sm_im2col_cn_kernel(const float* __restrict__ f, int B, int C, int Hf, int Wf, int Ho, int Wo,
+                                                           int k, int st, int pad, int dil, int Tp, float* __restrict__ out)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, col = blockIdx.y;
+    if (n >= Tp) return;
+    out[(size_t)col * Tp + n] = sm_tap(f, B, C, Hf, Wf, Ho, Wo, k, st, pad, dil, n, col);
 }
 
 // out[b][c][fy][fx] = sum_{slabs} sum_{(r,q): fy = oy*s - pad + r*dil, fx = ox*s - pad + q*dil} M[(c,t)][(b,oy,ox)]
@@ -1394,40 +1412,236 @@ __global__ void __launch_bounds__(256) sm_col2im_kernel(const float* __restrict_
     out[idx] = acc;
 }
 
-struct SmPlan { int P, Tp, Rp, Kp, ncol; WinoSplit sp; size_t a_floats, b_floats, m_floats, total_bytes; };
+// out[b][r][o] = sum_{slabs} Y[slab][r][(b,o)]
+__global__ void __launch_bounds__(256) sm_sum_to_nchw_kernel(const float* __restrict__ Y, int nslab, size_t slab_stride, int B, int R, int HW, int Tp,
+                                                             float* __restrict__ out)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)B * R * HW) return;
+    const int o = (int)(idx % HW), r = (int)((idx / HW) % R), b = (int)(idx / ((size_t)HW * R));
+    const size_t off = (size_t)r * Tp + (size_t)b * HW + o;
+    float acc = 0.0f;
+    for (int sl = 0; sl < nslab; ++sl) acc += Y[(size_t)sl * slab_stride + off];
+    out[idx] = acc;
+}
+
+// In-workgroup reduction of the four waves' partial tiles (each wave took a quarter of the slab's reduction range): waves 1..3
+// park a tile in LDS, wave 0 adds them in order.  Deterministic; 4x fewer slabs for the same number of waves in flight.
+template <int NB>
+__device__ __forceinline__ void sm_reduce4(f32x16 (&acc)[NB], float* lds, int wave, int lane)
+{
+    if (wave > 0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lds[(((wave - 1) * NB + nb) * 16 + e) * 64 + lane] = acc[nb][e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nb][e] += lds[((w * NB + nb) * 16 + e) * 64 + lane];
+    }
+    __syncthreads();
+}
+
+// DATA: one workgroup (4 waves) = 128 columns q of Wm x the rows of its slab (a quarter per wave) x NB position blocks.
+//   A (MFMA j, lane (m, h)) = Wm[r + h][q0 + 4m + j]   — component j of the lane's float4 at Wm[r + h][q0 + 4m]
+//   B (lane (n, h))         = in[r + h][n0 + 32 nb + n]
+// slab s = blockIdx.y: Mcol_s[q0 + 4*row + j][n] for the 32x32 tile rows `row` of MFMA j.
+template <int NB>
+__global__ void __launch_bounds__(256) sm_data_kernel(const float* __restrict__ Wm, const float* __restrict__ In, int R, int Q, int Tp, int rows_per_wave,
+                                                      float* __restrict__ Mcol)
+{
+    __shared__ float red[3 * NB * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), m = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 128, n0 = blockIdx.z * (32 * NB);
+    const int ra = min(R, (blockIdx.y * 4 + wave) * rows_per_wave), rb = min(R, ra + rows_per_wave);
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.0f;
+    const float* wp = Wm + (size_t)(ra + h) * Q + q0 + 4 * m;
+    const float* ip = In + (size_t)(ra + h) * Tp + n0 + m;
+    constexpr int U = 8;                                  // row pairs in flight: 8 KB of the weight stream per wave
+    for (int r = ra; r < rb; r += 2 * U) {
+        f32x4v a[U];
+        float bv[U][NB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = r + 2 * u < rb;               // R and rows_per_wave are even: a pair is in or out as a whole
+            a[u] = ok ? *reinterpret_cast<const f32x4v*>(wp + (size_t)2 * u * Q) : f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[u][nb] = ok ? ip[(size_t)2 * u * Tp + 32 * nb] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], bv[u][nb], acc[j][nb], 0, 0, 0);
+        wp += (size_t)2 * U * Q;
+        ip += (size_t)2 * U * Tp;
+    }
+    float* out = Mcol + (size_t)blockIdx.y * Q * Tp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sm_reduce4<NB>(acc[j], red, wave, lane);
+        if (wave == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    out[(size_t)(q0 + 4 * row + j) * Tp + n0 + 32 * nb + m] = acc[j][nb][e];
+                }
+        }
+    }
+}
+
+// FWD: one workgroup (4 waves) = 32 rows r of Wm x the columns of its slab (a quarter per wave) x NB position blocks.
+//   A (MFMA j, lane (m, h)) = Wm[r0 + m][q + 4h + j]   — component j of the lane's float4 at Wm[r0 + m][q + 4h]
+//   B (MFMA j, lane (n, h)) = col[q + 4h + j][n0 + 32 nb + n]
+template <int NB>
+__global__ void __launch_bounds__(256) sm_fwd_kernel(const float* __restrict__ Wm, const float* __restrict__ Xc, int R, int Q, int Tp, int cols_per_wave,
+                                                     float* __restrict__ Y)
+{
+    __shared__ float red[3 * NB * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), m = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * 32, n0 = blockIdx.z * (32 * NB);
+    const int qa = min(Q, (blockIdx.y * 4 + wave) * cols_per_wave), qb = min(Q, qa + cols_per_wave);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nb][e] = 0.0f;
+    const float* wp = Wm + (size_t)(r0 + m) * Q + qa + 4 * h;
+    const float* xp = Xc + (size_t)(qa + 4 * h) * Tp + n0 + m;
+    constexpr int U = 4;                                  // groups of 8 columns in flight
+    for (int q = qa; q < qb; q += 8 * U) {
+        f32x4v a[U];
+        float bv[U][4][NB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = q + 8 * u < qb;               // Q and cols_per_wave are multiples of 8
+            a[u] = ok ? *reinterpret_cast<const f32x4v*>(wp + 8 * u) : f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bv[u][j][nb] = ok ? xp[(size_t)(8 * u + j) * Tp + 32 * nb] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], bv[u][j][nb], acc[nb], 0, 0, 0);
+        wp += 8 * U;
+        xp += (size_t)8 * U * Tp;
+    }
+    sm_reduce4<NB>(acc, red, wave, lane);
+    if (wave == 0) {
+        float* out = Y + (size_t)blockIdx.y * R * Tp;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                out[(size_t)(r0 + row) * Tp + n0 + 32 * nb + m] = acc[nb][e];
+            }
+    }
+}
+
+// WRW: one wave = the 32 x 128 block dW[r0 .. r0+31][q0 .. q0+127], reduction over all Pp (even, zero padded) positions.
+//   A (lane (m, h)) = Ct[p + h][r0 + m]                      coarse tensor as [p][r]
+//   B (MFMA j)      = component j of the float4 Vt[p + h][q0 + 4n]   im2col of the fine tensor as [p][(c,t)]  -> tile column n is q0 + 4n + j
+__global__ void __launch_bounds__(64) sm_wrw_kernel(const float* __restrict__ Ct, const float* __restrict__ Vt, int R, int Q, int Pp, float* __restrict__ dW)
+{
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 128, r0 = blockIdx.y * 32;
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+    const float* cp = Ct + (size_t)h * R + r0 + m;
+    const float* vp = Vt + (size_t)h * Q + q0 + 4 * m;
+    constexpr int U = 4;
+    for (int p = 0; p < Pp; p += 2 * U) {
+        float av[U];
+        f32x4v b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = p + 2 * u < Pp;
+            av[u] = ok ? cp[(size_t)2 * u * R] : 0.0f;
+            b[u] = ok ? *reinterpret_cast<const f32x4v*>(vp + (size_t)2 * u * Q) : f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b[u][j], acc[j], 0, 0, 0);
+        cp += (size_t)2 * U * R;
+        vp += (size_t)2 * U * Q;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        *reinterpret_cast<f32x4v*>(dW + (size_t)(r0 + row) * Q + q0 + 4 * m) = f32x4v{acc[0][e], acc[1][e], acc[2][e], acc[3][e]};
+    }
+}
+
+struct SmPlan { int P, Tp, Pp, Q, nb, ngroups, nslab, per_slab; size_t a_floats, b_floats, m_floats, total_bytes; };
 
 // op 0 (DATA): in [B][R][Ho][Wo], W [R][Cq][k][k] -> out [B][Cq][Hf][Wf].   op 1 (WRW): coarse [B][R][Ho][Wo], fine [B][Cq][Hf][Wf]
-// -> dW [R][Cq][k][k]  (R = the weight's first channel dimension in both).
+// -> dW [R][Cq][k][k].   op 2 (FWD): fine [B][Cq][Hf][Wf], W -> out [B][R][Ho][Wo].   (R = the weight's first channel dimension.)
 static int sm_plan(int op, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf, int k, int st, int pad, int dil, SmPlan* p)
 {
-    if (op < 0 || op > 1) return fail(IPSR_ERR_INVALID, "small-map convolution: op %d", op);
+    if (op < 0 || op > 2) return fail(IPSR_ERR_INVALID, "small-map convolution: op %d", op);
     if (k < 1 || k > 4 || st < 1 || st > 2 || dil < 1 || pad < 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: k%d s%d p%d d%d", k, st, pad, dil);
     if (Ho != (Hf + 2 * pad - dil * (k - 1) - 1) / st + 1 || Wo != (Wf + 2 * pad - dil * (k - 1) - 1) / st + 1)
         return fail(IPSR_ERR_INVALID, "small-map convolution: %dx%d is not the output grid of %dx%d under k%d s%d p%d d%d", Ho, Wo, Hf, Wf, k, st, pad, dil);
     p->P = B * Ho * Wo;
-    p->ncol = Cq * k * k;
-    if (p->ncol % WG_BN != 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d x %d taps is not a multiple of %d", Cq, k * k, WG_BN);
-    if (p->P > 1024) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d output positions (made for <= 1024)", p->P);
+    p->Q = Cq * k * k;
+    if (p->Q % 128 != 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d x %d taps is not a multiple of 128", Cq, k * k);
+    if (R % 32 != 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d weight rows are not a multiple of 32", R);
+    if (p->P > 1024) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d positions (made for <= 1024)", p->P);
+    const int blocks = (p->P + 31) / 32;                           // 32-wide position blocks
+    p->nb = blocks >= 4 ? 4 : (blocks == 3 ? 4 : blocks);          // 1, 2 or 4 per wave
+    p->ngroups = (blocks + p->nb - 1) / p->nb;
+    p->Tp = p->ngroups * p->nb * 32;
+    p->Pp = (p->P + 1) & ~1;
+    p->a_floats = p->b_floats = p->m_floats = 0;
+    p->nslab = 1; p->per_slab = 0;
+    // waves in flight ~ 1024 (one per SIMD) when the slab count allows it: a slab costs its write + its read in the post-pass, so it is
+    // capped where that traffic would pass half the weight stream
+    const size_t w_bytes = (size_t)R * p->Q * 4;
     if (op == 0) {
-        if (R % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d reduction channels are not a multiple of %d", R, WG_BK);
-        p->Tp = (p->P + WG_BN - 1) / WG_BN * WG_BN;
-        p->Kp = p->ncol; p->Rp = R;
-        const int tiles = (p->Kp / WG_BM) * (p->Tp / WG_BN), stages = R / WG_BK;
-        int ns = std::max(1, std::min(stages / 8, 384 / std::max(tiles, 1)));
-        const int per = cdiv(stages, ns);
-        ns = cdiv(stages, per);
-        p->sp = WinoSplit{ns, per, 1, ns, per, 1};
-        p->a_floats = 0;
+        const int qb = p->Q / 128;
+        const size_t slab_bytes = (size_t)p->Q * p->Tp * 4;
+        const int cap = (int)std::max<size_t>(1, w_bytes / slab_bytes);
+        int ns = std::max(1, std::min({R / 64, cap, (256 + qb * p->ngroups - 1) / (qb * p->ngroups)}));
+        p->per_slab = (((R + 4 * ns - 1) / (4 * ns)) + 1) & ~1;                      // rows per WAVE (even)
+        p->nslab = (R + 4 * p->per_slab - 1) / (4 * p->per_slab);
         p->b_floats = (size_t)R * p->Tp;
-        p->m_floats = (size_t)ns * p->Kp * p->Tp;
+        p->m_floats = (size_t)p->nslab * p->Q * p->Tp;
+    } else if (op == 2) {
+        const int rb = R / 32;
+        const size_t slab_bytes = (size_t)R * p->Tp * 4;
+        const int cap = (int)std::max<size_t>(1, w_bytes / slab_bytes);
+        int ns = std::max(1, std::min({p->Q / 256, cap, (256 + rb * p->ngroups - 1) / (rb * p->ngroups)}));
+        p->per_slab = (((p->Q + 4 * ns - 1) / (4 * ns)) + 7) & ~7;                   // columns per WAVE (multiple of 8)
+        p->nslab = (p->Q + 4 * p->per_slab - 1) / (4 * p->per_slab);
+        p->b_floats = (size_t)p->Q * p->Tp;
+        p->m_floats = (size_t)p->nslab * R * p->Tp;
     } else {
-        if (R % WG_BM != 0) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d weight rows are not a multiple of %d", R, WG_BM);
-        p->Rp = (p->P + WG_BK - 1) / WG_BK * WG_BK;
-        p->Kp = R; p->Tp = p->ncol;
-        p->sp = WinoSplit{1, p->Rp / WG_BK, 1, 1, p->Rp / WG_BK, 1};
-        p->a_floats = (size_t)p->Rp * R;
-        p->b_floats = (size_t)p->Rp * p->ncol;
-        p->m_floats = 0;
+        p->a_floats = (size_t)p->Pp * R;
+        p->b_floats = (size_t)p->Pp * p->Q;
     }
     p->total_bytes = align_up(p->a_floats * 4, 256) + align_up(p->b_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
     return IPSR_OK;
@@ -1450,25 +1664,33 @@ int launch_smallmap(int op, const float* a, const float* b2, float* out, int B, 
     float* A = cv.take<float>(p.a_floats);
     float* Bv = cv.take<float>(p.b_floats);
     float* Mo = cv.take<float>(p.m_floats);
-    const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
-    if (op == 0) {
+    if (op == 0) {          // a = in, b2 = W
         sm_to_cn_kernel<<<dim3(cdiv(p.Tp, 256), R), 256, 0, st>>>(a, B, R, Ho * Wo, p.Tp, Bv);
-        if (int rc = check_launch("sm_to_cn_kernel")) return rc;
-        profile_mark_start(st, 3);
-        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(b2, Bv, R, p.Kp, p.Tp, kt, tt, p.sp, Mo);
-        profile_mark_stop(st, 3, 2.0 * R * p.Kp * p.Tp);
-        if (int rc = check_launch("wino_gemm_kernel")) return rc;
+        const dim3 grid(p.Q / 128, p.nslab, p.ngroups);
+        if (p.nb == 1) sm_data_kernel<1><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
+        else if (p.nb == 2) sm_data_kernel<2><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
+        else sm_data_kernel<4><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
+        if (int rc = check_launch("sm_data_kernel")) return rc;
         const size_t total = (size_t)B * Cq * Hf * Wf;
-        sm_col2im_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Mo, p.sp.nsplit, (size_t)p.Kp * p.Tp, B, Cq, Hf, Wf, Ho, Wo, k, st_, pad, dil, p.Tp, out);
+        sm_col2im_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Mo, p.nslab, (size_t)p.Q * p.Tp, B, Cq, Hf, Wf, Ho, Wo, k, st_, pad, dil, p.Tp, out);
         return check_launch("sm_col2im_kernel");
     }
-    sm_to_nc_kernel<<<dim3(cdiv(R, 256), p.Rp), 256, 0, st>>>(a, B, R, Ho * Wo, A);
-    sm_im2col_nt_kernel<<<dim3(cdiv(p.ncol, 256), p.Rp), 256, 0, st>>>(b2, B, Cq, Hf, Wf, Ho, Wo, k, st_, pad, dil, Bv);
-    if (int rc = check_launch("sm_im2col_nt_kernel")) return rc;
-    profile_mark_start(st, 3);
-    wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, p.Rp, p.Kp, p.Tp, kt, tt, p.sp, out);
-    profile_mark_stop(st, 3, 2.0 * p.Rp * p.Kp * p.Tp);
-    return check_launch("wino_gemm_kernel");
+    if (op == 2) {          // a = fine, b2 = W
+        sm_im2col_cn_kernel<<<dim3(cdiv(p.Tp, 256), p.Q), 256, 0, st>>>(a, B, Cq, Hf, Wf, Ho, Wo, k, st_, pad, dil, p.Tp, Bv);
+        const dim3 grid(R / 32, p.nslab, p.ngroups);
+        if (p.nb == 1) sm_fwd_kernel<1><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
+        else if (p.nb == 2) sm_fwd_kernel<2><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
+        else sm_fwd_kernel<4><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
+        if (int rc = check_launch("sm_fwd_kernel")) return rc;
+        const size_t total = (size_t)B * R * Ho * Wo;
+        sm_sum_to_nchw_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Mo, p.nslab, (size_t)R * p.Tp, B, R, Ho * Wo, p.Tp, out);
+        return check_launch("sm_sum_to_nchw_kernel");
+    }
+    // op 1: a = coarse, b2 = fine
+    sm_to_nc_kernel<<<dim3(cdiv(R, 256), p.Pp), 256, 0, st>>>(a, B, R, Ho * Wo, A);
+    sm_im2col_nt_kernel<<<dim3(cdiv(p.Q, 256), p.Pp), 256, 0, st>>>(b2, B, Cq, Hf, Wf, Ho, Wo, k, st_, pad, dil, Bv);
+    sm_wrw_kernel<<<dim3(p.Q / 128, R / 32), 64, 0, st>>>(A, Bv, R, p.Q, p.Pp, out);
+    return check_launch("sm_wrw_kernel");
 }
 
 }  // namespace ipsr

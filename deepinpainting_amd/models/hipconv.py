@@ -12,8 +12,9 @@ Three engines per (operation, geometry), chosen by `select()` from measurements 
   "wino_s2"   csrc/winograd.hip   the 4x4 stride-2 pad-1 layers (Conv2d of netP/netD/netF, ConvTranspose2d of netP/netG) by F(5x5,2x2) on
                                   the polyphase components — forward, input and weight gradient, 5-30 % faster than MIOpen at
                                   >= 128 / 64 channels on coarse grids of 16..64
-  "smallmap"  csrc/winograd.hip   weight gradients of the 4x4 stride-2 layers on the innermost levels (<= 256 positions per batch): one GEMM
-                                  over the positions that writes dW in its native layout
+  "smallmap"  csrc/winograd.hip   the innermost levels: the weight tensor streamed once, 16 bytes per lane straight into MFMA operands —
+                                  weight gradients of the 4x4 stride-2 layers up to 256 positions per batch (dW written in its native
+                                  layout), forward and input gradient of the 3x3 / 4x4 layers up to 32 positions
   "direct"    csrc/conv_gemm.hip  one-launch implicit GEMM, NCHW in/out (every k3/k4, stride 1/2, dilated and transposed
                                   geometry of the nets, forward and backward-data): at parity with MIOpen (~100 TF), used
                                   where it measured >= 7 % faster
@@ -58,6 +59,8 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil):
     if mode == "auto" and _is_k4s1(k, stride, pad, dil) and op in (ops.CONV_FWD, ops.CONV_BWD_DATA) \
             and cred % 16 == 0 and min(Cin, Cout) >= 128 and 16 <= H <= 128:
         return "wino_dil"        # netD's 4x4 stride-1 convolution: the same F(3x3,4x4) pipeline on the image itself
+    if mode == "auto" and _smallmap_data_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
+        return "smallmap"        # innermost levels (<= 32 positions per batch): the weight tensor streamed once into MFMA operands
     if mode == "auto":
         g = _s2_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
         if g is not None and _s2_wins(g) and ops.s2_winograd_supported(_s2_mode(op), B, *g):
@@ -104,6 +107,20 @@ def _smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
         return B, Cin, Cout, H, W, Hy, Wy, k, stride, pad, dil
     Hy, Wy = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     return B, Cout, Cin, Hy, Wy, H, W, k, stride, pad, dil
+
+
+def _smallmap_op(op):
+    """Conv2d forward / ConvTranspose2d backward-data contract the weight's second dimension (SM_FWD); the other two its first."""
+    return ops.SM_FWD if op in (ops.CONV_FWD, ops.CONVT_BWD_DATA) else ops.SM_DATA
+
+
+def _smallmap_data_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """Forward / input gradient on grids of <= 32 positions per batch (2x2 and 1x1 at batch 8): 15-20 us on the device against
+    MIOpen's 40-50 (profiles/r02_hipconv_small.txt); from 128 positions up the op is a real GEMM and MIOpen ties."""
+    if os.environ.get("IPSR_NO_SMALLMAP", "0") == "1" or k not in (3, 4) or min(Cin, Cout) < 256:
+        return False
+    g = _smallmap_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
+    return g[3] >= 1 and g[4] >= 1 and g[0] * g[3] * g[4] <= 32 and ops.smallmap_supported(_smallmap_op(op), *g)
 
 
 def _smallmap_wrw_wins(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
@@ -159,6 +176,8 @@ class _HipConv(torch.autograd.Function):
             y = ops.conv2d(op, xc, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng_fwd == "wino_dil":
             y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+        elif eng_fwd == "smallmap":
+            y = ops.conv_smallmap(_smallmap_op(op), xc, w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         elif eng_fwd == "wino_s2":
             y = ops.conv4x4s2_winograd(_s2_mode(op), xc, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         else:
@@ -183,6 +202,8 @@ class _HipConv(torch.autograd.Function):
                 dx = ops.conv2d(op, dy, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
             elif eng == "wino_dil":
                 dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+            elif eng == "smallmap":
+                dx = ops.conv_smallmap(_smallmap_op(op), dy, w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
             elif eng == "wino_s2":
                 dx = ops.conv4x4s2_winograd(_s2_mode(op), dy, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
             else:
@@ -245,6 +266,8 @@ def conv_nobias(m, x, weight=None):
             return ops.conv2d(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng == "wino_dil":
             return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+        elif eng == "smallmap":
+            return ops.conv_smallmap(_smallmap_op(op), x.contiguous(), w.detach(), *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         elif eng == "wino_s2":
             return ops.conv4x4s2_winograd(_s2_mode(op), x.contiguous(), w.detach(), B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
     if transposed:

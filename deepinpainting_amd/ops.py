@@ -487,7 +487,7 @@ def conv4x4s2_winograd(mode, a, b, B, Kc, Cf, nh, nw, out=None):
     return out
 
 
-SM_DATA, SM_WRW = 0, 1
+SM_DATA, SM_WRW, SM_FWD = 0, 1, 2
 
 
 def smallmap_supported(op, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil):
@@ -497,11 +497,12 @@ def smallmap_supported(op, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil):
 def conv_smallmap(op, a, b, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil, out=None):
     """Small-map convolutions with the weight tensor [R,Cq,k,k] as the GEMM operand in place (ipsr_conv_smallmap):
     op SM_DATA: a = in [B,R,Ho,Wo], b = weight -> [B,Cq,Hf,Wf] (Conv2d backward-data / ConvTranspose2d forward);
-    op SM_WRW:  a = coarse [B,R,Ho,Wo], b = fine [B,Cq,Hf,Wf] -> dW [R,Cq,k,k]."""
+    op SM_WRW:  a = coarse [B,R,Ho,Wo], b = fine [B,Cq,Hf,Wf] -> dW [R,Cq,k,k];
+    op SM_FWD:  a = fine [B,Cq,Hf,Wf], b = weight -> [B,R,Ho,Wo] (Conv2d forward / ConvTranspose2d backward-data)."""
     a = _req(a, torch.float32, "operand a")
     b = _req(b, torch.float32, "operand b")
     coarse, fine, wsh = (B, R, Ho, Wo), (B, Cq, Hf, Wf), (R, Cq, k, k)
-    want = {SM_DATA: (coarse, wsh, fine), SM_WRW: (coarse, fine, wsh)}[op]
+    want = {SM_DATA: (coarse, wsh, fine), SM_WRW: (coarse, fine, wsh), SM_FWD: (fine, wsh, coarse)}[op]
     if tuple(a.shape) != want[0] or tuple(b.shape) != want[1]:
         raise RuntimeError("conv_smallmap op %d: operands %s / %s do not match %s / %s" % (op, tuple(a.shape), tuple(b.shape), want[0], want[1]))
     if out is not None and (tuple(out.shape) != tuple(want[2]) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device):

@@ -277,7 +277,8 @@ int ipsr_conv4x4s2_winograd(int mode, const float* a, const float* b, float* out
  * (Conv2d input / ConvTranspose2d output), Ho x Wo the grid on its first-channel side.
  *   op 0  a = in [B,R,Ho,Wo]       b = weight        out = [B,Cq,Hf,Wf]    Conv2d backward-data / ConvTranspose2d forward
  *   op 1  a = coarse [B,R,Ho,Wo]   b = fine [B,Cq,Hf,Wf]   out = dW [R,Cq,k,k]   weight gradient of either module
- * R % 16 == 0 (op 0) / R % 128 == 0 (op 1), Cq*k*k % 128 == 0, B*Ho*Wo <= 1024. */
+ *   op 2  a = fine [B,Cq,Hf,Wf]    b = weight        out = [B,R,Ho,Wo]     Conv2d forward / ConvTranspose2d backward-data
+ * R % 32 == 0, Cq*k*k % 128 == 0, B*Ho*Wo <= 1024. */
 size_t ipsr_conv_smallmap_workspace_bytes(int op, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf, int k, int stride, int pad, int dil);
 int ipsr_conv_smallmap(int op, const float* a, const float* b, float* out, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf,
                        int k, int stride, int pad, int dil, void* ws, size_t ws_bytes, void* stream);

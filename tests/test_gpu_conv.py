@@ -253,6 +253,14 @@ def test_smallmap_engine_vs_fp64(kind, Ci, Co, H, W, k, st, pad, dil, B):
         assert _rel(dx, dx64) <= 2e-5
         dw = ops.conv_smallmap(ops.SM_WRW, dy, x, *geo)
     assert tuple(dw.shape) == tuple(w.shape) and _rel(dw, dw64) <= 2e-5
+    # the third operation: Conv2d forward / ConvTranspose2d backward-data (weight rows x im2col of the fine tensor)
+    if tr:
+        dxt = torch.full((B, Ci, H, W), float("nan"), device="cuda")
+        ops.conv_smallmap(ops.SM_FWD, dy, w, *geo, out=dxt)
+        assert _rel(dxt, dx64) <= 2e-5
+    else:
+        yc = ops.conv_smallmap(ops.SM_FWD, x, w, *geo)
+        assert _rel(yc, y64.detach()) <= 2e-5
 
 
 @pytest.mark.parametrize("engine", ["direct", "winograd", "auto"])
@@ -265,7 +273,8 @@ def test_module_path_forward_and_gradients(engine):
     cases = [(nn.Conv2d(128, 128, 4, 2, 3, dilation=2), 32, 32), (nn.Conv2d(64, 128, 3, 1, 1), 16, 16), (nn.ConvTranspose2d(128, 64, 3, 1, 1), 16, 16),
              (nn.Conv2d(32, 32, 4, 2, 3, dilation=2), 16, 16), (nn.ConvTranspose2d(32, 16, 4, 2, 1), 8, 8), (nn.Conv2d(16, 32, 4, 2, 1), 16, 16),
              (nn.Conv2d(64, 128, 4, 2, 1), 32, 32), (nn.ConvTranspose2d(128, 64, 4, 2, 1), 16, 16), (nn.Conv2d(128, 256, 4, 1, 1), 16, 16),
-             (nn.Conv2d(256, 256, 4, 2, 1), 4, 4), (nn.ConvTranspose2d(256, 256, 4, 2, 1), 2, 2)]
+             (nn.Conv2d(256, 256, 4, 2, 1), 4, 4), (nn.ConvTranspose2d(256, 256, 4, 2, 1), 2, 2), (nn.Conv2d(256, 256, 3, 1, 1), 2, 2),
+             (nn.ConvTranspose2d(512, 256, 3, 1, 1), 2, 2), (nn.Conv2d(256, 256, 4, 2, 3, dilation=2), 4, 4)]
     hipconv._FORCE = engine
     try:
         for m, H, W in cases:
@@ -324,6 +333,10 @@ def test_dispatcher_rules_and_refusals():
     assert hipconv.select_wrw(False, 8, 512, 8, 8, 512, 4, 2, 3, 2) == "smallmap"        # netG dilated down @8 -> 4
     assert hipconv.select_wrw(True, 8, 512, 8, 8, 512, 4, 2, 1, 1) == "miopen"           # 512 positions: no gain measured
     assert hipconv.select_wrw(False, 8, 512, 4, 4, 512, 3, 1, 1, 1) == "miopen"          # 3x3: MIOpen ties or wins
+    assert sel(ops.CONV_FWD, 8, 512, 4, 4, 512, 4, 2, 1, 1) == "smallmap"                # <= 32 positions: forward and input gradient too
+    assert sel(ops.CONVT_BWD_DATA, 8, 512, 1, 1, 512, 4, 2, 1, 1) == "smallmap"
+    assert sel(ops.CONVT_FWD, 8, 1024, 2, 2, 512, 3, 1, 1, 1) == "smallmap"
+    assert sel(ops.CONV_BWD_DATA, 8, 512, 8, 8, 512, 4, 2, 1, 1) == "miopen"             # 128 positions: a real GEMM, MIOpen ties
     with pytest.raises(NotImplementedError):
         ops.conv2d(ops.CONV_FWD, torch.zeros(1, 3, 8, 8, device="cuda"), torch.zeros(4, 3, 3, 3, device="cuda"), (1, 3, 8, 8), 4, 3, 1, 1, 1)
     with pytest.raises(RuntimeError):
