@@ -1469,7 +1469,7 @@ __global__ void __launch_bounds__(256) sm_data_kernel(const float* __restrict__ 
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.0f;
     const float* wp = Wm + (size_t)(ra + h) * Q + q0 + 4 * m;
     const float* ip = In + (size_t)(ra + h) * Tp + n0 + m;
-    constexpr int U = 8;                                  // row pairs in flight: 8 KB of the weight stream per wave
+    constexpr int U = NB == 1 ? 8 : (NB == 2 ? 4 : 2);     // row pairs in flight (8 KB of the weight stream per wave at NB = 1); bounded by the 4*NB accumulator tiles
     for (int r = ra; r < rb; r += 2 * U) {
         f32x4v a[U];
         float bv[U][NB];
@@ -1613,6 +1613,7 @@ static int sm_plan(int op, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf,
     if (p->P > 1024) return fail(IPSR_ERR_UNSUPPORTED, "small-map convolution: %d positions (made for <= 1024)", p->P);
     const int blocks = (p->P + 31) / 32;                           // 32-wide position blocks
     p->nb = blocks >= 4 ? 4 : (blocks == 3 ? 4 : blocks);          // 1, 2 or 4 per wave
+    if (op == 0 && p->nb == 4) p->nb = 2;                          // DATA keeps 4 accumulator tiles per position block: 2 blocks fill the registers
     p->ngroups = (blocks + p->nb - 1) / p->nb;
     p->Tp = p->ngroups * p->nb * 32;
     p->Pp = (p->P + 1) & ~1;
@@ -1668,8 +1669,7 @@ int launch_smallmap(int op, const float* a, const float* b2, float* out, int B, 
         sm_to_cn_kernel<<<dim3(cdiv(p.Tp, 256), R), 256, 0, st>>>(a, B, R, Ho * Wo, p.Tp, Bv);
         const dim3 grid(p.Q / 128, p.nslab, p.ngroups);
         if (p.nb == 1) sm_data_kernel<1><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
-        else if (p.nb == 2) sm_data_kernel<2><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
-        else sm_data_kernel<4><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
+        else sm_data_kernel<2><<<grid, 256, 0, st>>>(b2, Bv, R, p.Q, p.Tp, p.per_slab, Mo);
         if (int rc = check_launch("sm_data_kernel")) return rc;
         const size_t total = (size_t)B * Cq * Hf * Wf;
         sm_col2im_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Mo, p.nslab, (size_t)p.Q * p.Tp, B, Cq, Hf, Wf, Ho, Wo, k, st_, pad, dil, p.Tp, out);
