@@ -25,6 +25,7 @@ maps (2.0-2.4x MIOpen), MIOpen otherwise (`select_wrw`).
 `IPSR_CONV_ENGINE=miopen|direct|winograd|auto` (default auto) forces one engine wherever it is implemented — for the
 per-engine parity tests and for A/B timing.  bf16 autocast and non-contiguous / non-fp32 inputs always take MIOpen.
 """
+import functools
 import os
 
 import torch
@@ -42,8 +43,13 @@ def _mode():
 
 
 def select(op, B, Cin, H, W, Cout, k, stride, pad, dil):
-    """-> "winograd" | "direct" | "miopen" for one convolution call.  (Cin, H, W) = the module's input, as in ipsr_conv2d."""
-    mode = _mode()
+    """-> the engine for one convolution call.  (Cin, H, W) = the module's input, as in ipsr_conv2d.  Memoised per (mode, shape):
+    the rules query the library (workspace probes), ~150 convolution calls per training step ask."""
+    return _select(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
+
+
+@functools.lru_cache(maxsize=4096)
+def _select(mode, _nosm, op, B, Cin, H, W, Cout, k, stride, pad, dil):
     fwd = op in (ops.CONV_FWD, ops.CONVT_FWD)
     cred, kout = (Cin, Cout) if fwd else (Cout, Cin)            # reduction / produced channels of this operation
     wino_ok = k == 3 and stride == 1 and pad == 1 and dil == 1 and cred % 16 == 0
@@ -137,9 +143,13 @@ def _is_k4s1(k, stride, pad, dil):
 
 
 def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
-    """-> "winograd" | "miopen" for the weight gradient of one layer (profiles/r02_hipconv_k3_wrw.txt: F(3x3,4x4) is 2.0-2.4x
+    """-> the engine for the weight gradient of one layer (profiles/r02_hipconv_k3_wrw.txt: F(3x3,4x4) is 2.0-2.4x
     MIOpen from 256 channels up on maps of 16x16..64x64; on larger maps its tile-major transforms lose to MIOpen)."""
-    mode = _mode()
+    return _select_wrw(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0"), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+
+
+@functools.lru_cache(maxsize=4096)
+def _select_wrw(mode, _nosm, transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
     if mode == "auto" and not transposed and _is_dilated4(k, stride, pad, dil) and min(Cin, Cout) >= 128 and 32 <= H <= 128 \
             and H % 2 == 0 and W % 2 == 0:
         return "wino_dil"
