@@ -84,3 +84,26 @@ def test_header_is_plain_c(tmp_path):
         if shutil.which(cc) is None:
             pytest.skip("%s not available" % cc)
         subprocess.check_call([cc, "-Wall", "-Werror", "-I", os.path.join(root, "include")] + flags + ["-c", str(src), "-o", str(tmp_path / (cc + ".o"))])
+
+
+def test_conv_dispatcher_rules_on_the_host():
+    """models/hipconv.py picks an engine per (operation, shape) from measured rules plus workspace probes of the library — pure host
+    logic (no kernel is launched): the step's main shapes land on the engines DESIGN.md §5.5 names, and shapes an engine cannot
+    express are never routed to it."""
+    from deepinpainting_amd import ops
+    from deepinpainting_amd.models import hipconv
+    sel, wrw = hipconv.select, hipconv.select_wrw
+    assert sel(ops.CONV_FWD, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd"              # VGG conv4_x, netG level 32x32
+    assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 3, 1, 1, 1) == "miopen"                # 64 channels at 256x256: transform bound
+    assert sel(ops.CONV_BWD_DATA, 8, 512, 32, 32, 512, 4, 2, 3, 2) == "wino_dil"         # netG dilated down convolution
+    assert sel(ops.CONV_FWD, 8, 256, 32, 32, 512, 4, 1, 1, 1) == "wino_dil"              # netD's 4x4 stride-1 layer
+    assert sel(ops.CONVT_FWD, 8, 512, 32, 32, 128, 4, 2, 1, 1) == "wino_s2"              # netP up 512 -> 128
+    assert sel(ops.CONV_FWD, 8, 512, 4, 4, 512, 4, 2, 1, 1) == "smallmap"                # innermost level, 32 positions
+    assert sel(ops.CONV_FWD, 8, 3, 256, 256, 64, 4, 2, 1, 1) == "miopen"                 # 3 input channels
+    assert sel(ops.CONV_FWD, 8, 250, 32, 32, 512, 3, 1, 1, 1) == "miopen"                # reduction not a multiple of 16
+    assert wrw(False, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd" and wrw(True, 8, 512, 32, 32, 128, 4, 2, 1, 1) == "wino_s2"
+    assert wrw(False, 8, 512, 8, 8, 512, 4, 2, 1, 1) == "smallmap" and wrw(False, 8, 128, 128, 128, 128, 3, 1, 1, 1) == "miopen"
+    # probes agree with the entry points' own argument checks
+    assert ops.s2_winograd_supported(ops.S2_FINE_TO_COARSE, 8, 128, 64, 64, 64) and not ops.s2_winograd_supported(ops.S2_FINE_TO_COARSE, 8, 128, 3, 64, 64)
+    assert ops.smallmap_supported(ops.SM_WRW, 8, 512, 512, 4, 4, 8, 8, 4, 2, 1, 1) and not ops.smallmap_supported(ops.SM_WRW, 8, 512, 500, 4, 4, 8, 8, 4, 2, 1, 1)
+    assert not ops.smallmap_supported(ops.SM_DATA, 8, 512, 512, 4, 4, 11, 11, 4, 2, 1, 1)         # 11x11 does not map to a 4x4 output
