@@ -1138,8 +1138,9 @@ __global__ void __launch_bounds__(256) wino5_output_kernel(const float* __restri
         }
 }
 
-// mode 1: the four phases of tile t and fine channel k (GEMM rows ph*K + k) -> the 10x10 block of y [B,K,2n_h,2n_w] around it:
-// y[2(5ty+m) - ey][2(5tx+m') - ex] = (A5^T M_ph A5)[m][m']  wherever the coarse index 5t + m - e lies in [0, n)
+// mode 1: phase ph = blockIdx.z of tile t and fine channel k (GEMM row ph*K + k) -> its 25 pixels of y [B,K,2n_h,2n_w]:
+// y[2(5ty+m) - ey][2(5tx+m') - ex] = (A5^T M_ph A5)[m][m']  wherever the coarse index 5t + m - e lies in [0, n).
+// One phase per thread (not the four of a tile): four times the threads in flight — these launches are latency bound.
 __global__ void __launch_bounds__(256) wino5_output_phase_kernel(const float* __restrict__ Mo, WinoSplit split, int B, int K, int Kp, int nh, int nw,
                                                                  int TY, int TX, int Tp, float* __restrict__ y)
 {
@@ -1150,23 +1151,19 @@ __global__ void __launch_bounds__(256) wino5_output_phase_kernel(const float* __
     const int ty = rem / TX, tx = rem - ty * TX;
     const int Wy = 2 * nw;
     float* yp = y + ((size_t)b * K + k) * (size_t)(2 * nh) * Wy;
-    const size_t plane = (size_t)Kp * Tp;
-    const int ey = blockIdx.z;
-    float m[6][6], o0[5][5], o1[5][5];
-    wino_load_sum(Mo, split, plane, (size_t)((2 * ey) * K + k) * Tp + t, m);
-    wino_at5_2d(m, o0);
-    wino_load_sum(Mo, split, plane, (size_t)((2 * ey + 1) * K + k) * Tp + t, m);
-    wino_at5_2d(m, o1);
+    const int ph = blockIdx.z, ey = ph >> 1, ex = ph & 1;
+    float m[6][6], o[5][5];
+    wino_load_sum(Mo, split, (size_t)Kp * Tp, (size_t)(ph * K + k) * Tp + t, m);
+    wino_at5_2d(m, o);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int iy = 5 * ty + i - ey;
         if (iy < 0 || iy >= nh) continue;
-        float* row = yp + (size_t)(2 * iy + ey) * Wy;
+        float* row = yp + (size_t)(2 * iy + ey) * Wy + ex;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int ix0 = 5 * tx + j, ix1 = ix0 - 1;
-            if (ix0 < nw) row[2 * ix0] = o0[i][j];
-            if (ix1 >= 0 && ix1 < nw) row[2 * ix1 + 1] = o1[i][j];
+            const int ix = 5 * tx + j - ex;
+            if (ix >= 0 && ix < nw) row[2 * ix] = o[i][j];
         }
     }
 }
@@ -1306,7 +1303,7 @@ int launch_winograd_s2(int mode, const float* a, const float* b2, float* out, in
         wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, p.red, p.Kp, p.Tp, kt, tt, p.sp, Mo);
         profile_mark_stop(st, 3, 72.0 * p.red * p.Kp * p.Tp);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
-        wino5_output_phase_kernel<<<dim3(cdiv(p.T, 256), Cf, 2), 256, 0, st>>>(Mo, p.sp, B, Cf, p.Kp, nh, nw, p.TY, p.TX, p.Tp, out);
+        wino5_output_phase_kernel<<<dim3(cdiv(p.T, 256), Cf, 4), 256, 0, st>>>(Mo, p.sp, B, Cf, p.Kp, nh, nw, p.TY, p.TX, p.Tp, out);
         return check_launch("wino5_output_phase_kernel");
     }
     wino_wrw_tile5_kernel<<<dim3(p.Tp / 16, p.Kp / 16), 256, 0, st>>>(b2, B, Kc, nh, nw, p.TY, p.TX, p.Tp, p.Kp, A);
