@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libipsr_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -58,6 +58,9 @@ SIGNATURES = {
     "ipsr_conv3x3_winograd_filter_floats": (c_size_t, [c_int, c_int, c_int]),
     "ipsr_conv3x3_winograd_ex": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                          c_void_p, c_size_t, c_void_p]),
+    "ipsr_conv3x3_thin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_long, ctypes.c_long, c_int, c_void_p]),
+    "ipsr_conv3x3_thin_wrw_workspace_bytes": (c_size_t, [c_int] * 5),
+    "ipsr_conv3x3_thin_wrw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ipsr_conv_smallmap_workspace_bytes": (c_size_t, [c_int] * 12),
     "ipsr_conv_smallmap": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]),
     "ipsr_conv4x4s2_winograd_workspace_bytes": (c_size_t, [c_int] * 6),

@@ -1,0 +1,270 @@
+// thin_conv.hip — the 3x3 stride-1 pad-1 layers with 3 or 6 channels on one side, at full resolution:
+//   VGG16 conv1_1 (3 -> 64 on 256x256, models/vgg16.py:9; forward x3 per step, input gradient x1),
+//   netG's first convolution (6 -> 64, models/networks.py:300-312) and its last ConvTranspose2d (128 -> 3, :255-259).
+// These are not matrix-core work: 27-54 multiply-adds per output against 134-268 MB of activations on the wide side, i.e. HBM
+// streams.  MIOpen runs them through its generic paths (65-230 us each, NHWC transposes included); here each is ONE pass over
+// the wide tensor on the vector ALUs with the narrow tensor and the weights served from L1 / LDS:
+//   few -> many   out[b][o][y][x] = sum_{i<I<=8} sum_t Wg(o,i,t) in[b][i][y+r-1][x+s-1]   (+ bias, ReLU): writes the wide tensor once
+//   many -> few   the same sum with O <= 8 outputs and I wide: reads the wide tensor once (4 pixels per lane, float4 rows)
+//   weight grad   G[cb][cs][u][v] = sum_{b,y,x} big[b][cb][y][x] * small[b][cs][y+u-1][x+v-1]: reads the wide tensor once
+// Wg(o,i,t) = W[o*so + i*si + (flip ? 8 - t : t)] expresses Conv2d / ConvTranspose2d, forward / backward-data (as in winograd.hip):
+//   Conv2d forward       W[co][ci]: o = co, i = ci, so = Ci*9, si = 9,    flip 0      Conv2d backward-data   o = ci, i = co, so = 9,    si = Ci*9, flip 1
+//   ConvT  forward       W[ci][co]: o = co, i = ci, so = 9,    si = Co*9, flip 1      ConvT  backward-data   o = ci, i = co, so = Co*9, si = 9,    flip 0
+// and the weight gradient of either is G with big = the wide-channel tensor of the pair (x, dy), small = the other one:
+//   Conv2d dW[co][ci] = G(big = dy, small = x)[co][ci];  ConvTranspose2d dW[ci][co] = G(big = x, small = dy)[ci][co].
+#include "ipsr_common.h"
+
+namespace ipsr {
+
+constexpr int THIN_OC = 16;          // output channels per workgroup (few -> many)
+constexpr int THIN_CB = 2;           // wide channels per workgroup (weight gradient)
+constexpr int THIN_ROWS = 64;        // rows per workgroup (weight gradient)
+
+__device__ __forceinline__ float thin_relu(float v) { return v < 0.0f ? 0.0f : v; }      // NaN stays NaN (torch.relu)
+
+// few -> many.  One thread = one pixel x 16 output channels; the I*9 window values live in registers, the 16*I*9 weights in LDS
+// (uniform reads: broadcast).  grid (ceil(W/256), H, B * O/16).
+template <int I>
+__global__ void __launch_bounds__(256) thin_f2m_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, int relu,
+                                                       float* __restrict__ out, int B, int O, int H, int W, long so, long si, int flip)
+{
+    __shared__ float wl[THIN_OC][I * 9];
+    const int nchunk = O / THIN_OC;
+    const int b = blockIdx.z / nchunk, o0 = (blockIdx.z - b * nchunk) * THIN_OC;
+    for (int idx = threadIdx.x; idx < THIN_OC * I * 9; idx += 256) {
+        const int o = idx / (I * 9), rem = idx - o * (I * 9), i = rem / 9, t = rem - i * 9;
+        wl[o][rem] = w[(long)(o0 + o) * so + (long)i * si + (flip ? 8 - t : t)];
+    }
+    __syncthreads();
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    float win[I][9];
+#pragma unroll
+    for (int i = 0; i < I; ++i) {
+        const float* ip = in + ((size_t)b * I + i) * H * W;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            const bool yok = (unsigned)yy < (unsigned)H;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int xx = x + s - 1;
+                win[i][r * 3 + s] = (yok && (unsigned)xx < (unsigned)W) ? ip[(size_t)yy * W + xx] : 0.0f;
+            }
+        }
+    }
+    float* op = out + (((size_t)b * O + o0) * H + y) * W + x;
+#pragma unroll 4
+    for (int o = 0; o < THIN_OC; ++o) {
+        float acc = bias ? bias[o0 + o] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < I; ++i)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(wl[o][i * 9 + t], win[i][t], acc);
+        op[(size_t)o * H * W] = relu ? thin_relu(acc) : acc;
+    }
+}
+
+// many -> few.  One thread = 4 adjacent pixels x all O outputs; per input channel three float4 rows (+ the two halo columns),
+// the O*9 weights of the channel from LDS.  grid (ceil(W/1024 * 4 rows) ...): block = 4 rows x 64 lanes x 4 pixels.
+template <int O>
+__global__ void __launch_bounds__(256) thin_m2f_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+                                                       int B, int I, int H, int W, long so, long si, int flip)
+{
+    extern __shared__ float wl[];                 // [I][O*9]
+    for (int idx = threadIdx.x; idx < I * O * 9; idx += 256) {
+        const int i = idx / (O * 9), rem = idx - i * (O * 9), o = rem / 9, t = rem - o * 9;
+        wl[idx] = w[(long)o * so + (long)i * si + (flip ? 8 - t : t)];
+    }
+    __syncthreads();
+    const int b = blockIdx.z;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (y >= H || x0 >= W) return;
+    float acc[O][4];
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[o][p] = 0.0f;
+    const float* ib = in + (size_t)b * I * H * W;
+    for (int i = 0; i < I; ++i) {
+        const float* ip = ib + (size_t)i * H * W;
+        const float* wi = wl + i * (O * 9);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            float v[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if ((unsigned)yy < (unsigned)H) {
+                const float* rp = ip + (size_t)yy * W + x0;
+                const float4 c = *reinterpret_cast<const float4*>(rp);
+                v[1] = c.x; v[2] = c.y; v[3] = c.z; v[4] = c.w;
+                if (x0 > 0) v[0] = rp[-1];
+                if (x0 + 4 < W) v[5] = rp[4];
+            }
+#pragma unroll
+            for (int o = 0; o < O; ++o)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const float wv = wi[o * 9 + r * 3 + s];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[o][p] = __builtin_fmaf(wv, v[p + s], acc[o][p]);
+                }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+        *reinterpret_cast<float4*>(out + (((size_t)b * O + o) * H + y) * W + x0) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+}
+
+// weight gradient, pass 1.  One workgroup = THIN_CB wide channels x THIN_ROWS rows of one sample; a thread walks its 4 pixels of each
+// row (4 rows at a time), keeps THIN_CB*CS*9 partial sums, the workgroup reduces them through LDS (fixed order) and writes one
+// partial vector.  grid (ceil(W/256), ceil(H/THIN_ROWS), B * Cb/THIN_CB).
+template <int CS>
+__global__ void __launch_bounds__(256) thin_wrw_kernel(const float* __restrict__ big, const float* __restrict__ small, float* __restrict__ part,
+                                                       int B, int Cb, int H, int W)
+{
+    constexpr int NV = THIN_CB * CS * 9;
+    __shared__ float red[4][NV];                                   // one row per wave
+    const int ncb = Cb / THIN_CB;
+    const int b = blockIdx.z / ncb, cb0 = (blockIdx.z - b * ncb) * THIN_CB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = (blockIdx.x * 64 + lane) * 4;
+    float acc[THIN_CB][CS][9];
+#pragma unroll
+    for (int c = 0; c < THIN_CB; ++c)
+#pragma unroll
+        for (int k = 0; k < CS; ++k)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[c][k][t] = 0.0f;
+    if (x0 < W) {
+        for (int yr = 0; yr < THIN_ROWS; yr += 4) {
+            const int y = blockIdx.y * THIN_ROWS + yr + wave;
+            if (y >= H) break;
+            float g[THIN_CB][4];
+#pragma unroll
+            for (int c = 0; c < THIN_CB; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(big + (((size_t)b * Cb + cb0 + c) * H + y) * W + x0);
+                g[c][0] = v.x; g[c][1] = v.y; g[c][2] = v.z; g[c][3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < CS; ++k) {
+                const float* sp = small + ((size_t)b * CS + k) * H * W;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int yy = y + u - 1;
+                    float v[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    if ((unsigned)yy < (unsigned)H) {
+                        const float* rp = sp + (size_t)yy * W + x0;
+                        const float4 c4 = *reinterpret_cast<const float4*>(rp);
+                        v[1] = c4.x; v[2] = c4.y; v[3] = c4.z; v[4] = c4.w;
+                        if (x0 > 0) v[0] = rp[-1];
+                        if (x0 + 4 < W) v[5] = rp[4];
+                    }
+#pragma unroll
+                    for (int c = 0; c < THIN_CB; ++c)
+#pragma unroll
+                        for (int s = 0; s < 3; ++s)
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) acc[c][k][u * 3 + s] = __builtin_fmaf(g[c][p], v[p + s], acc[c][k][u * 3 + s]);
+                }
+            }
+        }
+    }
+    // wave reduction (fixed butterfly), then the four waves in order
+#pragma unroll
+    for (int c = 0; c < THIN_CB; ++c)
+#pragma unroll
+        for (int k = 0; k < CS; ++k)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float v = acc[c][k][t];
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
+                if (lane == 0) red[wave][(c * CS + k) * 9 + t] = v;
+            }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[blk * NV + threadIdx.x] = v;
+    }
+}
+
+// pass 2: G[cb][cs][t] = sum over (sample, row block, column block) of the partial vectors, ascending.
+__global__ void __launch_bounds__(256) thin_wrw_reduce_kernel(const float* __restrict__ part, float* __restrict__ G, int B, int Cb, int CS, int nblk_yx)
+{
+    const int NV = THIN_CB * CS * 9;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cb * CS * 9) return;
+    const int cb = idx / (CS * 9), rem = idx - cb * (CS * 9);
+    const int grp = cb / THIN_CB, c = cb - grp * THIN_CB;
+    const int ncb = Cb / THIN_CB;
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* p = part + ((size_t)(b * ncb + grp) * nblk_yx) * NV + c * (CS * 9) + rem;
+        for (int j = 0; j < nblk_yx; ++j) acc += p[(size_t)j * NV];
+    }
+    G[idx] = acc;
+}
+
+}  // namespace ipsr
+
+using namespace ipsr;
+
+extern "C" {
+
+int ipsr_conv3x3_thin(int op, const float* in, const float* w, const float* bias, int relu, float* out, int B, int I, int O, int H, int W,
+                      long so, long si, int flip, void* stream)
+{
+    if (!in || !w || !out) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: null pointer");
+    if (B < 1 || I < 1 || O < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (op == 0) {          // few -> many
+        if (O % THIN_OC != 0 || (I != 3 && I != 6)) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: few->many needs 3 or 6 inputs and outputs %% 16 == 0 (got %d -> %d)", I, O);
+        if ((size_t)B * (O / THIN_OC) > 65535 || H > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: grid too large");
+        const dim3 grid(cdiv(W, 256), H, B * (O / THIN_OC));
+        if (I == 3) thin_f2m_kernel<3><<<grid, 256, 0, st>>>(in, w, bias, relu, out, B, O, H, W, so, si, flip);
+        else thin_f2m_kernel<6><<<grid, 256, 0, st>>>(in, w, bias, relu, out, B, O, H, W, so, si, flip);
+        return check_launch("thin_f2m_kernel");
+    }
+    if (op == 1) {          // many -> few
+        if (bias || relu) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: many->few has no epilogue");
+        if ((O != 3 && O != 6) || W % 4 != 0) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: many->few needs 3 or 6 outputs and W %% 4 == 0 (got %d -> %d, W=%d)", I, O, W);
+        if ((reinterpret_cast<uintptr_t>(in) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: tensors must be 16-byte aligned");
+        const size_t lds = (size_t)I * O * 9 * sizeof(float);
+        if (lds > 48 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: %d input channels exceed the LDS weight buffer", I);
+        const dim3 grid(cdiv(W, 256), cdiv(H, 4), B);
+        if (O == 3) thin_m2f_kernel<3><<<grid, 256, lds, st>>>(in, w, out, B, I, H, W, so, si, flip);
+        else thin_m2f_kernel<6><<<grid, 256, lds, st>>>(in, w, out, B, I, H, W, so, si, flip);
+        return check_launch("thin_m2f_kernel");
+    }
+    return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: op %d", op);
+}
+
+size_t ipsr_conv3x3_thin_wrw_workspace_bytes(int B, int Cb, int Cs, int H, int W)
+{
+    if (B < 1 || Cb < 1 || H < 1 || W < 1 || (Cs != 3 && Cs != 6) || Cb % THIN_CB != 0 || W % 4 != 0) return 0;
+    const size_t nblk = (size_t)B * (Cb / THIN_CB) * cdiv(H, THIN_ROWS) * cdiv(W, 256);
+    return align_up(nblk * THIN_CB * Cs * 9 * sizeof(float), 256) + 256;
+}
+
+int ipsr_conv3x3_thin_wrw(const float* big, const float* small, float* g, int B, int Cb, int Cs, int H, int W, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!big || !small || !g || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin_wrw: null pointer");
+    const size_t need = ipsr_conv3x3_thin_wrw_workspace_bytes(B, Cb, Cs, H, W);
+    if (need == 0) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin_wrw: Cb=%d Cs=%d %dx%d is not implemented", Cb, Cs, H, W);
+    if (ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "ipsr_conv3x3_thin_wrw: workspace %zu < %zu", ws_bytes, need);
+    if ((reinterpret_cast<uintptr_t>(big) & 15u) || (reinterpret_cast<uintptr_t>(small) & 15u) || (reinterpret_cast<uintptr_t>(ws) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin_wrw: tensors / workspace must be 16-byte aligned");
+    if ((size_t)B * (Cb / THIN_CB) > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin_wrw: grid too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    const dim3 grid(cdiv(W, 256), cdiv(H, THIN_ROWS), B * (Cb / THIN_CB));
+    if (Cs == 3) thin_wrw_kernel<3><<<grid, 256, 0, st>>>(big, small, part, B, Cb, H, W);
+    else thin_wrw_kernel<6><<<grid, 256, 0, st>>>(big, small, part, B, Cb, H, W);
+    if (int rc = check_launch("thin_wrw_kernel")) return rc;
+    thin_wrw_reduce_kernel<<<cdiv(Cb * Cs * 9, 256), 256, 0, st>>>(part, g, B, Cb, Cs, (int)(grid.x * grid.y));
+    return check_launch("thin_wrw_reduce_kernel");
+}
+
+}  // extern "C"

@@ -12,6 +12,8 @@ Three engines per (operation, geometry), chosen by `select()` from measurements 
   "wino_s2"   csrc/winograd.hip   the 4x4 stride-2 pad-1 layers (Conv2d of netP/netD/netF, ConvTranspose2d of netP/netG) by F(5x5,2x2) on
                                   the polyphase components — forward, input and weight gradient, 5-30 % faster than MIOpen at
                                   >= 128 / 64 channels on coarse grids of 16..64
+  "thin"      csrc/thin_conv.hip  3x3 stride-1 layers with a 3- or 6-channel side at full resolution (VGG conv1_1, netG's last ConvTranspose2d):
+                                  one pass over the wide tensor on the vector ALUs, 1.3-3x MIOpen
   "smallmap"  csrc/winograd.hip   the innermost levels: the weight tensor streamed once, 16 bytes per lane straight into MFMA operands —
                                   weight gradients of the 4x4 stride-2 layers up to 256 positions per batch (dW written in its native
                                   layout), forward and input gradient of the 3x3 / 4x4 layers up to 32 positions
@@ -45,7 +47,7 @@ def _mode():
 def select(op, B, Cin, H, W, Cout, k, stride, pad, dil):
     """-> the engine for one convolution call.  (Cin, H, W) = the module's input, as in ipsr_conv2d.  Memoised per (mode, shape):
     the rules query the library (workspace probes), ~150 convolution calls per training step ask."""
-    return _select(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
+    return _select(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0") + os.environ.get("IPSR_NO_THIN", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
 
 
 @functools.lru_cache(maxsize=4096)
@@ -65,6 +67,8 @@ def _select(mode, _nosm, op, B, Cin, H, W, Cout, k, stride, pad, dil):
     if mode == "auto" and _is_k4s1(k, stride, pad, dil) and op in (ops.CONV_FWD, ops.CONV_BWD_DATA) \
             and cred % 16 == 0 and min(Cin, Cout) >= 128 and 16 <= H <= 128:
         return "wino_dil"        # netD's 4x4 stride-1 convolution: the same F(3x3,4x4) pipeline on the image itself
+    if mode == "auto" and _thin_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
+        return "thin"            # 3/6-channel side at full resolution: one pass over the wide tensor on the vector ALUs
     if mode == "auto" and _smallmap_data_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
         return "smallmap"        # innermost levels (<= 32 positions per batch): the weight tensor streamed once into MFMA operands
     if mode == "auto":
@@ -113,6 +117,20 @@ def _smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
         return B, Cin, Cout, H, W, Hy, Wy, k, stride, pad, dil
     Hy, Wy = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
     return B, Cout, Cin, Hy, Wy, H, W, k, stride, pad, dil
+
+
+def _thin_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """3x3 stride-1 layers with a 3- or 6-channel side on maps of >= 64x64 (profiles/r02_thin.txt, device time at 256x256, batch 8):
+    many -> few (VGG conv1_1 input gradient 185 -> 61 us, netG's last ConvTranspose2d forward 217 -> 130 us) and 3 -> many
+    (VGG conv1_1 forward 70 -> 52 us, and the bias + ReLU pass goes into the kernel); 6 -> 64 forward and the weight gradients
+    stay on MIOpen (87 vs 99 us; 134 vs 296 us)."""
+    if os.environ.get("IPSR_NO_THIN", "0") == "1":           # A/B switch
+        return False
+    if not (k == 3 and stride == 1 and pad == 1 and dil == 1) or H * W < 4096 or not ops.thin_supported(op, Cin, H, W, Cout):
+        return False
+    fwd = op in (ops.CONV_FWD, ops.CONVT_FWD)
+    i, o = (Cin, Cout) if fwd else (Cout, Cin)
+    return o in (3, 6) or i == 3
 
 
 def _smallmap_op(op):
@@ -186,6 +204,8 @@ class _HipConv(torch.autograd.Function):
             y = ops.conv2d(op, xc, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng_fwd == "wino_dil":
             y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+        elif eng_fwd == "thin":
+            y = ops.conv3x3_thin(op, xc, w, (B, Cin, H, W), Cout)
         elif eng_fwd == "smallmap":
             y = ops.conv_smallmap(_smallmap_op(op), xc, w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         elif eng_fwd == "wino_s2":
@@ -212,6 +232,8 @@ class _HipConv(torch.autograd.Function):
                 dx = ops.conv2d(op, dy, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
             elif eng == "wino_dil":
                 dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+            elif eng == "thin":
+                dx = ops.conv3x3_thin(op, dy, w, (B, Cin, H, W), Cout)
             elif eng == "smallmap":
                 dx = ops.conv_smallmap(_smallmap_op(op), dy, w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
             elif eng == "wino_s2":
@@ -276,6 +298,8 @@ def conv_nobias(m, x, weight=None):
             return ops.conv2d(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng == "wino_dil":
             return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+        elif eng == "thin":
+            return ops.conv3x3_thin(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout)
         elif eng == "smallmap":
             return ops.conv_smallmap(_smallmap_op(op), x.contiguous(), w.detach(), *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         elif eng == "wino_s2":

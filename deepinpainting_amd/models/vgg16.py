@@ -83,6 +83,7 @@ class Vgg16(torch.nn.Module):
           * Winograd F(4x4,3x3) (csrc/winograd.hip) where models/hipconv.py selects it, with the bias + ReLU (+ the 2x2
             max-pool when it follows) done in the kernel's output transform and the transformed filter cached per layer
             (the weights are frozen);
+          * conv1_1 (3 input channels at full resolution): csrc/thin_conv.hip, bias + ReLU in the same pass;
           * otherwise the convolution without bias (MIOpen has none; PyTorch would add it in a separate pass), then ONE pass
             for bias + ReLU (+ pool) — ops.bias_act_ / ops.bias_relu_pool2.
         Both are value-identical to Conv2d(bias) -> ReLU(inplace) -> MaxPool2d up to the convolution's own rounding."""
@@ -106,6 +107,11 @@ class Vgg16(torch.nn.Module):
                     x = ops.conv3x3_winograd(ops.CONV_FWD, x.contiguous(), m.weight, (B, Cin, H, W), m.out_channels, bias=m.bias,
                                              epilogue="relu_pool" if pool else "relu", filter_cache=cache[1], filter_cache_valid=valid)
                     i += 3 if pool else 2
+                    continue
+                if x.dtype == torch.float32 and not torch.is_autocast_enabled() and not pool and \
+                        hipconv.select(ops.CONV_FWD, B, Cin, H, W, m.out_channels, 3, 1, 1, 1) == "thin":
+                    x = ops.conv3x3_thin(ops.CONV_FWD, x.contiguous(), m.weight, (B, Cin, H, W), m.out_channels, bias=m.bias, relu=True)   # conv1_1
+                    i += 2
                     continue
                 y = hipconv.conv_nobias(m, x)
                 if pool:

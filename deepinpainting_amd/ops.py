@@ -487,6 +487,56 @@ def conv4x4s2_winograd(mode, a, b, B, Kc, Cf, nh, nw, out=None):
     return out
 
 
+def thin_supported(op, Cin, H, W, Cout):
+    """3x3 stride-1 pad-1 with 3 or 6 channels on one side (ipsr_conv3x3_thin): which side is thin depends on the operation."""
+    fwd = op in (CONV_FWD, CONVT_FWD)
+    i, o = (Cin, Cout) if fwd else (Cout, Cin)
+    if i in (3, 6) and o % 16 == 0 and o >= 16:
+        return True
+    return o in (3, 6) and W % 4 == 0 and i * o * 36 <= 48 * 1024 and i >= 16
+
+
+def conv3x3_thin(op, inp, weight, in_shape, Cout, bias=None, relu=False, out=None):
+    """k3 s1 p1 Conv2d / ConvTranspose2d forward or backward-data with a 3- or 6-channel side (ipsr_conv3x3_thin).  `in_shape` =
+    the module's input (B, Cin, H, W); `inp` is x for the forward ops and dy for the backward-data ops; bias / ReLU only few -> many."""
+    B, Cin, H, W = in_shape
+    inp = _req(inp, torch.float32, "input")
+    weight = _req(weight, torch.float32, "weight")
+    fwd = op in (CONV_FWD, CONVT_FWD)
+    I, O = (Cin, Cout) if fwd else (Cout, Cin)
+    if tuple(inp.shape) != (B, I, H, W):
+        raise RuntimeError("conv3x3_thin: input %s does not match %s" % (tuple(inp.shape), (B, I, H, W)))
+    so, si, flip = {CONV_FWD: (Cin * 9, 9, 0), CONV_BWD_DATA: (9, Cin * 9, 1), CONVT_FWD: (9, Cout * 9, 1), CONVT_BWD_DATA: (Cout * 9, 9, 0)}[op]
+    if out is None:
+        out = torch.empty((B, O, H, W), dtype=torch.float32, device=inp.device)
+    few2many = I in (3, 6) and O % 16 == 0
+    _lib.check(_lib.lib().ipsr_conv3x3_thin(0 if few2many else 1, inp.data_ptr(), weight.data_ptr(), _ptr(_f32(bias)) if bias is not None else None,
+                                            int(bool(relu)), out.data_ptr(), B, I, O, H, W, so, si, flip, _stream()), "ipsr_conv3x3_thin")
+    return out
+
+
+def conv3x3_thin_wrw(transposed, x, dy, out=None):
+    """Weight gradient of a k3 s1 p1 Conv2d ([Cout,Cin,3,3]) / ConvTranspose2d ([Cin,Cout,3,3]) with a 3- or 6-channel side."""
+    x = _req(x, torch.float32, "x")
+    dy = _req(dy, torch.float32, "dy")
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    wshape = (Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3)
+    big, small = (x, dy) if transposed else (dy, x)            # G[big ch][small ch] is the weight's own [dim0][dim1] only when dim0 is wide
+    Cb, Cs = big.shape[1], small.shape[1]
+    L = _lib.lib()
+    if Cs in (3, 6):
+        g = out if out is not None else torch.empty(wshape, dtype=torch.float32, device=x.device)
+        nbytes = L.ipsr_conv3x3_thin_wrw_workspace_bytes(B, Cb, Cs, H, W)
+        if nbytes == 0:
+            raise NotImplementedError("ipsr_conv3x3_thin_wrw: Cb=%d Cs=%d %dx%d is not implemented" % (Cb, Cs, H, W))
+        ws = _workspace(nbytes, x.device)
+        _lib.check(L.ipsr_conv3x3_thin_wrw(big.data_ptr(), small.data_ptr(), g.data_ptr(), B, Cb, Cs, H, W, ws.data_ptr(), ws.numel(), _stream()),
+                   "ipsr_conv3x3_thin_wrw")
+        return g
+    raise NotImplementedError("conv3x3_thin_wrw: the weight's first channel dimension must be the wide one (got %s)" % (wshape,))
+
+
 SM_DATA, SM_WRW, SM_FWD = 0, 1, 2
 
 

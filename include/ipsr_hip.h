@@ -283,6 +283,21 @@ size_t ipsr_conv_smallmap_workspace_bytes(int op, int B, int R, int Cq, int Ho, 
 int ipsr_conv_smallmap(int op, const float* a, const float* b, float* out, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf,
                        int k, int stride, int pad, int dil, void* ws, size_t ws_bytes, void* stream);
 
+/* The 3x3 stride-1 pad-1 layers with 3 or 6 channels on one side, at full resolution — VGG16 conv1_1 (models/vgg16.py:9), netG's
+ * first Conv2d 6 -> 64 (models/networks.py:300-312) and its last ConvTranspose2d 128 -> 3 (:255-259): one pass over the wide
+ * tensor on the vector ALUs (these are HBM streams, not matrix-core work).
+ *   out[b][o][y][x] = sum_i sum_t W[o*so + i*si + (flip ? 8-t : t)] * in[b][i][y+r-1][x+s-1]      (t = 3r+s)
+ *   op 0  few -> many: I in {3,6}, O % 16 == 0; optional bias [O] and ReLU (VGG)
+ *   op 1  many -> few: O in {3,6}, W % 4 == 0, I*O*36 bytes <= 48 KB; bias must be NULL, relu 0
+ * Conv2d forward: so = Cin*9, si = 9, flip 0; Conv2d backward-data: so = 9, si = Cin*9, flip 1 (o = ci, i = co);
+ * ConvTranspose2d forward: so = 9, si = Cout*9, flip 1; ConvTranspose2d backward-data: so = Cout*9, si = 9, flip 0.
+ * ipsr_conv3x3_thin_wrw: g[cb][cs][u][v] = sum_{b,y,x} big[b][cb][y][x] * small[b][cs][y+u-1][x+v-1] — the weight gradient of
+ * either module with big = the wide tensor of (x, dy) and small = the other (Cs in {3,6}, Cb even, W % 4 == 0). */
+int ipsr_conv3x3_thin(int op, const float* in, const float* w, const float* bias, int relu, float* out, int B, int I, int O, int H, int W,
+                      long so, long si, int flip, void* stream);
+size_t ipsr_conv3x3_thin_wrw_workspace_bytes(int B, int Cb, int Cs, int H, int W);
+int ipsr_conv3x3_thin_wrw(const float* big, const float* small, float* g, int B, int Cb, int Cs, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------
  * replaces InnerCos.forward (models/InnerCos.py:30-41) and InnerCos2.forward
  * (models/InnerCos2.py:34-46):  loss = mean_{b,c<Cuse,n} ((x[b,c,n]*mask[n])*strength - target)^2.

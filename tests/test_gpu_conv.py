@@ -263,6 +263,41 @@ def test_smallmap_engine_vs_fp64(kind, Ci, Co, H, W, k, st, pad, dil, B):
         assert _rel(yc, y64.detach()) <= 2e-5
 
 
+@pytest.mark.parametrize("kind,Ci,Co,H,W,B", [("conv", 3, 64, 32, 48, 2), ("conv", 6, 64, 20, 36, 3), ("convT", 128, 3, 24, 32, 2), ("convT", 32, 6, 9, 12, 1),
+                                              ("conv", 3, 16, 5, 7, 2), ("convT", 64, 3, 64, 256, 1)])
+def test_thin_3x3_layers_vs_fp64(kind, Ci, Co, H, W, B):
+    """ipsr_conv3x3_thin(_wrw): VGG conv1_1 (3 -> 64, + bias + ReLU), netG's first Conv2d (6 -> 64) and last ConvTranspose2d
+    (128 -> 3) — forward, input gradient and weight gradient on the vector ALUs, within 2e-5 of fp64; odd sizes, W % 4 == 0 where
+    the many -> few kernel requires it."""
+    from deepinpainting_amd import ops
+    g = torch.Generator().manual_seed(Ci * 11 + H)
+    tr = kind == "convT"
+    x = torch.randn(B, Ci, H, W, generator=g).cuda()
+    w = (torch.randn((Ci, Co, 3, 3) if tr else (Co, Ci, 3, 3), generator=g) * 0.1).cuda()
+    bias = torch.randn(Co, generator=g).cuda()
+    xd, wd = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True)
+    y64 = F.conv_transpose2d(xd, wd, None, 1, 1) if tr else F.conv2d(xd, wd, None, 1, 1)
+    dy = torch.randn(y64.shape, generator=g).cuda()
+    dx64, dw64 = torch.autograd.grad(y64, (xd, wd), dy.double().cpu())
+    fop, bop = (ops.CONVT_FWD, ops.CONVT_BWD_DATA) if tr else (ops.CONV_FWD, ops.CONV_BWD_DATA)
+    if ops.thin_supported(fop, Ci, H, W, Co):
+        y = ops.conv3x3_thin(fop, x, w, (B, Ci, H, W), Co)
+        assert _rel(y, y64.detach()) <= 2e-5
+        if not tr:          # few -> many with the VGG epilogue
+            yb = ops.conv3x3_thin(fop, x, w, (B, Ci, H, W), Co, bias=bias, relu=True)
+            assert _rel(yb, torch.relu(y64.detach() + bias.double().cpu().view(1, -1, 1, 1))) <= 2e-5
+    else:
+        assert W % 4 != 0
+    if ops.thin_supported(bop, Ci, H, W, Co):
+        dx = ops.conv3x3_thin(bop, dy, w, (B, Ci, H, W), Co)
+        assert _rel(dx, dx64) <= 2e-5
+    else:
+        assert W % 4 != 0
+    if W % 4 == 0:
+        dw = ops.conv3x3_thin_wrw(tr, x, dy)
+        assert tuple(dw.shape) == tuple(w.shape) and _rel(dw, dw64) <= 2e-5
+
+
 @pytest.mark.parametrize("engine", ["direct", "winograd", "auto"])
 def test_module_path_forward_and_gradients(engine):
     """models/hipconv.py: Conv2d / ConvTranspose2d modules through the dispatcher with one engine forced — output, input
@@ -274,7 +309,8 @@ def test_module_path_forward_and_gradients(engine):
              (nn.Conv2d(32, 32, 4, 2, 3, dilation=2), 16, 16), (nn.ConvTranspose2d(32, 16, 4, 2, 1), 8, 8), (nn.Conv2d(16, 32, 4, 2, 1), 16, 16),
              (nn.Conv2d(64, 128, 4, 2, 1), 32, 32), (nn.ConvTranspose2d(128, 64, 4, 2, 1), 16, 16), (nn.Conv2d(128, 256, 4, 1, 1), 16, 16),
              (nn.Conv2d(256, 256, 4, 2, 1), 4, 4), (nn.ConvTranspose2d(256, 256, 4, 2, 1), 2, 2), (nn.Conv2d(256, 256, 3, 1, 1), 2, 2),
-             (nn.ConvTranspose2d(512, 256, 3, 1, 1), 2, 2), (nn.Conv2d(256, 256, 4, 2, 3, dilation=2), 4, 4)]
+             (nn.ConvTranspose2d(512, 256, 3, 1, 1), 2, 2), (nn.Conv2d(256, 256, 4, 2, 3, dilation=2), 4, 4),
+             (nn.Conv2d(3, 64, 3, 1, 1), 64, 64), (nn.ConvTranspose2d(128, 3, 3, 1, 1), 64, 64)]
     hipconv._FORCE = engine
     try:
         for m, H, W in cases:
@@ -304,7 +340,9 @@ def test_dispatcher_rules_and_refusals():
     assert sel(ops.CONV_FWD, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd"          # VGG conv4_x / netG level 32x32
     assert sel(ops.CONVT_BWD_DATA, 8, 1024, 32, 32, 256, 3, 1, 1, 1) == "winograd"
     assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 3, 1, 1, 1) == "miopen"            # 64 -> 64 at 256x256: traffic-bound, MIOpen wins
-    assert sel(ops.CONV_FWD, 8, 3, 256, 256, 64, 3, 1, 1, 1) == "miopen"             # 3 input channels
+    assert sel(ops.CONV_FWD, 8, 3, 256, 256, 64, 3, 1, 1, 1) == "thin"               # VGG conv1_1: vector-ALU pass
+    assert sel(ops.CONV_BWD_DATA, 8, 3, 256, 256, 64, 3, 1, 1, 1) == "thin" and sel(ops.CONVT_FWD, 8, 128, 256, 256, 3, 3, 1, 1, 1) == "thin"
+    assert sel(ops.CONV_FWD, 8, 6, 256, 256, 64, 3, 1, 1, 1) == "miopen"             # 6 -> 64: MIOpen is faster
     assert sel(ops.CONV_FWD, 8, 512, 4, 4, 512, 3, 1, 1, 1) == "miopen"              # tiny maps
     assert sel(ops.CONV_BWD_DATA, 8, 512, 32, 32, 512, 4, 2, 3, 2) == "wino_dil"         # netG dilated down convolution
     assert sel(ops.CONV_FWD, 8, 128, 128, 128, 128, 4, 2, 3, 2) == "wino_dil"
