@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libipsr_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 
@@ -81,6 +81,8 @@ SIGNATURES = {
     "ipsr_profile_read": (c_int, [c_void_p, c_int]),
     "ipsr_profile_read_region": (c_int, [c_int, c_void_p, c_int]),
     "ipsr_profile_read_region_work": (c_int, [c_int, c_void_p, c_void_p, c_int]),
+    "ipsr_wino_gemm_split": (c_int, [c_int, c_int, c_int, c_void_p]),
+    "ipsr_debug_force_wino_split": (c_int, [c_int, c_int, c_int]),
 }
 
 

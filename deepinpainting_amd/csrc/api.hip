@@ -127,7 +127,7 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 9; }
+int ipsr_abi_version(void) { return 10; }
 
 const char* ipsr_last_error(void) { return g_err; }
 

@@ -508,13 +508,15 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
 //    fill the tail evenly: whole convolution -14 % (512@32x32), -23 % (1024 -> 256 @32x32), -10 % (512 -> 128 @64x64).
 //  * small grids with short reductions (<= 144 workgroups, <= 32 stages) stay uncut: the cut shortens the GEMM by 3-8 us and
 //    costs the output transform 10 us per extra slab on a map with that few tiles.
+static int g_force_split[3] = {0, 0, 0};                     // ipsr_debug_force_wino_split: {nsplit, xi_split, nsplit_t}, 0 = automatic
+
 static WinoSplit wino_choose_split(int tiles36, int stages, size_t m_bytes)
 {
     const int tiles = tiles36 / 36;
     WinoSplit best{1, stages, 36, 1, stages};
-    if (const char* f = getenv("IPSR_WINO_SPLIT")) {         // tuning aid: "nsplit,xi_split,nsplit_t"
-        int a = 1, x = 36, b = 1;
-        if (sscanf(f, "%d,%d,%d", &a, &x, &b) == 3 && a >= 1 && b >= 1 && x >= 1 && x <= 36 && a <= stages && b <= stages) {
+    if (g_force_split[0] > 0) {                              // tuning aid (tools/sweep_wino_split.py), off unless asked for
+        const int a = g_force_split[0], x = g_force_split[1], b = g_force_split[2];
+        if (a <= stages && b <= stages) {
             const int pa = cdiv(stages, a), pb = cdiv(stages, b);
             return WinoSplit{cdiv(stages, pa), pa, x, cdiv(stages, pb), pb};
         }
@@ -1695,6 +1697,23 @@ int launch_smallmap(int op, const float* a, const float* b2, float* out, int B, 
 using namespace ipsr;
 
 extern "C" {
+
+int ipsr_debug_force_wino_split(int nsplit, int xi_split, int nsplit_t)
+{
+    if (nsplit == 0 && xi_split == 0 && nsplit_t == 0) { g_force_split[0] = g_force_split[1] = g_force_split[2] = 0; return IPSR_OK; }
+    if (nsplit < 1 || nsplit_t < 1 || xi_split < 1 || xi_split > 36) return fail(IPSR_ERR_INVALID, "ipsr_debug_force_wino_split: bad split %d,%d,%d", nsplit, xi_split, nsplit_t);
+    g_force_split[0] = nsplit; g_force_split[1] = xi_split; g_force_split[2] = nsplit_t;
+    return IPSR_OK;
+}
+
+int ipsr_wino_gemm_split(int rows, int cols, int reduction, int* out5)
+{
+    if (!out5 || rows < 1 || cols < 1 || reduction < 1 || rows % WG_BM || cols % WG_BN || reduction % WG_BK)
+        return fail(IPSR_ERR_INVALID, "ipsr_wino_gemm_split: rows / cols must be multiples of 128 and the reduction of 16");
+    const WinoSplit sp = wino_choose_split(36 * (rows / WG_BM) * (cols / WG_BN), reduction / WG_BK, (size_t)36 * rows * cols * 4);
+    out5[0] = sp.nsplit; out5[1] = sp.sps; out5[2] = sp.xi_split; out5[3] = sp.nsplit_t; out5[4] = sp.sps_t;
+    return IPSR_OK;
+}
 
 size_t ipsr_conv3x3_winograd_workspace_bytes(int op, int B, int Cin, int H, int W, int Cout)
 {

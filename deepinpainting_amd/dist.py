@@ -72,15 +72,24 @@ def broadcast_module(module, src=0, group=None):
 
 
 # Gradient sinks: parameter storage pointer -> its slice of an armed bucket.  A kernel that produces a weight gradient can write it
-# THERE (models/hipconv.py does for the Winograd weight-gradient kernels): autograd then adopts that tensor as .grad and the
-# reducer finds the gradient already in place — no copy into the bucket for that parameter.
+# THERE (models/hipconv.py does for the Winograd / small-map weight-gradient kernels).  Ownership is HANDED OVER: `grad_sink_for`
+# pops the entry and returns the only reference to that view, so
+#   * autograd's AccumulateGrad sees a tensor nobody else references and adopts it as .grad instead of cloning it (it clones whenever
+#     another reference exists) — the reducer then finds the gradient already in its slice and copies nothing;
+#   * a SECOND backward node of the same parameter inside one graph (netD / netF are applied to the fake and the real batch in one
+#     backward_D, models/IPSR.py:187-206) gets None, writes a tensor of its own, and autograd adds the two: handing the same slice
+#     out twice would make the second kernel overwrite the first result and autograd sum two aliases of it (2 x dW_second).
 _GRAD_SINKS = {}
+SINK_STATS = {"handed": 0, "copied": 0, "in_place": 0}      # test / diagnostics counters (per process)
 
 
 def grad_sink_for(param_data_ptr, shape):
-    """The bucket slice a gradient of this parameter should be written into right now, or None."""
-    v = _GRAD_SINKS.get(param_data_ptr)
-    return v if (v is not None and tuple(v.shape) == tuple(shape)) else None
+    """The bucket slice a gradient of this parameter should be written into right now, or None.  At most once per arm()."""
+    v = _GRAD_SINKS.pop(param_data_ptr, None)
+    if v is None or tuple(v.shape) != tuple(shape):
+        return None
+    SINK_STATS["handed"] += 1
+    return v
 
 
 _SLOT_ALIGN = 64        # floats: every parameter's slice of a bucket starts on a 256-byte boundary (the weight-gradient kernels
@@ -186,7 +195,10 @@ class GradBucketReducer(object):
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
+            else:
+                SINK_STATS["in_place"] += 1
         if dst:
+            SINK_STATS["copied"] += len(dst)
             torch._foreach_copy_(dst, src)
         flat.mul_(1.0 / self.world)          # the mean's scaling happens here, under the backward, not after the wait
         self._work.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), views))

@@ -60,6 +60,13 @@ class IPSRFunction(torch.autograd.Function):
         return grad_input, None, None, None, None, None, None, None, None, None, None, None
 
 
+# Test hook: callable(bwd_index [B, ints] int32 device tensor) -> the tensor the backward should use instead.  The backward's
+# only input besides the gradient is this sparse trunc(kbar); a test that wants two runs to share ONE truncation (DESIGN.md §6:
+# an ulp in a 512-long dot product switches a whole gradient column on or off) records it in the first run and replays it in
+# the second, or replays the reference's own (tests/golden/trainer_step.npz).  None (always, outside those tests) = untouched.
+bwd_index_hook = None
+
+
 class IPSRFunctionDeviceCounts(torch.autograd.Function):
     """The same layer with the masked positions described ON THE DEVICE: `mpi32` [Mcap] (one index for the batch) or
     [B,Mcap] (one row per sample) and `counts` [B] int32 — what IPSR_model uses internally (include/ipsr_hip.h,
@@ -75,6 +82,8 @@ class IPSRFunctionDeviceCounts(torch.autograd.Function):
                         want_index=ctx.needs_input_grad[0], counts=counts)
         ctx.Mcap, ctx.shift_sz, ctx.triple_w = int(mpi32.size(-1)), int(shift_sz), triple_w
         ctx.bwd_index, ctx.ind, ctx.vmax = f.bwd_index, f.ind, f.vmax
+        if bwd_index_hook is not None and f.bwd_index is not None:
+            ctx.bwd_index = bwd_index_hook(f.bwd_index)
         return f.out
 
     @staticmethod

@@ -43,11 +43,23 @@ class IPSR_model(nn.Module):
         self.mask = None
         self.ref = None
         self._index_shape = None
+        self._flag32 = self._mpi32 = self._counts = None
+        self._host_index = None
+        self._mask_src = None           # (tensor, version, layer_to_last, threshold) of the last set_mask: an unchanged mask keeps its index
+        # capacity of the device-side index (columns of mask_point_idx handed to the kernels; everything the layer sizes by M —
+        # compressed attention, backward CSR, LDS of the compress kernel — is sized by it):
+        #   "auto"  the largest per-sample count, rounded up to 32: ONE host read per NEW mask (set_mask with the same, unmodified
+        #           mask tensor keeps the index and costs nothing);   "full"  N, never a host read;   int  caller-supplied bound
+        self.index_capacity = "auto"
 
     def set_mask(self, mask_global, layer_to_last, threshold, feat_mask=None):
         """reference :30-33.  `feat_mask` (optional, [1,1,h,w] byte) lets the trainer share ONE
         cal_feat_mask result between this layer and the two InnerCos modules (the reference computes
         the same pyramid three times per set_input, models/IPSR.py:155-158)."""
+        src = self._mask_src
+        if feat_mask is None and src is not None and src[0] is mask_global and src[1] == mask_global._version \
+                and src[2:] == (layer_to_last, threshold) and self.mask is not None:
+            return self.mask                 # same mask tensor, not modified since: the feature mask and the index stand
         if feat_mask is not None:
             mask = feat_mask
         elif mask_global.size(0) > 1:
@@ -56,6 +68,7 @@ class IPSR_model(nn.Module):
             mask = util.cal_feat_mask(mask_global, layer_to_last, threshold)
         self.mask = mask[:, 0] if mask.size(0) > 1 else mask.squeeze()      # [h,w], or [B,h,w] with per-sample masks
         self.cal_fixed_flag = True
+        self._mask_src = (mask_global, mask_global._version, layer_to_last, threshold) if feat_mask is None else None
         return self.mask
 
     def set_ref(self, latent_ref):
@@ -71,11 +84,22 @@ class IPSR_model(nn.Module):
         return (torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), torch.cat([o[2] for o in outs]))
 
     def _ensure_index(self, input):
-        if self.cal_fixed_flag or self._index_shape != (self.h, self.w):
+        # the device index and the reference-surface (CPU) index are cached separately: a CPU forward must not pass for a valid
+        # device index at the same (h, w), nor an index built on another device
+        if self.cal_fixed_flag or self._index_shape != (self.h, self.w) or self._flag32 is None or self._flag32.device != input.device:
             assert self.mask is not None, 'set_mask() must be called before forward()'
-            self._flag32, self._mpi32, self._counts = self._index_rows(self.mask)
+            mask = self.mask if self.mask.device == input.device else self.mask.to(input.device)
+            flag32, mpi32, counts = self._index_rows(mask)
             n_win = (self.h - int(self.shift_sz) + 1) * (self.w - int(self.shift_sz) + 1)
-            assert self._flag32.size(1) == n_win, 'mask %s does not match a %dx%d feature' % (tuple(self.mask.shape), self.h, self.w)
+            assert flag32.size(1) == n_win, 'mask %s does not match a %dx%d feature' % (tuple(self.mask.shape), self.h, self.w)
+            cap = self.index_capacity
+            if cap == "auto":
+                cap = int(counts.max().item())      # one host read per new mask, off the per-forward path
+            elif cap == "full":
+                cap = n_win
+            cap = min(n_win, max(32, (int(cap) + 31) // 32 * 32))
+            self._flag32, self._counts = flag32, counts
+            self._mpi32 = mpi32[:, :cap].contiguous()          # entries past counts[b] are never read; the kernels size by `cap`
             self._host_index = None                 # the reference-surface tensors are rebuilt lazily
             self.cal_fixed_flag = False
             self._index_shape = (self.h, self.w)
@@ -129,10 +153,10 @@ class IPSR_model(nn.Module):
         tensor gets (the oracle-backed twin patches IPSRFunction for that) — the GPU path above is the same computation."""
         if self.mask.dim() == 3:
             raise NotImplementedError("per-sample masks need the GPU path")
-        if self.cal_fixed_flag or self._index_shape != (self.h, self.w):
+        if self.cal_fixed_flag or self._index_shape != (self.h, self.w) or self._flag32 is not None or self._host_index is None:
             latter = input.narrow(0, 0, 1).detach()
             self._host_index = [util.cal_mask_given_mask_thred(latter.squeeze(0), self.mask, self.shift_sz, self.stride, self.mask_thred)]
-            self._flag32 = None
+            self._flag32 = self._mpi32 = self._counts = None     # the device index (if any) is stale now: _ensure_index rebuilds it
             self.cal_fixed_flag = False
             self._index_shape = (self.h, self.w)
         if not (torch.is_tensor(self.sp_x) or torch.is_tensor(self.sp_y)):

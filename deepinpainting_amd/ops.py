@@ -506,9 +506,16 @@ def conv3x3_thin(op, inp, weight, in_shape, Cout, bias=None, relu=False, out=Non
     I, O = (Cin, Cout) if fwd else (Cout, Cin)
     if tuple(inp.shape) != (B, I, H, W):
         raise RuntimeError("conv3x3_thin: input %s does not match %s" % (tuple(inp.shape), (B, I, H, W)))
+    want_w = (Cout, Cin, 3, 3) if op in (CONV_FWD, CONV_BWD_DATA) else (Cin, Cout, 3, 3)
+    if tuple(weight.shape) != want_w:
+        raise RuntimeError("conv3x3_thin op %d: weight %s does not match %s" % (op, tuple(weight.shape), want_w))
+    if not thin_supported(op, Cin, H, W, Cout):
+        raise NotImplementedError("conv3x3_thin op %d: Cin=%d Cout=%d %dx%d is not a thin-layer shape" % (op, Cin, Cout, H, W))
     so, si, flip = {CONV_FWD: (Cin * 9, 9, 0), CONV_BWD_DATA: (9, Cin * 9, 1), CONVT_FWD: (9, Cout * 9, 1), CONVT_BWD_DATA: (Cout * 9, 9, 0)}[op]
     if out is None:
         out = torch.empty((B, O, H, W), dtype=torch.float32, device=inp.device)
+    elif tuple(out.shape) != (B, O, H, W) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != inp.device:
+        raise RuntimeError("conv3x3_thin: `out` must be a contiguous fp32 %s tensor on %s" % ((B, O, H, W), inp.device))
     few2many = I in (3, 6) and O % 16 == 0
     _lib.check(_lib.lib().ipsr_conv3x3_thin(0 if few2many else 1, inp.data_ptr(), weight.data_ptr(), _ptr(_f32(bias)) if bias is not None else None,
                                             int(bool(relu)), out.data_ptr(), B, I, O, H, W, so, si, flip, _stream()), "ipsr_conv3x3_thin")

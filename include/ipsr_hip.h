@@ -333,6 +333,16 @@ int ipsr_profile_read_region(int region, float* ms /*[host]*/, int max_n);
  * 256 x capacity launches); `work` receives the flop count (2 x 36 x rows x columns x reduction, padded sizes) of each launch. */
 int ipsr_profile_read_region_work(int region, float* ms /*[host]*/, double* work /*[host]*/, int max_n);
 
+/* How the reduction of the 36 Winograd GEMMs of a layer is cut over workgroups (csrc/winograd.hip, wino_choose_split): for a GEMM
+ * of `rows` x `cols` (multiples of 128: produced channels x tiles, padded) with `reduction` (multiple of 16) terms,
+ * out5 = {nsplit, stages per range, xi_split, nsplit_tail, stages per tail range}: the GEMMs of points xi < xi_split run in
+ * `nsplit` ranges, the others in `nsplit_tail`.  Pure function; the parity tests use it to prove that both the uniform and the
+ * head / tail cut are exercised.  ipsr_debug_force_wino_split(nsplit, xi_split, nsplit_tail) overrides the rule for every
+ * following call in this process (tuning aid of tools/sweep_wino_split.py; (0,0,0) restores the rule) — with the measurement
+ * hook above the only global state of the library, and like it off by default. */
+int ipsr_wino_gemm_split(int rows, int cols, int reduction, int* out5 /*[host]*/);
+int ipsr_debug_force_wino_split(int nsplit, int xi_split, int nsplit_tail);
+
 #ifdef __cplusplus
 }
 #endif

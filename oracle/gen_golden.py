@@ -427,12 +427,31 @@ def run_trainer_case(name):
     for i, net in enumerate((model.netG, model.netP, model.netD, model.netF, model.vgg)):
         reinit_deterministic(net, 500 + i)
     img, mask, ref = trainer_inputs()
+    # the reference keeps kbar in a LongTensor (models/IPSRFunction.py:36,134): capture what ITS forward stored for the
+    # backward (ctx.ind_lst) — the truncation that decides which gradient columns exist upstream of the layer
+    import models.IPSRFunction as rF
+    captured = []
+    orig_forward = rF.IPSRFunction.forward
+
+    def capturing_forward(ctx, *a, **k):
+        out = orig_forward(ctx, *a, **k)
+        captured.append(ctx.ind_lst.detach().clone())
+        return out
+    rF.IPSRFunction.forward = staticmethod(capturing_forward)
     model.set_input(img, mask, ref)
     model.set_ref_latent()
     model.set_gt_latent()
     model.optimize_parameters()
     errs = model.get_current_errors()
+
+    def sparse_kbar(t):
+        kb = t[0].reshape(t.shape[1], -1)                           # [N (patch k), N (position q)] int64
+        kk, qq = torch.nonzero(kb, as_tuple=True)
+        return kk.numpy().astype(np.int32), qq.numpy().astype(np.int32), kb[kk, qq].numpy().astype(np.int32), np.int64(kb.shape[0])
+    assert len(captured) == 1                                       # one layer forward per optimize_parameters
+    k1 = sparse_kbar(captured[0])
     d = dict(
+        kbar_k=k1[0], kbar_q=k1[1], kbar_v=k1[2], kbar_n=k1[3],
         errors=np.array([errs['G_GAN'], errs['G_L1'], errs['D'], errs['F']], np.float64),
         ng_loss=np.array([float(model.ng_loss_value), float(model.ng_loss_value2)], np.float64),
         loss_G=np.float64(model.loss_G.item()), loss_D=np.float64(model.loss_D.item()),
@@ -455,8 +474,12 @@ def run_trainer_case(name):
     model.set_ref_latent()
     model.set_gt_latent()
     model.optimize_parameters()
+    rF.IPSRFunction.forward = staticmethod(orig_forward)
     e2 = model.get_current_errors()
     d["errors_iter2"] = np.array([e2['G_GAN'], e2['G_L1'], e2['D'], e2['F']], np.float64)
+    assert len(captured) == 2
+    k2 = sparse_kbar(captured[1])
+    d.update(kbar2_k=k2[0], kbar2_q=k2[1], kbar2_v=k2[2])
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **d)
     print("%-28s -> %s (%.1f KB)  errors=%s" % (name, os.path.relpath(path), os.path.getsize(path) / 1024.0, dict(errs)))
@@ -479,6 +502,14 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "patch":          # only the shift_sz > 1 fixtures
         _install_cpu_aliases()
         patch_cases(_import_reference())
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":        # only the trainer-step fixture (same seeds / thread count as the full run)
+        _install_cpu_aliases()
+        _import_reference()
+        torch.manual_seed(0)
+        torch.set_num_threads(4)
+        os.makedirs(OUT, exist_ok=True)
+        run_trainer_case(sys.argv[2] if len(sys.argv) > 2 else "trainer_step")
         return
     _install_cpu_aliases()
     R = _import_reference()

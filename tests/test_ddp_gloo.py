@@ -103,6 +103,88 @@ def test_bucketed_allreduce_world2(tmp_path):
         assert torch.equal(a, b)
 
 
+class _SinkLinear(torch.autograd.Function):
+    """y = x @ w^T whose weight gradient is written where models/hipconv.py's kernels write theirs: into the armed bucket slice
+    handed out by dist.grad_sink_for (out=sink OVERWRITES, like the HIP weight-gradient kernels), else into a fresh tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from deepinpainting_amd import dist as idist
+        x, w = ctx.saved_tensors
+        sink = idist.grad_sink_for(w.data_ptr(), w.shape)
+        dw = sink if sink is not None else torch.empty_like(w)
+        torch.mm(dy.t(), x, out=dw)
+        return dy @ w, dw
+
+
+def _sink_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from deepinpainting_amd import dist as idist
+    idist.init_distributed(backend="gloo")
+    torch.manual_seed(7)
+    once = nn.Linear(6, 5, bias=False)          # applied once per backward  (netG / netP layers)
+    twice = nn.Linear(5, 5, bias=False)         # applied to two batches in ONE graph (netD / netF in backward_D)
+    red = idist.GradBucketReducer([once, twice], bucket_bytes=1 << 20)
+    torch.manual_seed(50 + rank)
+    xa, xb = torch.randn(4, 6), torch.randn(4, 6)
+    out = {}
+    for step in range(2):                        # second step: .grad starts as None again (zero_grad(set_to_none=True))
+        for p in list(once.parameters()) + list(twice.parameters()):
+            p.grad = None
+        idist.SINK_STATS.update(handed=0, copied=0, in_place=0)
+        red.arm()
+        ha, hb = _SinkLinear.apply(xa, once.weight), _SinkLinear.apply(xb, once.weight.detach())
+        loss = (_SinkLinear.apply(ha, twice.weight) * 1.5).pow(2).mean() + _SinkLinear.apply(hb, twice.weight).pow(2).mean()
+        loss.backward()
+        flat = red.buckets[0]["flat"]
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        inside = [lo <= p.grad.data_ptr() < hi for p in (once.weight, twice.weight)]
+        stats_before_finish = dict(idist.SINK_STATS)
+        red.finish()
+        out["step%d" % step] = dict(g_once=once.weight.grad.clone(), g_twice=twice.weight.grad.clone(), inside=inside,
+                                    stats=dict(idist.SINK_STATS), stats_before_finish=stats_before_finish)
+    # what plain autograd gives on this rank's data
+    once.weight.grad = twice.weight.grad = None
+    ha, hb = xa @ once.weight.t(), xb @ once.weight.detach().t()
+    ((ha @ twice.weight.t() * 1.5).pow(2).mean() + (hb @ twice.weight.t()).pow(2).mean()).backward()
+    out["local"] = dict(g_once=once.weight.grad.clone(), g_twice=twice.weight.grad.clone())
+    torch.save(out, os.path.join(out_dir, "sink_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradient_sinks_hand_over_ownership_and_survive_a_module_applied_twice(tmp_path):
+    """A weight gradient written into its bucket slice (what the HIP weight-gradient kernels do under DDP) must (a) BE the
+    parameter's .grad afterwards — autograd adopts the tensor, the reducer copies nothing for it — and (b) stay correct when the
+    module is applied twice in one graph (netD / netF in backward_D): the slice is handed out once, the second backward node
+    writes its own tensor and autograd adds the two.  The exchanged result is compared with the true mean of the ranks' plain
+    autograd gradients."""
+    world, port = 2, _free_port()
+    mp.spawn(_sink_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "sink_rank%d.pt" % r)) for r in range(world)]
+    for key in ("g_once", "g_twice"):
+        want = (res[0]["local"][key] + res[1]["local"][key]) / 2
+        for r in range(world):
+            for step in ("step0", "step1"):
+                torch.testing.assert_close(res[r][step][key], want, rtol=1e-5, atol=1e-7)
+    for r in range(world):
+        for step in ("step0", "step1"):
+            st = res[r][step]
+            # applied once: the kernel's output IS .grad (adopted, not cloned) and the reducer copies nothing for it
+            assert st["inside"][0], "a sink-written gradient does not live in its bucket slice"
+            assert st["stats_before_finish"]["handed"] == 2          # one hand-over per parameter, not per backward node
+            # applied twice: autograd sums the two nodes' tensors where it likes; that sum is copied in iff it is not in the slice
+            assert st["stats"]["copied"] == (0 if st["inside"][1] else 1), st["stats"]
+            assert st["stats"]["in_place"] == 2 - st["stats"]["copied"], st["stats"]
+
+
 def test_single_process_reducer_is_inert():
     sys.path.insert(0, ROOT)
     from deepinpainting_amd import dist as idist

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Time the Winograd GEMM of one 3x3 layer under a forced reduction split (IPSR_WINO_SPLIT="nsplit,xi_split,nsplit_t", read by
-wino_choose_split at every call) — the measurements behind the head/tail rule of csrc/winograd.hip.
+"""Time the Winograd GEMM of one 3x3 layer under a forced reduction split (ipsr_debug_force_wino_split(nsplit, xi_split, nsplit_t),
+honoured by wino_choose_split at every call) — the measurements behind the head/tail rule of csrc/winograd.hip.
 
     python tools/sweep_wino_split.py --shape 512,32,512 --splits 1,36,1 1,32,2 1,32,4 2,36,1
 """
@@ -30,10 +30,7 @@ def main():
         x = torch.randn(B, Cin, H, H, device="cuda")
         w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
         for sp in a.splits:
-            if sp == "auto":
-                os.environ.pop("IPSR_WINO_SPLIT", None)
-            else:
-                os.environ["IPSR_WINO_SPLIT"] = sp
+            _lib.check(lib.ipsr_debug_force_wino_split(*((0, 0, 0) if sp == "auto" else map(int, sp.split(",")))), "ipsr_debug_force_wino_split")
             for _ in range(3):
                 ops.conv3x3_winograd(ops.CONV_FWD, x, w, (B, Cin, H, H), Cout)
             torch.cuda.synchronize()
@@ -49,6 +46,7 @@ def main():
             k = lib.ipsr_profile_read_region_work(3, ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(work, ctypes.c_void_p), n)
             lib.ipsr_profile_enable(0)
             g = statistics.median(ms[i] for i in range(k))
+            lib.ipsr_debug_force_wino_split(0, 0, 0)
             print("%-14s split %-8s  GEMM %.4f ms (%.1f TF)   whole conv %.4f ms" % (shp, sp, g, work[0] / g / 1e9, e0.elapsed_time(e1) / a.iters), flush=True)
 
 
