@@ -249,7 +249,16 @@ def main():
     ap.add_argument("--rccl-algo", default=None, help="NCCL_ALGO for the gradient all-reduce (default: RCCL's tuner)")
     ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO (e.g. Simple)")
     ap.add_argument("--rccl-min-channels", default=None, help="NCCL_MIN_NCHANNELS")
+    ap.add_argument("--conv-math", choices=("fp32", "bf16x6", "bf16x3"), default="fp32",
+                    help="arithmetic of the Winograd convolution GEMMs for fp32 activations (default fp32 = the reference's; the split-bf16 "
+                         "forms are reported as what they are, never as the headline)")
+    ap.add_argument("--debug-opt", action="append", default=[], help="key=value for ipsr_debug_set_option (kernel-variant A/B; never set by default)")
     args = ap.parse_args()
+    if args.debug_opt:
+        from deepinpainting_amd import _lib as _dbg_lib
+        for kv in args.debug_opt:
+            k, v = map(int, kv.split("="))
+            _dbg_lib.check(_dbg_lib.lib().ipsr_debug_set_option(k, v), "ipsr_debug_set_option")
 
     from deepinpainting_amd import _lib, dist as idist
     from deepinpainting_amd.models.models import create_model
@@ -269,7 +278,7 @@ def main():
     torch.backends.cudnn.benchmark = os.environ.get("IPSR_BENCH_MIOPEN_FIND", "0") == "1"
 
     opt = Option(gpu_ids=[local_rank], batchSize=args.batch, use_dropout=True, quiet=True, allow_random_vgg=True,
-                 batch_vgg=os.environ.get("IPSR_BENCH_BATCH_VGG", "0") == "1", amp_bf16=(args.dtype == "bf16"),
+                 batch_vgg=os.environ.get("IPSR_BENCH_BATCH_VGG", "0") == "1", amp_bf16=(args.dtype == "bf16"), conv_math=args.conv_math,
                  checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
     torch.manual_seed(1234)                       # identical init on every rank (rank 0 is broadcast anyway)
     model = quiet(create_model, opt)
@@ -404,6 +413,7 @@ def main():
                    ("BASELINE config 5 (NOT the headline metric): as config 2 with the convolutions under bf16 autocast, "
                     "IPSR layer / InnerCos / losses fp32, batch %d/GPU" % args.batch),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "dropout": True,
+                   "conv_math": (args.conv_math if args.dtype == "f32" else "bf16x3 (Winograd operands split hi + lo on the bf16 MFMA, fp32 accumulate)"),
                    "vgg16": "seeded random init (no pretrained weights offline)"},
         "ipsr_layer_ms": {"forward": round(fwd_ms, 4), "backward": round(bwd_ms, 4), "total": round(fwd_ms + bwd_ms, 4),
                           "shape": "[%d,%d,%d,%d], M=256" % (BATCH, C_FEAT, H_FEAT, H_FEAT),

@@ -72,6 +72,9 @@ struct ProfileScope {
     ~ProfileScope() { profile_mark_stop(st, region); }
 };
 
+static int g_debug_opt[16] = {0};
+int debug_option(int key) { return (key >= 0 && key < 16) ? g_debug_opt[key] : 0; }
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 struct FwdPlan {
@@ -128,6 +131,13 @@ using namespace ipsr;
 extern "C" {
 
 int ipsr_abi_version(void) { return 10; }
+
+int ipsr_debug_set_option(int key, int value)
+{
+    if (key < 0 || key >= 16) return fail(IPSR_ERR_INVALID, "ipsr_debug_set_option: key %d outside [0, 16)", key);
+    g_debug_opt[key] = value;
+    return IPSR_OK;
+}
 
 const char* ipsr_last_error(void) { return g_err; }
 

@@ -18,6 +18,9 @@ int check_launch(const char* what);
 void profile_mark_start(hipStream_t st, int region = 0);
 void profile_mark_stop(hipStream_t st, int region = 0, double work = 0.0);
 
+// tuning switches (ipsr_debug_set_option in ipsr_hip.h): A/B aids, every key defaults to the shipped behaviour
+int debug_option(int key);
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -46,6 +49,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned wg, unsigned nwg)
     const unsigned xcd = wg & 7u, slot = wg >> 3;
     const unsigned start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
     return start + slot;
+}
+
+// 2-D grids of the transform kernels, blockIdx = (tile block, channel): the dispatcher deals consecutive linear block ids to
+// different XCDs, so with few tile blocks per channel every XCD ends up writing a fixed 1-KB slot of every row of the operand
+// planes.  remap2d hands each XCD a CONTIGUOUS range of (channel, tile block) instead: whole rows per XCD.
+__device__ __forceinline__ void remap2d(bool on, unsigned& bx, unsigned& by)
+{
+    bx = blockIdx.x; by = blockIdx.y;
+    if (on) {
+        const unsigned L = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+        by = L / gridDim.x; bx = L - by * gridDim.x;
+    }
 }
 
 // k-split partial (max, argmax) of the correlation kernel, merged on the fly by their consumers.

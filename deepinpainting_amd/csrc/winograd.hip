@@ -22,6 +22,8 @@
 //
 // Numerics: the standard interpolation points (0, +-1, +-2, inf); fp32 error ~4e-6 of the output scale at 512 channels
 // (tests/test_gpu_conv.py measures it per shape against an fp64 convolution).
+#include <type_traits>
+
 #include "ipsr_common.h"
 
 namespace ipsr {
@@ -114,12 +116,127 @@ __device__ __forceinline__ void wino_at3(const float m[6], float y[3])       // 
     y[2] = m[1] + m[2] + 4.0f * m[3] + 4.0f * m[4] + m[5];
 }
 
-// U[xi][c][k], k < Kp (zero beyond K), from W[c*sc + k*sm + r*3 + s] (flip: r -> 2-r, s -> 2-s)
-__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ W, int C, int K, int Kp, long sc, long sm, int flip,
-                                                          float* __restrict__ U)
+// ---------------------------------------------------------------------------------------------------
+// SPLIT operands for the bf16 matrix cores (BASELINE config 5: "CDNA4 bf16 MFMA for ... convs"; also an opt-in arithmetic for
+// the fp32 nets).  F(4x4,3x3) amplifies rounding ~100x (transform coefficients up to 8 and 1/24 with heavy cancellation in
+// A^T M A), so operands merely ROUNDED to bf16 would leave 3-6 % error in the output.  Instead every transformed operand value
+// v is stored as NPL bf16 numbers whose sum is v to 2^-16 (NPL = 2: hi + lo) or 2^-24 (NPL = 3: hi + mid + lo), and the GEMM
+// multiplies the planes pairwise on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//      NPL = 2:  hi*hi + hi*lo + lo*hi                               3 MFMAs of 32 cycles per 16 channels (fp32: 8 x 64 cycles)
+//      NPL = 3:  hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi   6 MFMAs, every dropped term <= 2^-24 of the product
+// Layout: the bf16 MFMA wants 8 consecutive reduction indices per lane, so an operand is stored
+//      Op[xi][plane][red / 8][row][8]      (red = the GEMM's reduction index: channel, or tile for the weight gradients;
+//                                           row = produced channel k / tile t / channel c; 16 bytes per (red block, row))
+// which makes a lane's MFMA fragment ONE 16-byte LDS read and a 128-row tile of one reduction block 2 KB of contiguous memory
+// for the LDS-DMA.  The transform kernels produce it through an LDS exchange (a thread computes one (red, row) element of all
+// 36 points; 8 threads' results make one 16-byte vector).
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SPLIT_ROWS = 32;                       // rows (and 8 reduction indices) per workgroup of the transform kernels
+constexpr int SPLIT_CHUNK = 12;                      // points staged in LDS at a time: 12 KB (NPL = 2) / 18 KB (NPL = 3) per workgroup
+template <int NPL> constexpr int split_stage_elems() { return SPLIT_CHUNK * NPL * SPLIT_ROWS * 8; }
+
+// one thread's 36 values (reduction slot pk of 8, row rl of 32) -> the workgroup's 36 * NPL * 32 vectors of 8 bf16 at
+// dst[((xi * NPL + plane) * nblk + blk) * rows + row0 + rl][8].  The points cross LDS twelve at a time: the whole exchange at
+// once (37 / 55 KB) left two workgroups per CU and the kernels latency bound.
+template <int NPL>
+__device__ __forceinline__ void store_split(unsigned short* __restrict__ stage, const float (&v)[6][6], int pk, int rl,
+                                            unsigned short* __restrict__ dst, size_t nblk, size_t rows, size_t blk, size_t row0)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
-    if (k >= Kp) return;
+    constexpr int NVEC = SPLIT_CHUNK * NPL * SPLIT_ROWS;           // 16-byte vectors per chunk
+    const uint4* src = reinterpret_cast<const uint4*>(stage);
+#pragma unroll
+    for (int ch = 0; ch < 36 / SPLIT_CHUNK; ++ch) {
+#pragma unroll
+        for (int e = 0; e < SPLIT_CHUNK; ++e) {
+            const int xi = ch * SPLIT_CHUNK + e;
+            float r = v[xi / 6][xi % 6];
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                const unsigned short b = f2bf(r);
+                stage[((e * NPL + p) * SPLIT_ROWS + rl) * 8 + pk] = b;
+                r -= bf2f(b);                          // exact: the residual of a rounding fits the format
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (NVEC + 255) / 256; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (NVEC % 256 == 0 || idx < NVEC) {
+                const int xp = idx / SPLIT_ROWS, r2 = idx - xp * SPLIT_ROWS;
+                *reinterpret_cast<uint4*>(dst + (((size_t)(ch * SPLIT_CHUNK * NPL + xp) * nblk + blk) * rows + row0 + r2) * 8) = src[idx];
+            }
+        }
+        __syncthreads();                               // the stage is refilled by the next chunk / the caller's next phase
+    }
+}
+
+// Thread <-> (tile t, channel c) maps of the operand-producing transform kernels, and where a thread's 36 values go.
+//   TMAJOR = false (forward / input-gradient operands: the GEMM reduces over channels)
+//       MODE 0: workgroup = 256 tiles of one channel, grid (Tp/256, C)      -> fp32 planes  V[xi][c][t]
+//       MODE n: workgroup = 8 channels x 32 tiles,    grid (Tp/32, C/8)     -> split bf16   Vs[xi][plane][c/8][t][8]
+//   TMAJOR = true  (weight-gradient operands: the GEMM reduces over tiles)
+//       MODE 0: workgroup = 16 tiles x 16 channels,   grid (Tp/16, Cp/16)   -> fp32         Vt[xi][t][c]   (through LDS: 64-byte runs)
+//       MODE n: workgroup = 8 tiles x 32 channels,    grid (Tp/8, Cp/32)    -> split bf16   Vs[xi][plane][t/8][c][8]
+struct OpIdx { int t, c, pk, rl; unsigned bx, by; };
+
+template <bool TMAJOR, int MODE> constexpr int op_smem_bytes()
+{
+    return MODE > 0 ? SPLIT_CHUNK * (MODE > 0 ? MODE : 1) * SPLIT_ROWS * 8 * 2 : (TMAJOR ? 36 * 16 * 17 * 4 : 16);
+}
+
+template <bool TMAJOR, int MODE>
+__device__ __forceinline__ OpIdx op_index(bool remap)
+{
+    OpIdx ix;
+    remap2d(remap, ix.bx, ix.by);
+    const int tid = threadIdx.x;
+    if (!TMAJOR && MODE == 0) { ix.pk = 0; ix.rl = 0; ix.t = ix.bx * 256 + tid; ix.c = ix.by; }
+    else if (!TMAJOR) { ix.pk = tid >> 5; ix.rl = tid & 31; ix.t = ix.bx * SPLIT_ROWS + ix.rl; ix.c = ix.by * 8 + ix.pk; }
+    else if (MODE == 0) { ix.pk = tid & 15; ix.rl = tid >> 4; ix.t = ix.bx * 16 + ix.pk; ix.c = ix.by * 16 + ix.rl; }
+    else { ix.pk = tid & 7; ix.rl = tid >> 3; ix.t = ix.bx * 8 + ix.pk; ix.c = ix.by * SPLIT_ROWS + ix.rl; }
+    return ix;
+}
+
+static dim3 op_grid(bool tmajor, int mode, int Tp, int Cn)      // Cn: channels (TMAJOR: padded to 128)
+{
+    if (!tmajor) return mode == 0 ? dim3(cdiv(Tp, 256), Cn) : dim3(Tp / SPLIT_ROWS, Cn / 8);
+    return mode == 0 ? dim3(Tp / 16, Cn / 16) : dim3(Tp / 8, Cn / SPLIT_ROWS);
+}
+
+__device__ __forceinline__ void wino_store_tmajor(float (*stage)[16][17], const float v[6][6], int tl, int cl, float* __restrict__ dst,
+                                                  int t0, int c0, int Tp, int Cp);
+
+// Cn = channels of the operand (TMAJOR: the padded row length Cp), Tp = padded tiles
+template <bool TMAJOR, int MODE>
+__device__ __forceinline__ void op_emit(unsigned char* smem, const float (&v)[6][6], const OpIdx& ix, void* __restrict__ out, int Cn, int Tp)
+{
+    if (MODE > 0) {
+        unsigned short* stage = reinterpret_cast<unsigned short*>(smem);
+        if (!TMAJOR) store_split<(MODE > 0 ? MODE : 1)>(stage, v, ix.pk, ix.rl, static_cast<unsigned short*>(out), Cn / 8, Tp, ix.by, (size_t)ix.bx * SPLIT_ROWS);
+        else store_split<(MODE > 0 ? MODE : 1)>(stage, v, ix.pk, ix.rl, static_cast<unsigned short*>(out), Tp / 8, Cn, ix.bx, (size_t)ix.by * SPLIT_ROWS);
+    } else if (TMAJOR) {
+        wino_store_tmajor(reinterpret_cast<float (*)[16][17]>(smem), v, ix.pk, ix.rl, static_cast<float*>(out), ix.bx * 16, ix.by * 16, Tp, Cn);
+    } else {
+        float* V = static_cast<float*>(out);
+        const size_t plane = (size_t)Cn * Tp;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) V[(size_t)(i * 6 + j) * plane + (size_t)ix.c * Tp + ix.t] = v[i][j];
+    }
+}
+
+// U[xi][c][k], k < Kp (zero beyond K), from W[c*sc + k*sm + r*3 + s] (flip: r -> 2-r, s -> 2-s)
+// MODE 0: fp32 planes U[xi][c][k].  MODE 2 / 3: split bf16, Us[xi][plane][c/8][k][8] (grid = (Kp/32, C/8)).
+template <int MODE>
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ W, int C, int K, int Kp, long sc, long sm, int flip,
+                                                          void* __restrict__ Uout)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short stage[MODE > 0 ? split_stage_elems<MODE ? MODE : 1>() : 8];
+    int k, c;
+    if (MODE > 0) { k = blockIdx.x * SPLIT_ROWS + (threadIdx.x & 31); c = blockIdx.y * 8 + (threadIdx.x >> 5); }
+    else { k = blockIdx.x * 256 + threadIdx.x; c = blockIdx.y; if (k >= Kp) return; }
     float g[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -139,6 +256,12 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) wino_g(t[i], u[i]);          // rows: u[i,:] = G t[i,:]
+    if (MODE > 0) {
+        store_split<MODE ? MODE : 1>(stage, u, threadIdx.x >> 5, threadIdx.x & 31, static_cast<unsigned short*>(Uout), C / 8, Kp, blockIdx.y,
+                                     (size_t)blockIdx.x * SPLIT_ROWS);
+        return;
+    }
+    float* U = static_cast<float*>(Uout);
     const size_t plane = (size_t)C * Kp;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -146,30 +269,36 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
         for (int j = 0; j < 6; ++j) U[(size_t)(i * 6 + j) * plane + (size_t)c * Kp + k] = u[i][j];
 }
 
-// V[xi][c][t], t < Tp (zero beyond T = B*TY*TX)
-__global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, int B, int C, int H, int Wd, int TY, int TX, int Tp,
-                                                         float* __restrict__ V)
+// MODE 0: fp32 planes V[xi][c][t].  MODE 2 / 3: split bf16, Vs[xi][plane][c/8][t][8] (grid = (Tp/32, C/8)).  TIN: float, or
+// unsigned short = bf16 activations (BASELINE config 5).
+template <int MODE, typename TIN>
+__global__ void __launch_bounds__(256) wino_input_kernel(const TIN* __restrict__ x, int B, int C, int H, int Wd, int TY, int TX, int Tp,
+                                                         void* __restrict__ Vout, int remap)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
-    if (t >= Tp) return;
+    __shared__ __attribute__((aligned(16))) unsigned short stage[MODE > 0 ? split_stage_elems<MODE ? MODE : 1>() : 8];
+    unsigned bx, by;
+    remap2d(remap != 0, bx, by);
+    int t, c;
+    if (MODE > 0) { t = bx * SPLIT_ROWS + (threadIdx.x & 31); c = by * 8 + (threadIdx.x >> 5); }
+    else { t = bx * 256 + threadIdx.x; c = by; if (t >= Tp) return; }
     const int T = B * TY * TX;
     float d[6][6];
     if (t < T) {
         const int b = t / (TY * TX), rem = t - b * TY * TX;
         const int ty = rem / TX, tx = rem - ty * TX;
-        const float* xp = x + ((size_t)b * C + c) * H * Wd;
+        const TIN* xp = x + ((size_t)b * C + c) * H * Wd;
         const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
         if ((Wd & 3) == 0) {
-            // the window's inner four columns are the tile's own, 16-byte aligned: one float4 + two halo scalars per row
+            // the window's inner four columns are the tile's own, vector aligned: one 4-element load + two halo scalars per row
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const int yy = y0 + i;
                 const bool yok = (unsigned)yy < (unsigned)H;
-                const float* rp = xp + (size_t)(yok ? yy : 0) * Wd;
-                const float4 mid = yok ? *reinterpret_cast<const float4*>(rp + x0 + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
-                d[i][0] = (yok && x0 >= 0) ? rp[x0] : 0.0f;
+                const TIN* rp = xp + (size_t)(yok ? yy : 0) * Wd;
+                const float4 mid = yok ? ld4(rp, (size_t)(x0 + 1) >> 2) : make_float4(0.f, 0.f, 0.f, 0.f);
+                d[i][0] = (yok && x0 >= 0) ? ld1(rp, (size_t)x0) : 0.0f;
                 d[i][1] = mid.x; d[i][2] = mid.y; d[i][3] = mid.z; d[i][4] = mid.w;
-                d[i][5] = (yok && x0 + 5 < Wd) ? rp[x0 + 5] : 0.0f;
+                d[i][5] = (yok && x0 + 5 < Wd) ? ld1(rp, (size_t)(x0 + 5)) : 0.0f;
             }
         } else {
 #pragma unroll
@@ -179,7 +308,7 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const int xx = x0 + j;
-                    d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+                    d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? ld1(xp, (size_t)yy * Wd + xx) : 0.0f;
                 }
             }
         }
@@ -200,6 +329,12 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) wino_bt(w[i], v[i]);         // rows
+    if (MODE > 0) {
+        store_split<MODE ? MODE : 1>(stage, v, threadIdx.x >> 5, threadIdx.x & 31, static_cast<unsigned short*>(Vout), C / 8, Tp, by,
+                                     (size_t)bx * SPLIT_ROWS);
+        return;
+    }
+    float* V = static_cast<float*>(Vout);
     const size_t plane = (size_t)C * Tp;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -211,11 +346,13 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
 // EPI: 0 plain; 1 = + bias[k], ReLU; 2 = + bias[k], ReLU, 2x2 max-pool (y is then [B,K,H/2,W/2]) — the VGG16 chain
 // Conv2d(bias) -> ReLU(inplace) [-> MaxPool2d(2,2)] (models/vgg16.py:9-21) without a second pass over the activations.
 // NaN-propagating like torch's relu / max_pool2d.
-template <int EPI>
+template <int EPI, typename TOUT>
 __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mo, WinoSplit split, const float* __restrict__ bias,
-                                                          int B, int K, int Kp, int H, int Wd, int TY, int TX, int Tp, float* __restrict__ y)
+                                                          int B, int K, int Kp, int H, int Wd, int TY, int TX, int Tp, TOUT* __restrict__ y, int remap)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    unsigned bx, by;
+    remap2d(remap != 0, bx, by);
+    const int t = bx * 256 + threadIdx.x, k = by;
     const int T = B * TY * TX;
     if (t >= T) return;
     float m[6][6];
@@ -243,7 +380,7 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
     const int ty = rem / TX, tx = rem - ty * TX;
     if (EPI == 2) {                                // H, W even (host-checked): the 4x4 tile pools to 2x2
         const int Hh = H >> 1, Wh = Wd >> 1;
-        float* yp = y + ((size_t)b * K + k) * Hh * Wh;
+        TOUT* yp = y + ((size_t)b * K + k) * Hh * Wh;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -251,22 +388,22 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
                 const float a0 = o[2 * i][2 * j], a1 = o[2 * i][2 * j + 1], a2 = o[2 * i + 1][2 * j], a3 = o[2 * i + 1][2 * j + 1];
                 const float m01 = (a0 > a1 || a0 != a0) ? a0 : a1, m23 = (a2 > a3 || a2 != a2) ? a2 : a3;
                 const int yy = 2 * ty + i, xx = 2 * tx + j;
-                if (yy < Hh && xx < Wh) yp[(size_t)yy * Wh + xx] = (m01 > m23 || m01 != m01) ? m01 : m23;
+                if (yy < Hh && xx < Wh) st1(yp, (size_t)yy * Wh + xx, (m01 > m23 || m01 != m01) ? m01 : m23);
             }
         return;
     }
-    float* yp = y + ((size_t)b * K + k) * H * Wd;
+    TOUT* yp = y + ((size_t)b * K + k) * H * Wd;
     const int y0 = 4 * ty, x0 = 4 * tx;
     if ((Wd & 3) == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (y0 + i < H) *reinterpret_cast<float4*>(yp + (size_t)(y0 + i) * Wd + x0) = make_float4(o[i][0], o[i][1], o[i][2], o[i][3]);
+            if (y0 + i < H) st4(yp, ((size_t)(y0 + i) * Wd + x0) >> 2, make_float4(o[i][0], o[i][1], o[i][2], o[i][3]));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (y0 + i < H && x0 + j < Wd) yp[(size_t)(y0 + i) * Wd + x0 + j] = o[i][j];
+                if (y0 + i < H && x0 + j < Wd) st1(yp, (size_t)(y0 + i) * Wd + x0 + j, o[i][j]);
     }
 }
 
@@ -288,18 +425,18 @@ __device__ __forceinline__ void wino_store_tmajor(float (*stage)[16][17], const 
 }
 
 // window operand (x for Conv2d, dy for ConvTranspose2d):  Vt[xi][t][c] = (B^T d B)[xi], zero for t >= T or c >= C
-__global__ void __launch_bounds__(256) wino_wrw_window_kernel(const float* __restrict__ x, int B, int C, int H, int Wd, int TY, int TX,
-                                                              int Tp, int Cp, float* __restrict__ Vt)
+template <int MODE, typename TIN>
+__global__ void __launch_bounds__(256) wino_wrw_window_kernel(const TIN* __restrict__ x, int B, int C, int H, int Wd, int TY, int TX,
+                                                              int Tp, int Cp, void* __restrict__ Vt)
 {
-    __shared__ float stage[36][16][17];
-    const int tl = threadIdx.x & 15, cl = threadIdx.x >> 4;
-    const int t0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
-    const int t = t0 + tl, c = c0 + cl, T = B * TY * TX;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[op_smem_bytes<true, MODE>()];
+    const OpIdx ix = op_index<true, MODE>(false);
+    const int t = ix.t, c = ix.c, T = B * TY * TX;
     float d[6][6];
     const bool live = t < T && c < C;
     int b = 0, ty = 0, tx = 0;
     if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
-    const float* xp = x + ((size_t)b * C + (live ? c : 0)) * H * Wd;
+    const TIN* xp = x + ((size_t)b * C + (live ? c : 0)) * H * Wd;
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -308,7 +445,7 @@ __global__ void __launch_bounds__(256) wino_wrw_window_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int xx = x0 + j;
-            d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+            d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? ld1(xp, (size_t)yy * Wd + xx) : 0.0f;
         }
     }
     float w[6][6], v[6][6];
@@ -322,28 +459,28 @@ __global__ void __launch_bounds__(256) wino_wrw_window_kernel(const float* __res
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) wino_bt(w[i], v[i]);
-    wino_store_tmajor(stage, v, tl, cl, Vt, t0, c0, Tp, Cp);
+    op_emit<true, MODE>(smem, v, ix, Vt, Cp, Tp);
 }
 
 // tile operand (dy for Conv2d, x for ConvTranspose2d):  Et[xi][t][k] = (G' e G'^T)[xi], e = the 4x4 tile, zero beyond T / K
-__global__ void __launch_bounds__(256) wino_wrw_tile_kernel(const float* __restrict__ dy, int B, int K, int H, int Wd, int TY, int TX,
-                                                            int Tp, int Kp, float* __restrict__ Et)
+template <int MODE, typename TIN>
+__global__ void __launch_bounds__(256) wino_wrw_tile_kernel(const TIN* __restrict__ dy, int B, int K, int H, int Wd, int TY, int TX,
+                                                            int Tp, int Kp, void* __restrict__ Et)
 {
-    __shared__ float stage[36][16][17];
-    const int tl = threadIdx.x & 15, cl = threadIdx.x >> 4;
-    const int t0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
-    const int t = t0 + tl, k = k0 + cl, T = B * TY * TX;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[op_smem_bytes<true, MODE>()];
+    const OpIdx ix = op_index<true, MODE>(false);
+    const int t = ix.t, k = ix.c, T = B * TY * TX;
     const bool live = t < T && k < K;
     int b = 0, ty = 0, tx = 0;
     if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
-    const float* dp = dy + ((size_t)b * K + (live ? k : 0)) * H * Wd;
+    const TIN* dp = dy + ((size_t)b * K + (live ? k : 0)) * H * Wd;
     float e[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int yy = 4 * ty + i, xx = 4 * tx + j;
-            e[i][j] = (live && yy < H && xx < Wd) ? dp[(size_t)yy * Wd + xx] : 0.0f;
+            e[i][j] = (live && yy < H && xx < Wd) ? ld1(dp, (size_t)yy * Wd + xx) : 0.0f;
         }
     float w[6][4], v[6][6];
 #pragma unroll
@@ -356,7 +493,7 @@ __global__ void __launch_bounds__(256) wino_wrw_tile_kernel(const float* __restr
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) wino_g4(w[i], v[i]);
-    wino_store_tmajor(stage, v, tl, cl, Et, t0, k0, Tp, Kp);
+    op_emit<true, MODE>(smem, v, ix, Et, Kp, Tp);
 }
 
 // dW[k][c][r][s] = (A'^T Mw[:][k][c] A')[r][s]
@@ -430,36 +567,39 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
 
     const int nstage = min(C / WG_BK - s_lo, sps);        // stages of this workgroup (>= 1)
     constexpr int NP = WG_BK / 4;                         // DMA pieces (1 KiB = 2 rows) per wave per stage: 2 of A, 2 of B
+    constexpr int AHEAD = WG_NBUF - 1;
+    // One pointer per DMA piece, advanced by a constant per stage; the prefetch is unconditional (past the last stage it re-reads
+    // the last one into a slot nobody reads again): no branch in the loop body and one constant vmcnt (see wino_gemm_split_kernel).
     const int dma_row = lane >> 5, dma_col = (lane & 31) * 4;
-    auto dma_piece = [&](int s, int p) {
+    const float* gp[NP];
+    int loff[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
         const bool isA = p < NP / 2;
         const int pair = wave + 4 * (isA ? p : p - NP / 2);
-        const int slot = (s & (WG_NBUF - 1)) * (2 * WG_BK * WG_BM) + (isA ? 0 : WG_BK * WG_BM) + pair * 2 * WG_BM;
-        const size_t row = (size_t)s * WG_BK + 2 * pair + dma_row;
-        const float* g = isA ? (A + row * Kp + k0 + dma_col) : (Bm + row * Tp + t0 + dma_col);
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)&lds[slot], 16, 0, 0);
-    };
-    auto wait_stage = [&](int younger) {
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-#pragma unroll
-    for (int p = 0; p < NP; ++p) dma_piece(0, p);
-    if (nstage > 1) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) dma_piece(1, p);
+        loff[p] = (isA ? 0 : WG_BK * WG_BM) + pair * 2 * WG_BM;
+        const size_t row = (size_t)2 * pair + dma_row;
+        gp[p] = isA ? (A + row * Kp + k0 + dma_col) : (Bm + row * Tp + t0 + dma_col);
     }
-    if (nstage > 2) {
+    const size_t strideA = (size_t)WG_BK * Kp, strideB = (size_t)WG_BK * Tp;
+    auto dma_piece = [&](int p, int slot, bool more) {
+        __builtin_amdgcn_global_load_lds((gptr_t)gp[p], (lptr_t)&lds[slot * (2 * WG_BK * WG_BM) + loff[p]], 16, 0, 0);
+        gp[p] += more ? (p < NP / 2 ? strideA : strideB) : 0;
+    };
+    int issued = 0, pf_slot = 0;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) dma_piece(2, p);
+    for (int a = 0; a < AHEAD; ++a) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dma_piece(p, pf_slot, issued + 1 < nstage);
+        ++issued;
+        pf_slot = (pf_slot + 1) & (WG_NBUF - 1);
     }
-    wait_stage(min(2, nstage - 1));
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NP) : "memory");
     __builtin_amdgcn_s_barrier();
 
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & (WG_NBUF - 1);
-        const bool prefetch = s + 3 < nstage;
+        const bool more = issued + 1 < nstage;
         const float* ta = lds + (size_t)cur * (2 * WG_BK * WG_BM) + h * WG_BM + wm * 32 + r;
         const float* tb = lds + (size_t)cur * (2 * WG_BK * WG_BM) + WG_BK * WG_BM + h * WG_BM + wn * 32 + r;
         float fa0[3], fa1[3], fb0[3], fb1[3];
@@ -471,7 +611,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
                 const int ro = (kk + 1) * 2 * WG_BM;
                 fa0[nx] = ta[ro]; fa1[nx] = ta[ro + 64]; fb0[nx] = tb[ro]; fb1[nx] = tb[ro + 64];
             }
-            if (prefetch && (kk % ((WG_BK / 2) / NP)) == 0) dma_piece(s + 3, kk / ((WG_BK / 2) / NP));
+            if ((kk % ((WG_BK / 2) / NP)) == 0) dma_piece(kk / ((WG_BK / 2) / NP), pf_slot, more);
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb0[cs], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb1[cs], acc[0][1], 0, 0, 0);
@@ -479,10 +619,13 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cs], fb1[cs], acc[1][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        wait_stage(min(s + 3, nstage - 1) - (s + 1));
+        ++issued;
+        pf_slot = (pf_slot + 1) & (WG_NBUF - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NP) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the redundant tail prefetches must not outlive the workgroup's LDS
 
     float* out = Mo + ((size_t)ks * split.nxi + xi) * Kp * Tp;
 #pragma unroll
@@ -496,6 +639,165 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
                 out[(size_t)k * Tp + t] = acc[im][jn][e];
             }
     }
+}
+
+// The same 36 GEMMs on the bf16 matrix cores with SPLIT operands (see store_split): M[xi][k][t] = sum_c U[xi][c][k] V[xi][c][t] with
+// U, V given as NPL bf16 planes each.  Same workgroup tile (128 x 128), same 4-slot LDS-DMA ring of 16-channel stages, same
+// reduction cuts and the same fp32 result layout as wino_gemm_kernel — only the inside of a stage differs: the stage holds
+// [plane][channel block of 8][128 rows][8] per operand (2 KB per (plane, block): the image the LDS-DMA writes lane-linearly),
+// a lane's fragment for `v_mfma_f32_32x32x16_bf16` (row r = lane & 31, channels 8h .. 8h+7, h = lane >> 5) is one ds_read_b128,
+// and one k-step of 16 channels is 3 (NPL = 2) or 6 (NPL = 3) MFMAs of 32 cycles per 32x32 tile instead of 8 of 64.
+template <int NPL>
+__global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_split_kernel(const unsigned short* __restrict__ U, const unsigned short* __restrict__ V,
+                                                                        int C, int Kp, int Tp, int ktiles, int ttiles, WinoSplit split,
+                                                                        float* __restrict__ Mo)
+{
+    constexpr int OPB = NPL * 2 * WG_BM * 8;                  // bf16 elements of one operand in a stage: planes x 2 channel blocks x 128 rows x 8
+    constexpr int SLOT = 2 * OPB;
+    constexpr int NSLOT = NPL == 2 ? 4 : 3;                   // 64 KB / 72 KB of LDS: two workgroups per CU either way
+    __shared__ __attribute__((aligned(16))) unsigned short lds[NSLOT * SLOT];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int tiles = ktiles * ttiles;
+    const unsigned head = (unsigned)(split.head_xi() * tiles * split.nsplit);
+    const bool is_tail = blockIdx.x >= head;
+    const unsigned L = is_tail ? xcd_remap(blockIdx.x - head, gridDim.x - head) : xcd_remap(blockIdx.x, head);
+    const int nsplit = is_tail ? split.nsplit_t : split.nsplit, sps = is_tail ? split.sps_t : split.sps;
+    const int per_xi = tiles * nsplit;
+    const int xi0 = L / per_xi, rem = L - xi0 * per_xi;
+    const int xi = xi0 + (is_tail ? split.xi_split : 0);
+    const int ks = rem % nsplit, kt = (rem / nsplit) % ktiles, tt = rem / (nsplit * ktiles);
+    const int k0 = kt * WG_BM, t0 = tt * WG_BN;
+    const int s_lo = ks * sps;
+    const int nblk = C / 8;
+    // plane p, channel block cb of this workgroup's rows: base + ((p * nblk + cb) * rows + row) * 8
+    const unsigned short* A = U + ((size_t)xi * NPL * nblk * Kp + k0) * 8;
+    const unsigned short* Bm = V + ((size_t)xi * NPL * nblk * Tp + t0) * 8;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nstage = min(C / WG_BK - s_lo, sps);
+    constexpr int NPIECE = 8 * NPL;                           // 1-KiB DMA pieces per stage: 2 operands x NPL planes x 2 blocks x 2 halves of 64 rows
+    constexpr int NP = NPIECE / 4;                            // per wave
+    constexpr int AHEAD = NSLOT - 1;                          // stages in flight
+    // A stage costs only 3 / 6 MFMAs of 32 cycles per tile here (the fp32 kernel: 8 of 64), so everything else in the loop has to be
+    // cheap: every wave keeps one pointer per DMA piece and advances it by a constant per stage, the prefetch is UNCONDITIONAL
+    // (past the last stage it re-reads the last one into a slot nobody reads again) so that the loop body has no branch and the
+    // number of DMAs in flight is the same in every iteration: one constant vmcnt.
+    const unsigned short* gp[NP];
+    int loff[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int q = wave + 4 * i;                           // uniform
+        const int opnd = q / (4 * NPL), within = q - opnd * 4 * NPL;
+        const int pl = within >> 2, cb = (within >> 1) & 1, half = within & 1;
+        loff[i] = opnd * OPB + ((pl * 2 + cb) * WG_BM + half * 64) * 8;
+        const size_t blk = (size_t)s_lo * 2 + cb;
+        gp[i] = opnd == 0 ? A + (((size_t)pl * nblk + blk) * Kp + half * 64 + lane) * 8 : Bm + (((size_t)pl * nblk + blk) * Tp + half * 64 + lane) * 8;
+    }
+    const size_t strideA = (size_t)2 * Kp * 8, strideB = (size_t)2 * Tp * 8;          // one stage = two channel blocks
+    auto dma_stage_piece = [&](int i, int slot) {
+        __builtin_amdgcn_global_load_lds((gptr_t)gp[i], (lptr_t)&lds[slot * SLOT + loff[i]], 16, 0, 0);
+    };
+    auto advance = [&](int i, bool more) {                    // -> the next stage's piece, or stay on the last stage
+        const int q = wave + 4 * i;
+        const size_t st_ = q < 4 * NPL ? strideA : strideB;
+        gp[i] += more ? st_ : 0;
+    };
+    int issued = 0;                                           // stages whose DMAs have been issued (clamped to nstage - 1 as a source)
+    int pf_slot = 0;
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { dma_stage_piece(i, pf_slot); advance(i, issued + 1 < nstage); }
+        ++issued;
+        pf_slot = pf_slot + 1 == NSLOT ? 0 : pf_slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NP) : "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0;
+    for (int s = 0; s < nstage; ++s) {
+        const unsigned short* sa = lds + cur * SLOT + (h * WG_BM + wm * 32 + r) * 8;
+        const unsigned short* sb = lds + cur * SLOT + OPB + (h * WG_BM + wn * 32 + r) * 8;
+        // fragments in the order the tiles need them — (0,0) first — so that the first MFMAs start while the later reads are in flight
+        // (the compiler places the counted lgkmcnt waits)
+        bf16x8 fa[NPL][2], fb[NPL][2];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            fa[p][0] = *reinterpret_cast<const bf16x8*>(sa + (p * 2 * WG_BM) * 8);
+            fb[p][0] = *reinterpret_cast<const bf16x8*>(sb + (p * 2 * WG_BM) * 8);
+        }
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) fb[p][1] = *reinterpret_cast<const bf16x8*>(sb + (p * 2 * WG_BM + 64) * 8);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) fa[p][1] = *reinterpret_cast<const bf16x8*>(sa + (p * 2 * WG_BM + 64) * 8);
+        const bool more = issued + 1 < nstage;
+        // products in ascending magnitude: the small cross terms first, hi*hi last
+        constexpr int NPROD = NPL == 2 ? 3 : 6;
+        constexpr int PA[6] = {NPL == 2 ? 1 : 2, 0, NPL == 2 ? 0 : 1, 1, 0, 0};      // NPL=2: (1,0)(0,1)(0,0)   NPL=3: (2,0)(0,2)(1,1)(1,0)(0,1)(0,0)
+        constexpr int PB[6] = {0, NPL == 2 ? 1 : 2, NPL == 2 ? 0 : 1, 0, 1, 0};
+        int piece = 0;
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            const int i = tile >> 1, j = tile & 1;
+#pragma unroll
+            for (int q = 0; q < NPROD; ++q) {
+                if (q % 3 == 0 && piece < NP) {               // this wave's DMA pieces of stage s + AHEAD, spread between the MFMAs
+                    dma_stage_piece(piece, pf_slot);
+                    advance(piece, more);
+                    ++piece;
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][i], fb[PB[q]][j], acc[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 4 * ((NPROD + 2) / 3); i < NP; ++i) { dma_stage_piece(i, pf_slot); advance(i, more); }
+        ++issued;
+        pf_slot = pf_slot + 1 == NSLOT ? 0 : pf_slot + 1;
+        cur = cur + 1 == NSLOT ? 0 : cur + 1;
+        // stage s + 1 has landed once all but the AHEAD - 1 youngest stages' DMAs are done
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NP) : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the redundant tail prefetches must not outlive the workgroup's LDS
+
+    float* out = Mo + ((size_t)ks * split.nxi + xi) * Kp * Tp;
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int t = t0 + wn * 32 + jn * 64 + r;
+#pragma unroll
+        for (int im = 0; im < 2; ++im)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * 32 + im * 64 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                out[(size_t)k * Tp + t] = acc[im][jn][e];
+            }
+    }
+}
+
+// launches the 36 GEMMs in the arithmetic `math`: 0 = fp32 operands on v_mfma_f32_32x32x2_f32; 2 / 3 = split bf16 operands
+static void launch_wino_gemm(int math, const void* A, const void* Bv, int red, int rows, int cols, const WinoSplit& sp, float* Mo, hipStream_t st)
+{
+    const int kt = rows / WG_BM, tt = cols / WG_BN;
+    const unsigned grid = sp.workgroups(kt * tt);
+    profile_mark_start(st, 3);
+    if (math == 2)
+        wino_gemm_split_kernel<2><<<grid, WG_THREADS, 0, st>>>(static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(Bv), red, rows, cols, kt, tt, sp, Mo);
+    else if (math == 3)
+        wino_gemm_split_kernel<3><<<grid, WG_THREADS, 0, st>>>(static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(Bv), red, rows, cols, kt, tt, sp, Mo);
+    else
+        wino_gemm_kernel<<<grid, WG_THREADS, 0, st>>>(static_cast<const float*>(A), static_cast<const float*>(Bv), red, rows, cols, kt, tt, sp, Mo);
+    profile_mark_stop(st, 3, 72.0 * red * rows * cols);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -543,6 +845,26 @@ static WinoSplit wino_choose_split(int tiles36, int stages, size_t m_bytes)
     return best;
 }
 
+// ---- arithmetic / element types of one convolution call -------------------------------------------------------------------------
+// math: 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (the reference's arithmetic); 2 / 3 = SPLIT bf16 operands (store_split) on
+// v_mfma_f32_32x32x16_bf16.  in_bf16 / out_bf16: the activation tensors read / written are bf16 (BASELINE config 5) instead of fp32;
+// weights, weight gradients and all transform arithmetic stay fp32.
+struct ConvArith { int math; bool in_bf16, out_bf16; };
+static inline bool arith_ok(const ConvArith& a) { return a.math == 0 || a.math == 2 || a.math == 3; }
+
+template <typename F> static inline void with_mode(int math, F&& f)
+{
+    if (math == 2) f(std::integral_constant<int, 2>{});
+    else if (math == 3) f(std::integral_constant<int, 3>{});
+    else f(std::integral_constant<int, 0>{});
+}
+template <typename F> static inline void with_type(bool bf16, F&& f)
+{
+    if (bf16) f(static_cast<bf16_t*>(nullptr));
+    else f(static_cast<float*>(nullptr));
+}
+#define ELEM_T(tag) std::remove_pointer_t<decltype(tag)>
+
 struct WinoPlan { int TY, TX, T, Tp, Kp; WinoSplit sp; size_t u_floats, v_floats, m_floats, total_bytes; };
 
 static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p)
@@ -552,8 +874,8 @@ static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p)
     p->T = B * p->TY * p->TX;
     p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;
     p->Kp = (K + WG_BM - 1) / WG_BM * WG_BM;
-    p->u_floats = (size_t)36 * C * p->Kp;
-    p->v_floats = (size_t)36 * C * p->Tp;
+    p->u_floats = (size_t)36 * C * p->Kp * 3 / 2;          // room for three bf16 planes (the split arithmetic with NPL = 3)
+    p->v_floats = (size_t)36 * C * p->Tp * 3 / 2;
     const size_t m1 = (size_t)36 * p->Kp * p->Tp;
     p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), C / WG_BK, m1 * 4);
     p->m_floats = m1 * p->sp.slabs();
@@ -568,37 +890,46 @@ size_t winograd_ws_bytes(int B, int C, int K, int H, int W)
     return p.total_bytes;
 }
 
-size_t winograd_filter_floats(int C, int K) { return (size_t)36 * C * ((K + WG_BM - 1) / WG_BM * WG_BM); }
+size_t winograd_filter_floats(int C, int K) { return (size_t)36 * C * ((K + WG_BM - 1) / WG_BM * WG_BM) * 3 / 2; }
 
 // y[B,K,H,W] = conv3x3(x[B,C,H,W]) with weight element (c, k, r, s) at w[c*sc + k*sm + r*3 + s], taps flipped when `flip`.
 // u_cache (optional, winograd_filter_floats(C, K) floats owned by the caller): the transformed filter; computed into it when
 // !u_valid, reused as is otherwise (frozen weights: VGG16).  epilogue: 0 none, 1 bias + ReLU, 2 bias + ReLU + 2x2 max-pool.
-int launch_winograd(const float* x, const float* w, float* y, int B, int C, int K, int H, int W, long sc, long sm, int flip,
+int launch_winograd(const void* x, const float* w, void* y, int B, int C, int K, int H, int W, long sc, long sm, int flip,
                     void* ws, size_t ws_bytes, hipStream_t st, const float* bias = nullptr, int epilogue = 0,
-                    float* u_cache = nullptr, int u_valid = 0)
+                    float* u_cache = nullptr, int u_valid = 0, ConvArith ar = ConvArith{0, false, false})
 {
     WinoPlan p;
     if (int rc = wino_plan(B, C, K, H, W, &p)) return rc;
     if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
     if (epilogue < 0 || epilogue > 2 || (epilogue == 2 && ((H | W) & 1)))
         return fail(IPSR_ERR_INVALID, "winograd: epilogue %d on a %dx%d map", epilogue, H, W);
+    if (!arith_ok(ar)) return fail(IPSR_ERR_INVALID, "winograd: arithmetic %d (0 = fp32 MFMA, 2 / 3 = split bf16)", ar.math);
     Carver cv(ws, ws_bytes);
     float* U = cv.take<float>(p.u_floats);
     float* V = cv.take<float>(p.v_floats);
     float* Mo = cv.take<float>(p.m_floats);
     if (u_cache) U = u_cache;
-    if (!(u_cache && u_valid)) wino_filter_kernel<<<dim3(cdiv(p.Kp, 256), C), 256, 0, st>>>(w, C, K, p.Kp, sc, sm, flip, U);
-    wino_input_kernel<<<dim3(cdiv(p.Tp, 256), C), 256, 0, st>>>(x, B, C, H, W, p.TY, p.TX, p.Tp, V);
+    const int remap = !debug_option(1);          // XCD-contiguous (channel, tile block) ranges; debug option 1 = off
+    with_mode(ar.math, [&](auto M) {
+        constexpr int MODE = decltype(M)::value;
+        if (!(u_cache && u_valid)) wino_filter_kernel<MODE><<<op_grid(false, MODE, p.Kp, C), 256, 0, st>>>(w, C, K, p.Kp, sc, sm, flip, U);
+        with_type(ar.in_bf16, [&](auto* tag) {
+            using T = ELEM_T(tag);
+            wino_input_kernel<MODE, T><<<op_grid(false, MODE, p.Tp, C), 256, 0, st>>>(static_cast<const T*>(x), B, C, H, W, p.TY, p.TX, p.Tp, V, remap);
+        });
+    });
     if (int rc = check_launch("wino_input_kernel")) return rc;
-    const int ktiles = p.Kp / WG_BM, ttiles = p.Tp / WG_BN;
-    profile_mark_start(st, 3);
-    wino_gemm_kernel<<<p.sp.workgroups(ktiles * ttiles), WG_THREADS, 0, st>>>(U, V, C, p.Kp, p.Tp, ktiles, ttiles, p.sp, Mo);
-    profile_mark_stop(st, 3, 72.0 * C * p.Kp * p.Tp);
+    launch_wino_gemm(ar.math, U, V, C, p.Kp, p.Tp, p.sp, Mo, st);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     const dim3 og(cdiv(p.T, 256), K);
-    if (epilogue == 2) wino_output_kernel<2><<<og, 256, 0, st>>>(Mo, p.sp, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
-    else if (epilogue == 1) wino_output_kernel<1><<<og, 256, 0, st>>>(Mo, p.sp, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
-    else wino_output_kernel<0><<<og, 256, 0, st>>>(Mo, p.sp, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, y);
+    with_type(ar.out_bf16, [&](auto* tag) {
+        using T = ELEM_T(tag);
+        T* yo = static_cast<T*>(y);
+        if (epilogue == 2) wino_output_kernel<2, T><<<og, 256, 0, st>>>(Mo, p.sp, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, yo, remap);
+        else if (epilogue == 1) wino_output_kernel<1, T><<<og, 256, 0, st>>>(Mo, p.sp, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, yo, remap);
+        else wino_output_kernel<0, T><<<og, 256, 0, st>>>(Mo, p.sp, bias, B, K, p.Kp, H, W, p.TY, p.TX, p.Tp, yo, remap);
+    });
     return check_launch("wino_output_kernel");
 }
 
@@ -611,8 +942,8 @@ static int wino_wrw_plan(int B, int K, int C, int H, int W, WinoWrwPlan* p)
     p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;            // reduction of the GEMM: a multiple of 16 (and of the 16-tile blocks)
     p->Kp = (K + WG_BM - 1) / WG_BM * WG_BM;
     p->Cp = (C + WG_BN - 1) / WG_BN * WG_BN;
-    p->e_floats = (size_t)36 * p->Tp * p->Kp;
-    p->v_floats = (size_t)36 * p->Tp * p->Cp;
+    p->e_floats = (size_t)36 * p->Tp * p->Kp * 3 / 2;            // room for three bf16 planes
+    p->v_floats = (size_t)36 * p->Tp * p->Cp * 3 / 2;
     const size_t m1 = (size_t)36 * p->Kp * p->Cp;
     p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
     p->m_floats = m1 * p->sp.slabs();
@@ -628,23 +959,28 @@ size_t winograd_wrw_ws_bytes(int B, int K, int C, int H, int W)
 }
 
 // dW[K][C][3][3] = sum over tiles:  tile operand `et` [B,K,H,W] (4x4 tiles), window operand `dt` [B,C,H,W] (6x6 windows)
-int launch_winograd_wrw(const float* et, const float* dt, float* dW, int B, int K, int C, int H, int W, void* ws, size_t ws_bytes, hipStream_t st)
+int launch_winograd_wrw(const void* et, const void* dt, float* dW, int B, int K, int C, int H, int W, void* ws, size_t ws_bytes, hipStream_t st,
+                        ConvArith ar = ConvArith{0, false, false})
 {
     WinoWrwPlan p;
     wino_wrw_plan(B, K, C, H, W, &p);
     if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "winograd wrw: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    if (!arith_ok(ar)) return fail(IPSR_ERR_INVALID, "winograd wrw: arithmetic %d", ar.math);
     Carver cv(ws, ws_bytes);
     float* Et = cv.take<float>(p.e_floats);
     float* Vt = cv.take<float>(p.v_floats);
     float* Mw = cv.take<float>(p.m_floats);
-    wino_wrw_tile_kernel<<<dim3(p.Tp / 16, p.Kp / 16), 256, 0, st>>>(et, B, K, H, W, p.TY, p.TX, p.Tp, p.Kp, Et);
-    wino_wrw_window_kernel<<<dim3(p.Tp / 16, p.Cp / 16), 256, 0, st>>>(dt, B, C, H, W, p.TY, p.TX, p.Tp, p.Cp, Vt);
+    with_mode(ar.math, [&](auto M) {
+        constexpr int MODE = decltype(M)::value;
+        with_type(ar.in_bf16, [&](auto* tag) {
+            using T = ELEM_T(tag);
+            wino_wrw_tile_kernel<MODE, T><<<op_grid(true, MODE, p.Tp, p.Kp), 256, 0, st>>>(static_cast<const T*>(et), B, K, H, W, p.TY, p.TX, p.Tp, p.Kp, Et);
+            wino_wrw_window_kernel<MODE, T><<<op_grid(true, MODE, p.Tp, p.Cp), 256, 0, st>>>(static_cast<const T*>(dt), B, C, H, W, p.TY, p.TX, p.Tp, p.Cp, Vt);
+        });
+    });
     if (int rc = check_launch("wino_wrw_window_kernel")) return rc;
-    const int ktiles = p.Kp / WG_BM, ctiles = p.Cp / WG_BN;
     // M[xi][k][c] = sum_t Et[xi][t][k] * Vt[xi][t][c]: the same GEMM with the tiles as the reduction
-    profile_mark_start(st, 3);
-    wino_gemm_kernel<<<p.sp.workgroups(ktiles * ctiles), WG_THREADS, 0, st>>>(Et, Vt, p.Tp, p.Kp, p.Cp, ktiles, ctiles, p.sp, Mw);
-    profile_mark_stop(st, 3, 72.0 * p.Tp * p.Kp * p.Cp);
+    launch_wino_gemm(ar.math, Et, Vt, p.Tp, p.Kp, p.Cp, p.sp, Mw, st);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     wino_wrw_output_kernel<<<dim3(cdiv(C, 256), K), 256, 0, st>>>(Mw, p.sp, K, C, p.Kp, p.Cp, dW);
     return check_launch("wino_wrw_output_kernel");
@@ -666,19 +1002,19 @@ int launch_winograd_wrw(const float* et, const float* dt, float* dW, int B, int 
 
 // generic window transform: V[xi][c][t] (TMAJOR = false) or V[xi][t][c] (true) of windows at origin OS*t read as
 // x[c][IS*(origin + i) + off]
-template <int OS, int IS, bool TMAJOR>
-__global__ void __launch_bounds__(256) wino_window_kernel(const float* __restrict__ x, int B, int C, int H, int Wd, int off, int TY, int TX,
-                                                          int Tp, int Cp, float* __restrict__ V)
+template <int OS, int IS, bool TMAJOR, int MODE, typename TIN>
+__global__ void __launch_bounds__(256) wino_window_kernel(const TIN* __restrict__ x, int B, int C, int H, int Wd, int off, int TY, int TX,
+                                                          int Tp, int Cp, void* __restrict__ V, int remap)
 {
-    __shared__ float stage[TMAJOR ? 36 : 1][16][17];
-    int t, c, tl = 0, cl = 0, t0 = 0, c0 = 0;
-    if (TMAJOR) { tl = threadIdx.x & 15; cl = threadIdx.x >> 4; t0 = blockIdx.x * 16; c0 = blockIdx.y * 16; t = t0 + tl; c = c0 + cl; }
-    else { t = blockIdx.x * 256 + threadIdx.x; c = blockIdx.y; if (t >= Tp) return; }
+    __shared__ __attribute__((aligned(16))) unsigned char smem[op_smem_bytes<TMAJOR, MODE>()];
+    const OpIdx ix = op_index<TMAJOR, MODE>(!TMAJOR && remap != 0);
+    const int t = ix.t, c = ix.c;
+    if (!TMAJOR && MODE == 0 && t >= Tp) return;
     const int T = B * TY * TX;
     const bool live = t < T && c < C;
     int b = 0, ty = 0, tx = 0;
     if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
-    const float* xp = x + ((size_t)b * C + (live ? c : 0)) * H * Wd;
+    const TIN* xp = x + ((size_t)b * C + (live ? c : 0)) * H * Wd;
     float d[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -687,7 +1023,7 @@ __global__ void __launch_bounds__(256) wino_window_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int xx = IS * (OS * tx + j) + off;
-            d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+            d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? ld1(xp, (size_t)yy * Wd + xx) : 0.0f;
         }
     }
     float w[6][6], v[6][6];
@@ -701,23 +1037,18 @@ __global__ void __launch_bounds__(256) wino_window_kernel(const float* __restric
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) wino_bt(w[i], v[i]);
-    if (TMAJOR) {
-        wino_store_tmajor(stage, v, tl, cl, V, t0, c0, Tp, Cp);
-    } else {
-        const size_t plane = (size_t)C * Tp;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) V[(size_t)(i * 6 + j) * plane + (size_t)c * Tp + t] = v[i][j];
-    }
+    op_emit<TMAJOR, MODE>(smem, v, ix, V, TMAJOR ? Cp : C, Tp);
 }
 
 // U[xi][c][k] = (G' g G'^T)[xi] for 4x4 taps: W[c*sc + k*sm + r*4 + s] (flip: r -> 3-r, s -> 3-s)
+template <int MODE>
 __global__ void __launch_bounds__(256) wino4_filter_kernel(const float* __restrict__ W, int C, int K, int Kp, long sc, long sm, int flip,
-                                                           float* __restrict__ U)
+                                                           void* __restrict__ U)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
-    if (k >= Kp) return;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[op_smem_bytes<false, MODE>()];
+    const OpIdx ix = op_index<false, MODE>(false);
+    const int k = ix.t, c = ix.c;
+    if (MODE == 0 && k >= Kp) return;
     float g[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -737,16 +1068,13 @@ __global__ void __launch_bounds__(256) wino4_filter_kernel(const float* __restri
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) wino_g4(t[i], u[i]);
-    const size_t plane = (size_t)C * Kp;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) U[(size_t)(i * 6 + j) * plane + (size_t)c * Kp + k] = u[i][j];
+    op_emit<false, MODE>(smem, u, ix, U, C, Kp);
 }
 
 // y[b][k][os*(3ty+i)+oo][os*(3tx+j)+oo] = (A'^T M A')[i][j] for 3ty+i < Ho, 3tx+j < Wo  (y is [B,K,Hy,Wy])
+template <typename TOUT>
 __global__ void __launch_bounds__(256) wino3_output_kernel(const float* __restrict__ Mo, WinoSplit split, int B, int K, int Kp, int Ho, int Wo,
-                                                           int TY, int TX, int Tp, int Hy, int Wy, int os, int oo, float* __restrict__ y)
+                                                           int TY, int TX, int Tp, int Hy, int Wy, int os, int oo, TOUT* __restrict__ y)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
     const int T = B * TY * TX;
@@ -767,35 +1095,35 @@ __global__ void __launch_bounds__(256) wino3_output_kernel(const float* __restri
     for (int i = 0; i < 3; ++i) wino_at3(w[i], o[i]);
     const int b = t / (TY * TX), rem = t - b * TY * TX;
     const int ty = rem / TX, tx = rem - ty * TX;
-    float* yp = y + ((size_t)b * K + k) * Hy * Wy;
+    TOUT* yp = y + ((size_t)b * K + k) * Hy * Wy;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int oy = 3 * ty + i, ox = 3 * tx + j;
-            if (oy < Ho && ox < Wo) yp[(size_t)(os * oy + oo) * Wy + os * ox + oo] = o[i][j];
+            if (oy < Ho && ox < Wo) st1(yp, (size_t)(os * oy + oo) * Wy + os * ox + oo, o[i][j]);
         }
 }
 
 // weight gradient: 3x3 tiles of dy -> Et[xi][t][k] = (G e G^T)[xi]
-__global__ void __launch_bounds__(256) wino_wrw_tile3_kernel(const float* __restrict__ dy, int B, int K, int Ho, int Wo, int TY, int TX,
-                                                             int Tp, int Kp, float* __restrict__ Et)
+template <int MODE, typename TIN>
+__global__ void __launch_bounds__(256) wino_wrw_tile3_kernel(const TIN* __restrict__ dy, int B, int K, int Ho, int Wo, int TY, int TX,
+                                                             int Tp, int Kp, void* __restrict__ Et)
 {
-    __shared__ float stage[36][16][17];
-    const int tl = threadIdx.x & 15, cl = threadIdx.x >> 4;
-    const int t0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
-    const int t = t0 + tl, k = k0 + cl, T = B * TY * TX;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[op_smem_bytes<true, MODE>()];
+    const OpIdx ix = op_index<true, MODE>(false);
+    const int t = ix.t, k = ix.c, T = B * TY * TX;
     const bool live = t < T && k < K;
     int b = 0, ty = 0, tx = 0;
     if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
-    const float* dp = dy + ((size_t)b * K + (live ? k : 0)) * Ho * Wo;
+    const TIN* dp = dy + ((size_t)b * K + (live ? k : 0)) * Ho * Wo;
     float e[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int yy = 3 * ty + i, xx = 3 * tx + j;
-            e[i][j] = (live && yy < Ho && xx < Wo) ? dp[(size_t)yy * Wo + xx] : 0.0f;
+            e[i][j] = (live && yy < Ho && xx < Wo) ? ld1(dp, (size_t)yy * Wo + xx) : 0.0f;
         }
     float w[6][3], v[6][6];
 #pragma unroll
@@ -808,7 +1136,7 @@ __global__ void __launch_bounds__(256) wino_wrw_tile3_kernel(const float* __rest
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) wino_g(w[i], v[i]);
-    wino_store_tmajor(stage, v, tl, cl, Et, t0, k0, Tp, Kp);
+    op_emit<true, MODE>(smem, v, ix, Et, Kp, Tp);
 }
 
 // dW[k][c][r][s] (4x4) = (A^T Mw[:][k][c] A)[r][s]
@@ -855,8 +1183,8 @@ static int dil_plan(int geom, int mode, int B, int Cin, int H, int W, int Cout, 
     if (mode == 2) {
         p->Kp = (Cout + WG_BM - 1) / WG_BM * WG_BM;
         p->Cp = (Cin + WG_BN - 1) / WG_BN * WG_BN;
-        p->a_floats = (size_t)36 * p->Tp * p->Kp;
-        p->b_floats = (size_t)36 * p->Tp * p->Cp;
+        p->a_floats = (size_t)36 * p->Tp * p->Kp * 3 / 2;        // room for three bf16 planes (split arithmetic)
+        p->b_floats = (size_t)36 * p->Tp * p->Cp * 3 / 2;
         const size_t m1 = (size_t)36 * p->Kp * p->Cp;
         p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
         p->m_floats = m1 * p->sp.slabs();
@@ -865,8 +1193,8 @@ static int dil_plan(int geom, int mode, int B, int Cin, int H, int W, int Cout, 
         if (red % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "4x4 winograd: %d reduction channels are not a multiple of %d", red, WG_BK);
         p->Kp = (prod + WG_BM - 1) / WG_BM * WG_BM;
         p->Cp = red;
-        p->a_floats = (size_t)36 * red * p->Kp;
-        p->b_floats = (size_t)36 * red * p->Tp;
+        p->a_floats = (size_t)36 * red * p->Kp * 3 / 2;
+        p->b_floats = (size_t)36 * red * p->Tp * 3 / 2;
         const size_t m1 = (size_t)36 * p->Kp * p->Tp;
         p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), red / WG_BK, m1 * 4);
         p->m_floats = m1 * p->sp.slabs();
@@ -882,66 +1210,72 @@ size_t winograd_dil_ws_bytes(int geom, int mode, int B, int Cin, int H, int W, i
     return p.total_bytes;
 }
 
-template <bool TMAJOR>
-static void launch_window3(int is, dim3 grid, hipStream_t st, const float* x, int B, int C, int H, int W, int off, const DilPlan& p, int Cp, float* V)
+template <bool TMAJOR, int MODE, typename T>
+static void launch_window3(int is, hipStream_t st, const T* x, int B, int C, int H, int W, int off, const DilPlan& p, int Cp, void* V)
 {
-    if (is == 2) wino_window_kernel<3, 2, TMAJOR><<<grid, 256, 0, st>>>(x, B, C, H, W, off, p.TY, p.TX, p.Tp, Cp, V);
-    else wino_window_kernel<3, 1, TMAJOR><<<grid, 256, 0, st>>>(x, B, C, H, W, off, p.TY, p.TX, p.Tp, Cp, V);
+    const dim3 grid = op_grid(TMAJOR, MODE, p.Tp, TMAJOR ? Cp : C);
+    const int remap = !debug_option(1);          // XCD-contiguous (channel, tile block) ranges; debug option 1 = off
+    if (is == 2) wino_window_kernel<3, 2, TMAJOR, MODE, T><<<grid, 256, 0, st>>>(x, B, C, H, W, off, p.TY, p.TX, p.Tp, Cp, V, remap);
+    else wino_window_kernel<3, 1, TMAJOR, MODE, T><<<grid, 256, 0, st>>>(x, B, C, H, W, off, p.TY, p.TX, p.Tp, Cp, V, remap);
 }
 
 // x [B,Cin,H,W], w [Cout,Cin,4,4], y / dy [B,Cout,Ho,Wo]
-int launch_winograd_dil(int geom, int mode, const float* a, const float* b2, float* out, int B, int Cin, int H, int W, int Cout,
-                        void* ws, size_t ws_bytes, hipStream_t st)
+int launch_winograd_dil(int geom, int mode, const void* a, const void* b2, void* out, int B, int Cin, int H, int W, int Cout,
+                        void* ws, size_t ws_bytes, hipStream_t st, ConvArith ar = ConvArith{0, false, false})
 {
     DilPlan p;
     if (int rc = dil_plan(geom, mode, B, Cin, H, W, Cout, &p)) return rc;
     if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "4x4 winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    if (!arith_ok(ar)) return fail(IPSR_ERR_INVALID, "4x4 winograd: arithmetic %d", ar.math);
     const int Ho = p.Ho, Wo = p.Wo;
     const int xis = geom == 0 ? 2 : 1, xoff = geom == 0 ? -3 : -1;        // X[i] = x[xis * i + xoff]
     Carver cv(ws, ws_bytes);
     float* A = cv.take<float>(p.a_floats);
     float* Bv = cv.take<float>(p.b_floats);
     float* Mo = cv.take<float>(p.m_floats);
-    if (mode == 0) {            // a = x, b2 = w, out = y
-        wino4_filter_kernel<<<dim3(cdiv(p.Kp, 256), Cin), 256, 0, st>>>(b2, Cin, Cout, p.Kp, 16, (long)Cin * 16, 0, A);
-        launch_window3<false>(xis, dim3(cdiv(p.Tp, 256), Cin), st, a, B, Cin, H, W, xoff, p, 0, Bv);
-        if (int rc = check_launch("wino_window_kernel")) return rc;
-        const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
-        profile_mark_start(st, 3);
-        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, Cin, p.Kp, p.Tp, kt, tt, p.sp, Mo);
-        profile_mark_stop(st, 3, 72.0 * Cin * p.Kp * p.Tp);
-        if (int rc = check_launch("wino_gemm_kernel")) return rc;
-        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cout), 256, 0, st>>>(Mo, p.sp, B, Cout, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, Ho, Wo, 1, 0, out);
-        return check_launch("wino3_output_kernel");
-    }
-    if (mode == 1) {            // a = dy, b2 = w, out = dx
-        // geom 0: only the odd rows / columns receive gradient, dx[2q+1] = sum_r' w[3-r'] dy[q - 1 + r']
-        // geom 1: dx[i] = sum_r' w[3-r'] dy[i - 2 + r'] at every position
-        if (geom == 0 && hipMemsetAsync(out, 0, (size_t)B * Cin * H * W * sizeof(float), st) != hipSuccess)
+    if (mode == 0 || mode == 1) {
+        // mode 0: a = x, b2 = w, out = y.   mode 1: a = dy, b2 = w, out = dx:
+        //   geom 0: only the odd rows / columns receive gradient, dx[2q+1] = sum_r' w[3-r'] dy[q - 1 + r']
+        //   geom 1: dx[i] = sum_r' w[3-r'] dy[i - 2 + r'] at every position
+        //   reduction over Cout: element (c = co, k = ci) of w[co][ci][r][s] at co*Cin*16 + ci*16, taps flipped
+        const int red = mode == 0 ? Cin : Cout, prod = mode == 0 ? Cout : Cin;
+        if (mode == 1 && geom == 0 && hipMemsetAsync(out, 0, (size_t)B * Cin * H * W * (ar.out_bf16 ? 2 : 4), st) != hipSuccess)
             return fail(IPSR_ERR_LAUNCH, "dilated winograd: hipMemsetAsync failed");
-        // reduction over Cout: element (c = co, k = ci) of w[co][ci][r][s] at co*Cin*16 + ci*16, taps flipped
-        wino4_filter_kernel<<<dim3(cdiv(p.Kp, 256), Cout), 256, 0, st>>>(b2, Cout, Cin, p.Kp, (long)Cin * 16, 16, 1, A);
-        launch_window3<false>(1, dim3(cdiv(p.Tp, 256), Cout), st, a, B, Cout, Ho, Wo, geom == 0 ? -1 : -2, p, 0, Bv);
+        const float* w = static_cast<const float*>(b2);
+        with_mode(ar.math, [&](auto M) {
+            constexpr int MODE = decltype(M)::value;
+            if (mode == 0) wino4_filter_kernel<MODE><<<op_grid(false, MODE, p.Kp, Cin), 256, 0, st>>>(w, Cin, Cout, p.Kp, 16, (long)Cin * 16, 0, A);
+            else wino4_filter_kernel<MODE><<<op_grid(false, MODE, p.Kp, Cout), 256, 0, st>>>(w, Cout, Cin, p.Kp, (long)Cin * 16, 16, 1, A);
+            with_type(ar.in_bf16, [&](auto* tag) {
+                using T = ELEM_T(tag);
+                if (mode == 0) launch_window3<false, MODE, T>(xis, st, static_cast<const T*>(a), B, Cin, H, W, xoff, p, 0, Bv);
+                else launch_window3<false, MODE, T>(1, st, static_cast<const T*>(a), B, Cout, Ho, Wo, geom == 0 ? -1 : -2, p, 0, Bv);
+            });
+        });
         if (int rc = check_launch("wino_window_kernel")) return rc;
-        const int kt = p.Kp / WG_BM, tt = p.Tp / WG_BN;
-        profile_mark_start(st, 3);
-        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, Cout, p.Kp, p.Tp, kt, tt, p.sp, Mo);
-        profile_mark_stop(st, 3, 72.0 * Cout * p.Kp * p.Tp);
+        launch_wino_gemm(ar.math, A, Bv, red, p.Kp, p.Tp, p.sp, Mo, st);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
-        wino3_output_kernel<<<dim3(cdiv(p.T, 256), Cin), 256, 0, st>>>(Mo, p.sp, B, Cin, p.Kp, p.Gy, p.Gx, p.TY, p.TX, p.Tp, H, W,
-                                                                         geom == 0 ? 2 : 1, geom == 0 ? 1 : 0, out);
+        with_type(ar.out_bf16, [&](auto* tag) {
+            using T = ELEM_T(tag);
+            if (mode == 0) wino3_output_kernel<T><<<dim3(cdiv(p.T, 256), prod), 256, 0, st>>>(Mo, p.sp, B, Cout, p.Kp, Ho, Wo, p.TY, p.TX, p.Tp, Ho, Wo, 1, 0, static_cast<T*>(out));
+            else wino3_output_kernel<T><<<dim3(cdiv(p.T, 256), prod), 256, 0, st>>>(Mo, p.sp, B, Cin, p.Kp, p.Gy, p.Gx, p.TY, p.TX, p.Tp, H, W,
+                                                                                    geom == 0 ? 2 : 1, geom == 0 ? 1 : 0, static_cast<T*>(out));
+        });
         return check_launch("wino3_output_kernel");
     }
-    // mode 2: a = x, b2 = dy, out = dW [Cout][Cin][4][4]
-    wino_wrw_tile3_kernel<<<dim3(p.Tp / 16, p.Kp / 16), 256, 0, st>>>(b2, B, Cout, Ho, Wo, p.TY, p.TX, p.Tp, p.Kp, A);
-    launch_window3<true>(xis, dim3(p.Tp / 16, p.Cp / 16), st, a, B, Cin, H, W, xoff, p, p.Cp, Bv);
+    // mode 2: a = x, b2 = dy, out = dW [Cout][Cin][4][4] (fp32)
+    with_mode(ar.math, [&](auto M) {
+        constexpr int MODE = decltype(M)::value;
+        with_type(ar.in_bf16, [&](auto* tag) {
+            using T = ELEM_T(tag);
+            wino_wrw_tile3_kernel<MODE, T><<<op_grid(true, MODE, p.Tp, p.Kp), 256, 0, st>>>(static_cast<const T*>(b2), B, Cout, Ho, Wo, p.TY, p.TX, p.Tp, p.Kp, A);
+            launch_window3<true, MODE, T>(xis, st, static_cast<const T*>(a), B, Cin, H, W, xoff, p, p.Cp, Bv);
+        });
+    });
     if (int rc = check_launch("wino_window_kernel")) return rc;
-    const int kt = p.Kp / WG_BM, ct = p.Cp / WG_BN;
-    profile_mark_start(st, 3);
-    wino_gemm_kernel<<<p.sp.workgroups(kt * ct), WG_THREADS, 0, st>>>(A, Bv, p.Tp, p.Kp, p.Cp, kt, ct, p.sp, Mo);
-    profile_mark_stop(st, 3, 72.0 * p.Tp * p.Kp * p.Cp);
+    launch_wino_gemm(ar.math, A, Bv, p.Tp, p.Kp, p.Cp, p.sp, Mo, st);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
-    wino_wrw_output4_kernel<<<dim3(cdiv(Cin, 256), Cout), 256, 0, st>>>(Mo, p.sp, Cout, Cin, p.Kp, p.Cp, out);
+    wino_wrw_output4_kernel<<<dim3(cdiv(Cin, 256), Cout), 256, 0, st>>>(Mo, p.sp, Cout, Cin, p.Kp, p.Cp, static_cast<float*>(out));
     return check_launch("wino_wrw_output4_kernel");
 }
 
@@ -1052,24 +1386,67 @@ __global__ void __launch_bounds__(256) wino52_filter_kernel(const float* __restr
     }
 }
 
+// split-bf16 twin (see store_split): workgroup = 8 reduction indices x 32 columns of (kc, cf) pairs, the four phases stored one after
+// the other.  form 0: reduction (ph, cf) -> blocks of 8 cf, columns kc (grid (Qp/32, Cf/8), padding columns are zero);
+// form 1: reduction kc -> blocks of 8 kc, columns (ph, cf) (grid (Cf/32, Kc/8); host requires Cf % 32 == 0 and Qp == 4*Cf).
+template <int NPL>
+__global__ void __launch_bounds__(256) wino52_filter_split_kernel(const float* __restrict__ W, int Kc, int Cf, int Qp, int form,
+                                                                  unsigned short* __restrict__ U)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short stage[split_stage_elems<NPL>()];
+    const int pk = threadIdx.x >> 5, rl = threadIdx.x & 31;
+    const int kc = form == 0 ? blockIdx.x * SPLIT_ROWS + rl : blockIdx.y * 8 + pk;
+    const int cf = form == 0 ? blockIdx.y * 8 + pk : blockIdx.x * SPLIT_ROWS + rl;
+    const bool live = kc < Kc && cf < Cf;
+    float w[4][4];
+    const float4* wp = reinterpret_cast<const float4*>(W + ((size_t)(live ? kc : 0) * Cf + (live ? cf : 0)) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = live ? wp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
+    }
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const int ey = ph >> 1, ex = ph & 1;
+        float g[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) g[a][b] = form == 0 ? w[2 * a + ey][2 * b + ex] : w[3 - ey - 2 * a][3 - ex - 2 * b];
+        float t[6][2], u[6][6];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float col[2] = {g[0][b], g[1][b]};
+            float o[6];
+            wino_g2(col, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][b] = o[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wino_g2(t[i], u[i]);
+        if (form == 0) store_split<NPL>(stage, u, pk, rl, U, (size_t)4 * Cf / 8, Qp, (size_t)ph * Cf / 8 + blockIdx.y, (size_t)blockIdx.x * SPLIT_ROWS);
+        else store_split<NPL>(stage, u, pk, rl, U, (size_t)Kc / 8, Qp, blockIdx.y, (size_t)ph * Cf + (size_t)blockIdx.x * SPLIT_ROWS);
+    }
+}
+
 // windows at tile stride 5: V[xi][cc][t] (TMAJOR = false) or V[xi][t][cc] (true), cc = (phase, c) of nphase*C.
 //   nphase = 4, IS = 2: P_e[5t + i] = x[2(5t+i) + e], e = (ey-1, ex-1)  (modes 0 and 2, x = the fine tensor)
 //   nphase = 1, IS = 1: x[5t + i - 1]                                    (mode 1, x = the coarse tensor)
-template <int IS, bool TMAJOR>
-__global__ void __launch_bounds__(256) wino5_window_kernel(const float* __restrict__ x, int B, int C, int H, int Wd, int nphase, int TY, int TX,
-                                                           int Tp, int Cp, float* __restrict__ V)
+template <int IS, bool TMAJOR, int MODE, typename TIN>
+__global__ void __launch_bounds__(256) wino5_window_kernel(const TIN* __restrict__ x, int B, int C, int H, int Wd, int nphase, int TY, int TX,
+                                                           int Tp, int Cp, void* __restrict__ V, int remap)
 {
-    __shared__ float stage[TMAJOR ? 36 : 1][16][17];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[op_smem_bytes<TMAJOR, MODE>()];
     const int Ctot = nphase * C;
-    int t, cc, tl = 0, cl = 0, t0 = 0, c0 = 0;
-    if (TMAJOR) { tl = threadIdx.x & 15; cl = threadIdx.x >> 4; t0 = blockIdx.x * 16; c0 = blockIdx.y * 16; t = t0 + tl; cc = c0 + cl; }
-    else { t = blockIdx.x * 256 + threadIdx.x; cc = blockIdx.y; if (t >= Tp) return; }
+    const OpIdx ix = op_index<TMAJOR, MODE>(!TMAJOR && remap != 0);
+    const int t = ix.t, cc = ix.c;
+    if (!TMAJOR && MODE == 0 && t >= Tp) return;
     const int T = B * TY * TX;
     const bool live = t < T && cc < Ctot;
     int b = 0, ty = 0, tx = 0, ph = 0, c = 0;
     if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; ph = cc / C; c = cc - ph * C; }
     const int offy = nphase == 4 ? (ph >> 1) - 1 : -1, offx = nphase == 4 ? (ph & 1) - 1 : -1;
-    const float* xp = x + ((size_t)b * C + c) * H * Wd;
+    const TIN* xp = x + ((size_t)b * C + c) * H * Wd;
     float d[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -1078,7 +1455,7 @@ __global__ void __launch_bounds__(256) wino5_window_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int xx = IS * (5 * tx + j) + offx;
-            d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? xp[(size_t)yy * Wd + xx] : 0.0f;
+            d[i][j] = (yok && (unsigned)xx < (unsigned)Wd) ? ld1(xp, (size_t)yy * Wd + xx) : 0.0f;
         }
     }
     float w[6][6], v[6][6];
@@ -1092,15 +1469,7 @@ __global__ void __launch_bounds__(256) wino5_window_kernel(const float* __restri
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) wino_bt(w[i], v[i]);
-    if (TMAJOR) {
-        wino_store_tmajor(stage, v, tl, cl, V, t0, c0, Tp, Cp);
-    } else {
-        const size_t plane = (size_t)Ctot * Tp;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) V[(size_t)(i * 6 + j) * plane + (size_t)cc * Tp + t] = v[i][j];
-    }
+    op_emit<TMAJOR, MODE>(smem, v, ix, V, TMAJOR ? Cp : Ctot, Tp);
 }
 
 __device__ __forceinline__ void wino_at5_2d(const float m[6][6], float o[5][5])
@@ -1119,8 +1488,9 @@ __device__ __forceinline__ void wino_at5_2d(const float m[6][6], float o[5][5])
 }
 
 // mode 0: y[b][k][5ty+i][5tx+j] = (A5^T M A5)[i][j]
+template <typename TOUT>
 __global__ void __launch_bounds__(256) wino5_output_kernel(const float* __restrict__ Mo, WinoSplit split, int B, int K, int Kp, int Ho, int Wo,
-                                                           int TY, int TX, int Tp, float* __restrict__ y)
+                                                           int TY, int TX, int Tp, TOUT* __restrict__ y)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
     const int T = B * TY * TX;
@@ -1130,21 +1500,22 @@ __global__ void __launch_bounds__(256) wino5_output_kernel(const float* __restri
     wino_at5_2d(m, o);
     const int b = t / (TY * TX), rem = t - b * TY * TX;
     const int ty = rem / TX, tx = rem - ty * TX;
-    float* yp = y + ((size_t)b * K + k) * Ho * Wo;
+    TOUT* yp = y + ((size_t)b * K + k) * Ho * Wo;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int oy = 5 * ty + i, ox = 5 * tx + j;
-            if (oy < Ho && ox < Wo) yp[(size_t)oy * Wo + ox] = o[i][j];
+            if (oy < Ho && ox < Wo) st1(yp, (size_t)oy * Wo + ox, o[i][j]);
         }
 }
 
 // mode 1: phase ph = blockIdx.z of tile t and fine channel k (GEMM row ph*K + k) -> its 25 pixels of y [B,K,2n_h,2n_w]:
 // y[2(5ty+m) - ey][2(5tx+m') - ex] = (A5^T M_ph A5)[m][m']  wherever the coarse index 5t + m - e lies in [0, n).
 // One phase per thread (not the four of a tile): four times the threads in flight — these launches are latency bound.
+template <typename TOUT>
 __global__ void __launch_bounds__(256) wino5_output_phase_kernel(const float* __restrict__ Mo, WinoSplit split, int B, int K, int Kp, int nh, int nw,
-                                                                 int TY, int TX, int Tp, float* __restrict__ y)
+                                                                 int TY, int TX, int Tp, TOUT* __restrict__ y)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
     const int T = B * TY * TX;
@@ -1152,7 +1523,7 @@ __global__ void __launch_bounds__(256) wino5_output_phase_kernel(const float* __
     const int b = t / (TY * TX), rem = t - b * TY * TX;
     const int ty = rem / TX, tx = rem - ty * TX;
     const int Wy = 2 * nw;
-    float* yp = y + ((size_t)b * K + k) * (size_t)(2 * nh) * Wy;
+    TOUT* yp = y + ((size_t)b * K + k) * (size_t)(2 * nh) * Wy;
     const int ph = blockIdx.z, ey = ph >> 1, ex = ph & 1;
     float m[6][6], o[5][5];
     wino_load_sum(Mo, split, (size_t)Kp * Tp, (size_t)(ph * K + k) * Tp + t, m);
@@ -1161,34 +1532,34 @@ __global__ void __launch_bounds__(256) wino5_output_phase_kernel(const float* __
     for (int i = 0; i < 5; ++i) {
         const int iy = 5 * ty + i - ey;
         if (iy < 0 || iy >= nh) continue;
-        float* row = yp + (size_t)(2 * iy + ey) * Wy + ex;
+        TOUT* row = yp + (size_t)(2 * iy + ey) * Wy + ex;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int ix = 5 * tx + j - ex;
-            if (ix >= 0 && ix < nw) row[2 * ix] = o[i][j];
+            if (ix >= 0 && ix < nw) st1(row, (size_t)(2 * ix), o[i][j]);
         }
     }
 }
 
 // mode 2: 5x5 tiles of the coarse tensor -> Et[xi][t][k] = (G5 e G5^T)[xi]
-__global__ void __launch_bounds__(256) wino_wrw_tile5_kernel(const float* __restrict__ dy, int B, int K, int Ho, int Wo, int TY, int TX,
-                                                             int Tp, int Kp, float* __restrict__ Et)
+template <int MODE, typename TIN>
+__global__ void __launch_bounds__(256) wino_wrw_tile5_kernel(const TIN* __restrict__ dy, int B, int K, int Ho, int Wo, int TY, int TX,
+                                                             int Tp, int Kp, void* __restrict__ Et)
 {
-    __shared__ float stage[36][16][17];
-    const int tl = threadIdx.x & 15, cl = threadIdx.x >> 4;
-    const int t0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
-    const int t = t0 + tl, k = k0 + cl, T = B * TY * TX;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[op_smem_bytes<true, MODE>()];
+    const OpIdx ix = op_index<true, MODE>(false);
+    const int t = ix.t, k = ix.c, T = B * TY * TX;
     const bool live = t < T && k < K;
     int b = 0, ty = 0, tx = 0;
     if (live) { b = t / (TY * TX); const int rem = t - b * TY * TX; ty = rem / TX; tx = rem - ty * TX; }
-    const float* dp = dy + ((size_t)b * K + (live ? k : 0)) * Ho * Wo;
+    const TIN* dp = dy + ((size_t)b * K + (live ? k : 0)) * Ho * Wo;
     float e[5][5];
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int yy = 5 * ty + i, xx = 5 * tx + j;
-            e[i][j] = (live && yy < Ho && xx < Wo) ? dp[(size_t)yy * Wo + xx] : 0.0f;
+            e[i][j] = (live && yy < Ho && xx < Wo) ? ld1(dp, (size_t)yy * Wo + xx) : 0.0f;
         }
     float w[6][5], v[6][6];
 #pragma unroll
@@ -1201,7 +1572,7 @@ __global__ void __launch_bounds__(256) wino_wrw_tile5_kernel(const float* __rest
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) wino_g5(w[i], v[i]);
-    wino_store_tmajor(stage, v, tl, cl, Et, t0, k0, Tp, Kp);
+    op_emit<true, MODE>(smem, v, ix, Et, Kp, Tp);
 }
 
 // mode 2: dW[kc][cf][2a+ey][2b+ex] = (A2^T Mw[:][kc][(ph, cf)] A2)[a][b]; one phase per blockIdx.z
@@ -1243,8 +1614,8 @@ static int s2_plan(int mode, int B, int Kc, int Cf, int nh, int nw, S2Plan* p)
         p->Kp = (Kc + WG_BM - 1) / WG_BM * WG_BM;
         p->Cp = (4 * Cf + WG_BN - 1) / WG_BN * WG_BN;
         p->red = p->Tp;
-        p->a_floats = (size_t)36 * p->Tp * p->Kp;
-        p->b_floats = (size_t)36 * p->Tp * p->Cp;
+        p->a_floats = (size_t)36 * p->Tp * p->Kp * 3 / 2;
+        p->b_floats = (size_t)36 * p->Tp * p->Cp * 3 / 2;
         m1 = (size_t)36 * p->Kp * p->Cp;
         p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
     } else {
@@ -1254,8 +1625,8 @@ static int s2_plan(int mode, int B, int Kc, int Cf, int nh, int nw, S2Plan* p)
         const int prod = mode == 0 ? Kc : 4 * Cf;
         p->Kp = (prod + WG_BM - 1) / WG_BM * WG_BM;
         p->Cp = p->red;
-        p->a_floats = (size_t)36 * p->red * p->Kp;
-        p->b_floats = (size_t)36 * p->red * p->Tp;
+        p->a_floats = (size_t)36 * p->red * p->Kp * 3 / 2;
+        p->b_floats = (size_t)36 * p->red * p->Tp * 3 / 2;
         m1 = (size_t)36 * p->Kp * p->Tp;
         p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), p->red / WG_BK, m1 * 4);
     }
@@ -1273,50 +1644,62 @@ size_t winograd_s2_ws_bytes(int mode, int B, int Kc, int Cf, int nh, int nw)
 
 // fine [B,Cf,2nh,2nw], coarse [B,Kc,nh,nw], w / dW [Kc][Cf][4][4].
 // mode 0: a = fine, b2 = w, out = coarse.   mode 1: a = coarse, b2 = w, out = fine.   mode 2: a = fine, b2 = coarse, out = dW.
-int launch_winograd_s2(int mode, const float* a, const float* b2, float* out, int B, int Kc, int Cf, int nh, int nw,
-                       void* ws, size_t ws_bytes, hipStream_t st)
+int launch_winograd_s2(int mode, const void* a, const void* b2, void* out, int B, int Kc, int Cf, int nh, int nw,
+                       void* ws, size_t ws_bytes, hipStream_t st, ConvArith ar = ConvArith{0, false, false})
 {
     S2Plan p;
     if (int rc = s2_plan(mode, B, Kc, Cf, nh, nw, &p)) return rc;
     if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "4x4 stride-2 winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
+    if (!arith_ok(ar)) return fail(IPSR_ERR_INVALID, "4x4 stride-2 winograd: arithmetic %d", ar.math);
+    // the split filter transform stores whole 8-channel blocks per phase (form 0) / whole 32-column blocks per phase (form 1):
+    // shapes it cannot express run the fp32 arithmetic instead (never less accurate)
+    if (ar.math && ((mode == 0 && Cf % 8 != 0) || (mode == 1 && (Cf % SPLIT_ROWS != 0 || p.Kp != 4 * Cf || Kc % 8 != 0)))) ar.math = 0;
     Carver cv(ws, ws_bytes);
     float* A = cv.take<float>(p.a_floats);
     float* Bv = cv.take<float>(p.b_floats);
     float* Mo = cv.take<float>(p.m_floats);
-    const int kt = p.Kp / WG_BM;
-    if (mode == 0) {
-        wino52_filter_kernel<<<dim3(cdiv(p.Kp, 256), Cf), 256, 0, st>>>(b2, Kc, Cf, p.Kp, 0, A);
-        wino5_window_kernel<2, false><<<dim3(cdiv(p.Tp, 256), p.red), 256, 0, st>>>(a, B, Cf, 2 * nh, 2 * nw, 4, p.TY, p.TX, p.Tp, 0, Bv);
+    const int remap = !debug_option(1);          // XCD-contiguous (channel, tile block) ranges; debug option 1 = off
+    if (mode == 0 || mode == 1) {
+        const float* w = static_cast<const float*>(b2);
+        if (ar.math == 0) {
+            if (mode == 0) wino52_filter_kernel<<<dim3(cdiv(p.Kp, 256), Cf), 256, 0, st>>>(w, Kc, Cf, p.Kp, 0, A);
+            else wino52_filter_kernel<<<dim3(cdiv(Cf + (p.Kp - 4 * Cf), 256), Kc), 256, 0, st>>>(w, Kc, Cf, p.Kp, 1, A);
+        } else {
+            const dim3 fg = mode == 0 ? dim3(p.Kp / SPLIT_ROWS, Cf / 8) : dim3(Cf / SPLIT_ROWS, Kc / 8);
+            if (ar.math == 2) wino52_filter_split_kernel<2><<<fg, 256, 0, st>>>(w, Kc, Cf, p.Kp, mode, reinterpret_cast<unsigned short*>(A));
+            else wino52_filter_split_kernel<3><<<fg, 256, 0, st>>>(w, Kc, Cf, p.Kp, mode, reinterpret_cast<unsigned short*>(A));
+        }
+        with_mode(ar.math, [&](auto M) {
+            constexpr int MODE = decltype(M)::value;
+            with_type(ar.in_bf16, [&](auto* tag) {
+                using T = ELEM_T(tag);
+                if (mode == 0) wino5_window_kernel<2, false, MODE, T><<<op_grid(false, MODE, p.Tp, p.red), 256, 0, st>>>(static_cast<const T*>(a), B, Cf, 2 * nh, 2 * nw, 4, p.TY, p.TX, p.Tp, 0, Bv, remap);
+                else wino5_window_kernel<1, false, MODE, T><<<op_grid(false, MODE, p.Tp, p.red), 256, 0, st>>>(static_cast<const T*>(a), B, Kc, nh, nw, 1, p.TY, p.TX, p.Tp, 0, Bv, remap);
+            });
+        });
         if (int rc = check_launch("wino5_window_kernel")) return rc;
-        const int tt = p.Tp / WG_BN;
-        profile_mark_start(st, 3);
-        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, p.red, p.Kp, p.Tp, kt, tt, p.sp, Mo);
-        profile_mark_stop(st, 3, 72.0 * p.red * p.Kp * p.Tp);
+        launch_wino_gemm(ar.math, A, Bv, p.red, p.Kp, p.Tp, p.sp, Mo, st);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
-        wino5_output_kernel<<<dim3(cdiv(p.T, 256), Kc), 256, 0, st>>>(Mo, p.sp, B, Kc, p.Kp, nh, nw, p.TY, p.TX, p.Tp, out);
+        with_type(ar.out_bf16, [&](auto* tag) {
+            using T = ELEM_T(tag);
+            if (mode == 0) wino5_output_kernel<T><<<dim3(cdiv(p.T, 256), Kc), 256, 0, st>>>(Mo, p.sp, B, Kc, p.Kp, nh, nw, p.TY, p.TX, p.Tp, static_cast<T*>(out));
+            else wino5_output_phase_kernel<T><<<dim3(cdiv(p.T, 256), Cf, 4), 256, 0, st>>>(Mo, p.sp, B, Cf, p.Kp, nh, nw, p.TY, p.TX, p.Tp, static_cast<T*>(out));
+        });
         return check_launch("wino5_output_kernel");
     }
-    if (mode == 1) {
-        wino52_filter_kernel<<<dim3(cdiv(Cf + (p.Kp - 4 * Cf), 256), Kc), 256, 0, st>>>(b2, Kc, Cf, p.Kp, 1, A);
-        wino5_window_kernel<1, false><<<dim3(cdiv(p.Tp, 256), p.red), 256, 0, st>>>(a, B, Kc, nh, nw, 1, p.TY, p.TX, p.Tp, 0, Bv);
-        if (int rc = check_launch("wino5_window_kernel")) return rc;
-        const int tt = p.Tp / WG_BN;
-        profile_mark_start(st, 3);
-        wino_gemm_kernel<<<p.sp.workgroups(kt * tt), WG_THREADS, 0, st>>>(A, Bv, p.red, p.Kp, p.Tp, kt, tt, p.sp, Mo);
-        profile_mark_stop(st, 3, 72.0 * p.red * p.Kp * p.Tp);
-        if (int rc = check_launch("wino_gemm_kernel")) return rc;
-        wino5_output_phase_kernel<<<dim3(cdiv(p.T, 256), Cf, 4), 256, 0, st>>>(Mo, p.sp, B, Cf, p.Kp, nh, nw, p.TY, p.TX, p.Tp, out);
-        return check_launch("wino5_output_phase_kernel");
-    }
-    wino_wrw_tile5_kernel<<<dim3(p.Tp / 16, p.Kp / 16), 256, 0, st>>>(b2, B, Kc, nh, nw, p.TY, p.TX, p.Tp, p.Kp, A);
-    wino5_window_kernel<2, true><<<dim3(p.Tp / 16, p.Cp / 16), 256, 0, st>>>(a, B, Cf, 2 * nh, 2 * nw, 4, p.TY, p.TX, p.Tp, p.Cp, Bv);
+    // mode 2: a = fine, b2 = coarse, out = dW (fp32)
+    with_mode(ar.math, [&](auto M) {
+        constexpr int MODE = decltype(M)::value;
+        with_type(ar.in_bf16, [&](auto* tag) {
+            using T = ELEM_T(tag);
+            wino_wrw_tile5_kernel<MODE, T><<<op_grid(true, MODE, p.Tp, p.Kp), 256, 0, st>>>(static_cast<const T*>(b2), B, Kc, nh, nw, p.TY, p.TX, p.Tp, p.Kp, A);
+            wino5_window_kernel<2, true, MODE, T><<<op_grid(true, MODE, p.Tp, p.Cp), 256, 0, st>>>(static_cast<const T*>(a), B, Cf, 2 * nh, 2 * nw, 4, p.TY, p.TX, p.Tp, p.Cp, Bv, 0);
+        });
+    });
     if (int rc = check_launch("wino5_window_kernel")) return rc;
-    const int ct = p.Cp / WG_BN;
-    profile_mark_start(st, 3);
-    wino_gemm_kernel<<<p.sp.workgroups(kt * ct), WG_THREADS, 0, st>>>(A, Bv, p.Tp, p.Kp, p.Cp, kt, ct, p.sp, Mo);
-    profile_mark_stop(st, 3, 72.0 * p.Tp * p.Kp * p.Cp);
+    launch_wino_gemm(ar.math, A, Bv, p.Tp, p.Kp, p.Cp, p.sp, Mo, st);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
-    wino_wrw_output2_kernel<<<dim3(cdiv(Cf, 256), Kc, 4), 256, 0, st>>>(Mo, p.sp, Kc, Cf, p.Kp, p.Cp, out);
+    wino_wrw_output2_kernel<<<dim3(cdiv(Cf, 256), Kc, 4), 256, 0, st>>>(Mo, p.sp, Kc, Cf, p.Kp, p.Cp, static_cast<float*>(out));
     return check_launch("wino_wrw_output2_kernel");
 }
 
@@ -1722,25 +2105,42 @@ size_t ipsr_conv3x3_winograd_workspace_bytes(int op, int B, int Cin, int H, int 
     return winograd_ws_bytes(B, fwd ? Cin : Cout, fwd ? Cout : Cin, H, W);
 }
 
-int ipsr_conv3x3_winograd(int op, const float* in, const float* weight, float* out, int B, int Cin, int H, int W, int Cout,
-                          void* ws, size_t ws_bytes, void* stream)
+static int arith_from(const char* who, int math, int io, ConvArith* ar)
+{
+    if ((math != 0 && math != 2 && math != 3) || io < 0 || io > 3)
+        return fail(IPSR_ERR_INVALID, "%s: math %d (0 = fp32 MFMA, 2 = split bf16 x3, 3 = split bf16 x6) / io %d (bit 0: bf16 activations in, bit 1: out)", who, math, io);
+    ar->math = math; ar->in_bf16 = (io & 1) != 0; ar->out_bf16 = (io & 2) != 0;
+    return IPSR_OK;
+}
+
+int ipsr_conv3x3_winograd_mp(int op, const void* in, const float* weight, const float* bias, int epilogue, float* filter_cache,
+                             int filter_cache_valid, void* out, int B, int Cin, int H, int W, int Cout, int math, int io,
+                             void* ws, size_t ws_bytes, void* stream)
 {
     if (!in || !weight || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd: null pointer");
     if (op < 0 || op > 3 || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd: bad argument");
-    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
-        return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd: out / workspace must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u) || (reinterpret_cast<uintptr_t>(filter_cache) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd: out / workspace / filter_cache must be 16-byte aligned");
+    ConvArith ar;
+    if (int rc = arith_from("ipsr_conv3x3_winograd_mp", math, io, &ar)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // k3 s1 p1: input and output have the same extent.  C = reduction channels, K = produced channels.
     switch (op) {
         case 0:      // Conv2d forward: weight [Cout][Cin][3][3]: (c, k) at c*9 + k*Cin*9
-            return launch_winograd(in, weight, out, B, Cin, Cout, H, W, 9, (long)Cin * 9, 0, ws, ws_bytes, st);
+            return launch_winograd(in, weight, out, B, Cin, Cout, H, W, 9, (long)Cin * 9, 0, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid, ar);
         case 1:      // Conv2d backward-data: dx = conv(dy, flipped w), reduction over Cout: (c=co, k=ci) at co*Cin*9 + ci*9
-            return launch_winograd(in, weight, out, B, Cout, Cin, H, W, (long)Cin * 9, 9, 1, ws, ws_bytes, st);
+            return launch_winograd(in, weight, out, B, Cout, Cin, H, W, (long)Cin * 9, 9, 1, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid, ar);
         case 2:      // ConvTranspose2d forward: weight [Cin][Cout][3][3], flipped: (c=ci, k=co) at ci*Cout*9 + co*9
-            return launch_winograd(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, ws, ws_bytes, st);
+            return launch_winograd(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid, ar);
         default:     // ConvTranspose2d backward-data: dx = conv(dy, w as [ci][co]), reduction over Cout: (c=co, k=ci) at co*9 + ci*Cout*9
-            return launch_winograd(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, ws, ws_bytes, st);
+            return launch_winograd(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid, ar);
     }
+}
+
+int ipsr_conv3x3_winograd(int op, const float* in, const float* weight, float* out, int B, int Cin, int H, int W, int Cout,
+                          void* ws, size_t ws_bytes, void* stream)
+{
+    return ipsr_conv3x3_winograd_mp(op, in, weight, nullptr, 0, nullptr, 0, out, B, Cin, H, W, Cout, 0, 0, ws, ws_bytes, stream);
 }
 
 size_t ipsr_conv3x3_winograd_filter_floats(int op, int Cin, int Cout)
@@ -1754,17 +2154,7 @@ int ipsr_conv3x3_winograd_ex(int op, const float* in, const float* weight, const
                              int filter_cache_valid, float* out, int B, int Cin, int H, int W, int Cout,
                              void* ws, size_t ws_bytes, void* stream)
 {
-    if (!in || !weight || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_ex: null pointer");
-    if (op < 0 || op > 3 || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_ex: bad argument");
-    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u) || (reinterpret_cast<uintptr_t>(filter_cache) & 15u))
-        return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_ex: out / workspace / filter_cache must be 16-byte aligned");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (op) {
-        case 0: return launch_winograd(in, weight, out, B, Cin, Cout, H, W, 9, (long)Cin * 9, 0, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
-        case 1: return launch_winograd(in, weight, out, B, Cout, Cin, H, W, (long)Cin * 9, 9, 1, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
-        case 2: return launch_winograd(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
-        default: return launch_winograd(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, ws, ws_bytes, st, bias, epilogue, filter_cache, filter_cache_valid);
-    }
+    return ipsr_conv3x3_winograd_mp(op, in, weight, bias, epilogue, filter_cache, filter_cache_valid, out, B, Cin, H, W, Cout, 0, 0, ws, ws_bytes, stream);
 }
 
 size_t ipsr_conv4x4_winograd_workspace_bytes(int geom, int mode, int B, int Cin, int H, int W, int Cout)
@@ -1773,15 +2163,23 @@ size_t ipsr_conv4x4_winograd_workspace_bytes(int geom, int mode, int B, int Cin,
     return winograd_dil_ws_bytes(geom, mode, B, Cin, H, W, Cout);
 }
 
-int ipsr_conv4x4_winograd(int geom, int mode, const float* a, const float* b, float* out, int B, int Cin, int H, int W, int Cout,
-                          void* ws, size_t ws_bytes, void* stream)
+int ipsr_conv4x4_winograd_mp(int geom, int mode, const void* a, const void* b, void* out, int B, int Cin, int H, int W, int Cout,
+                             int math, int io, void* ws, size_t ws_bytes, void* stream)
 {
     if (!a || !b || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_winograd: null pointer");
     if (geom < 0 || geom > 1 || mode < 0 || mode > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2)
         return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_winograd: bad argument");
     if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
         return fail(IPSR_ERR_INVALID, "ipsr_conv4x4_winograd: out / workspace must be 16-byte aligned");
-    return launch_winograd_dil(geom, mode, a, b, out, B, Cin, H, W, Cout, ws, ws_bytes, static_cast<hipStream_t>(stream));
+    ConvArith ar;
+    if (int rc = arith_from("ipsr_conv4x4_winograd_mp", math, io, &ar)) return rc;
+    return launch_winograd_dil(geom, mode, a, b, out, B, Cin, H, W, Cout, ws, ws_bytes, static_cast<hipStream_t>(stream), ar);
+}
+
+int ipsr_conv4x4_winograd(int geom, int mode, const float* a, const float* b, float* out, int B, int Cin, int H, int W, int Cout,
+                          void* ws, size_t ws_bytes, void* stream)
+{
+    return ipsr_conv4x4_winograd_mp(geom, mode, a, b, out, B, Cin, H, W, Cout, 0, 0, ws, ws_bytes, stream);
 }
 
 size_t ipsr_conv4x4_dilated_winograd_workspace_bytes(int mode, int B, int Cin, int H, int W, int Cout)
@@ -1801,14 +2199,22 @@ size_t ipsr_conv4x4s2_winograd_workspace_bytes(int mode, int B, int Kc, int Cf, 
     return winograd_s2_ws_bytes(mode, B, Kc, Cf, nh, nw);
 }
 
-int ipsr_conv4x4s2_winograd(int mode, const float* a, const float* b, float* out, int B, int Kc, int Cf, int nh, int nw,
-                            void* ws, size_t ws_bytes, void* stream)
+int ipsr_conv4x4s2_winograd_mp(int mode, const void* a, const void* b, void* out, int B, int Kc, int Cf, int nh, int nw,
+                               int math, int io, void* ws, size_t ws_bytes, void* stream)
 {
     if (!a || !b || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_winograd: null pointer");
     if (mode < 0 || mode > 2 || B < 1 || Kc < 1 || Cf < 1 || nh < 1 || nw < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_winograd: bad argument");
     if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
         return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_winograd: out / workspace must be 16-byte aligned");
-    return launch_winograd_s2(mode, a, b, out, B, Kc, Cf, nh, nw, ws, ws_bytes, static_cast<hipStream_t>(stream));
+    ConvArith ar;
+    if (int rc = arith_from("ipsr_conv4x4s2_winograd_mp", math, io, &ar)) return rc;
+    return launch_winograd_s2(mode, a, b, out, B, Kc, Cf, nh, nw, ws, ws_bytes, static_cast<hipStream_t>(stream), ar);
+}
+
+int ipsr_conv4x4s2_winograd(int mode, const float* a, const float* b, float* out, int B, int Kc, int Cf, int nh, int nw,
+                            void* ws, size_t ws_bytes, void* stream)
+{
+    return ipsr_conv4x4s2_winograd_mp(mode, a, b, out, B, Kc, Cf, nh, nw, 0, 0, ws, ws_bytes, stream);
 }
 
 size_t ipsr_conv_smallmap_workspace_bytes(int op, int B, int R, int Cq, int Ho, int Wo, int Hf, int Wf, int k, int stride, int pad, int dil)
@@ -1834,17 +2240,25 @@ size_t ipsr_conv3x3_winograd_wrw_workspace_bytes(int transposed, int B, int Cin,
     return transposed ? winograd_wrw_ws_bytes(B, Cin, Cout, H, W) : winograd_wrw_ws_bytes(B, Cout, Cin, H, W);
 }
 
-int ipsr_conv3x3_winograd_wrw(int transposed, const float* x, const float* dy, float* dw, int B, int Cin, int H, int W, int Cout,
-                              void* ws, size_t ws_bytes, void* stream)
+int ipsr_conv3x3_winograd_wrw_mp(int transposed, const void* x, const void* dy, float* dw, int B, int Cin, int H, int W, int Cout,
+                                 int math, int io, void* ws, size_t ws_bytes, void* stream)
 {
     if (!x || !dy || !dw || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_wrw: null pointer");
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_wrw: bad argument");
     if (reinterpret_cast<uintptr_t>(ws) & 15u) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_winograd_wrw: workspace must be 16-byte aligned");
+    ConvArith ar;
+    if (int rc = arith_from("ipsr_conv3x3_winograd_wrw_mp", math, io, &ar)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // Conv2d:          dW[co][ci][r][s] = sum dy[co][o] x[ci][o + r - 1]       tile operand dy, window operand x
     // ConvTranspose2d: dW[ci][co][r][s] = sum x[ci][i] dy[co][i + r - 1]       tile operand x,  window operand dy
-    if (transposed) return launch_winograd_wrw(x, dy, dw, B, Cin, Cout, H, W, ws, ws_bytes, st);
-    return launch_winograd_wrw(dy, x, dw, B, Cout, Cin, H, W, ws, ws_bytes, st);
+    if (transposed) return launch_winograd_wrw(x, dy, dw, B, Cin, Cout, H, W, ws, ws_bytes, st, ar);
+    return launch_winograd_wrw(dy, x, dw, B, Cout, Cin, H, W, ws, ws_bytes, st, ar);
+}
+
+int ipsr_conv3x3_winograd_wrw(int transposed, const float* x, const float* dy, float* dw, int B, int Cin, int H, int W, int Cout,
+                              void* ws, size_t ws_bytes, void* stream)
+{
+    return ipsr_conv3x3_winograd_wrw_mp(transposed, x, dy, dw, B, Cin, H, W, Cout, 0, 0, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

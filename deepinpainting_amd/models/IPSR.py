@@ -48,6 +48,11 @@ class IPSR(BaseModel):
         # BASELINE config 5: convolutions under bf16 autocast (CDNA4 bf16 MFMA); the IPSR layer, the InnerCos taps and all
         # losses stay fp32.  Off by default — the reference is fp32.
         self.amp_bf16 = bool(getattr(opt, 'amp_bf16', False))
+        # arithmetic of the Winograd convolution engines (models/hipconv.py, ops.MATH_CODE): fp32 operands on the fp32 matrix cores by
+        # default (the reference's arithmetic); "bf16x6" (fp32-accurate, split operands on the bf16 matrix cores) / "bf16x3" are opt-in.
+        # Under amp_bf16 the engines read / write bf16 activations and multiply split-bf16 operands (`conv_math_bf16`, default "bf16x3").
+        from . import hipconv
+        hipconv.set_conv_math(fp32=getattr(opt, 'conv_math', 'fp32'), bf16=getattr(opt, 'conv_math_bf16', 'bf16x3'))
         # conv-bias + InstanceNorm + activation in one HIP kernel each way (models/fused.py); False = plain torch modules
         networks.FusedSequential.enabled = bool(getattr(opt, 'fused_norm_act', True))
 

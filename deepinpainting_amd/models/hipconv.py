@@ -38,16 +38,37 @@ from .. import ops
 from .. import dist as ipsr_dist
 
 _FORCE = None          # test hook: overrides the environment
+# Arithmetic of the Winograd GEMMs (ops.MATH_CODE): "fp32" for fp32 activations (the reference's arithmetic; "bf16x6" / "bf16x3" are
+# opt-in, models/IPSR.py `opt.conv_math`), "bf16x3" for bf16 activations / under bf16 autocast (BASELINE config 5).
+_MATH = {"fp32": "fp32", "bf16": "bf16x3"}
+_BF16_ENGINES = ("winograd", "wino_dil", "wino_s2")         # the engines that read / write bf16 activation tensors
+
+
+def set_conv_math(fp32=None, bf16=None):
+    """Choose the arithmetic of the Winograd engines for fp32 activations and for bf16 activations (autocast)."""
+    from .. import ops as _ops
+    for key, val in (("fp32", fp32), ("bf16", bf16)):
+        if val is not None:
+            if val not in _ops.MATH_CODE:
+                raise ValueError("conv math must be one of %s" % sorted(k for k in _ops.MATH_CODE if k))
+            _MATH[key] = val
+
+
+def _amp_bf16():
+    return torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+_check_hook = None     # test hook: callable(kind, engine, geometry, operands, result) after every engine call of _HipConv
 
 
 def _mode():
     return _FORCE or os.environ.get("IPSR_CONV_ENGINE", "auto")
 
 
-def select(op, B, Cin, H, W, Cout, k, stride, pad, dil):
+def select(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     """-> the engine for one convolution call.  (Cin, H, W) = the module's input, as in ipsr_conv2d.  Memoised per (mode, shape):
-    the rules query the library (workspace probes), ~150 convolution calls per training step ask."""
-    return _select(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0") + os.environ.get("IPSR_NO_THIN", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
+    the rules query the library (workspace probes), ~150 convolution calls per training step ask.
+    bf16: the activations are bf16 tensors — only the Winograd engines read / write those; every other shape takes MIOpen."""
+    eng = _select(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0") + os.environ.get("IPSR_NO_THIN", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
+    return eng if (not bf16 or eng in _BF16_ENGINES) else "miopen"
 
 
 @functools.lru_cache(maxsize=4096)
@@ -160,10 +181,11 @@ def _is_k4s1(k, stride, pad, dil):
     return k == 4 and stride == 1 and pad == 1 and dil == 1
 
 
-def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
+def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     """-> the engine for the weight gradient of one layer (profiles/r02_hipconv_k3_wrw.txt: F(3x3,4x4) is 2.0-2.4x
     MIOpen from 256 channels up on maps of 16x16..64x64; on larger maps its tile-major transforms lose to MIOpen)."""
-    return _select_wrw(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0"), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+    eng = _select_wrw(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0"), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+    return eng if (not bf16 or eng in _BF16_ENGINES) else "miopen"
 
 
 @functools.lru_cache(maxsize=4096)
@@ -189,75 +211,101 @@ def _select_wrw(mode, _nosm, transposed, B, Cin, H, W, Cout, k, stride, pad, dil
     return "miopen"
 
 
+def _miopen_forward(x, w, transposed, stride, pad, dil):
+    if x.dtype != w.dtype and not torch.is_autocast_enabled():
+        w = w.to(x.dtype)
+    return F.conv_transpose2d(x, w, None, stride, pad, 0, 1, dil) if transposed else F.conv2d(x, w, None, stride, pad, dil)
+
+
+def _miopen_backward(dy, x, w, transposed, stride, pad, dil, which):
+    """aten.convolution_backward on operands of ONE dtype (bf16 activations: the fp32 weight is cast, its gradient cast back)."""
+    dt = dy.dtype
+    out = torch.ops.aten.convolution_backward(dy, x if x.dtype == dt else x.to(dt), w if w.dtype == dt else w.to(dt), None, [stride, stride],
+                                              [pad, pad], [dil, dil], transposed, [0, 0], 1, which)
+    return out[0], (out[1].to(w.dtype) if out[1] is not None else None)
+
+
 class _HipConv(torch.autograd.Function):
-    """Bias-free Conv2d / ConvTranspose2d: forward and input gradient on the selected HIP engine, weight gradient on MIOpen."""
+    """Bias-free Conv2d / ConvTranspose2d: forward, input gradient and weight gradient each on the engine `select` names for it
+    (MIOpen where none is faster).  `math` = the Winograd engines' arithmetic, `act` = dtype of the activation tensors produced."""
 
     @staticmethod
-    def forward(ctx, x, w, transposed, k, stride, pad, dil, eng_fwd):
+    def forward(ctx, x, w, transposed, k, stride, pad, dil, eng_fwd, math, act):
         B, Cin, H, W = x.shape
         Cout = w.shape[1] if transposed else w.shape[0]
         op = ops.CONVT_FWD if transposed else ops.CONV_FWD
         xc = x.contiguous()
         if eng_fwd == "winograd":
-            y = ops.conv3x3_winograd(op, xc, w, (B, Cin, H, W), Cout)
+            y = ops.conv3x3_winograd(op, xc, w, (B, Cin, H, W), Cout, math=math, out_dtype=act)
         elif eng_fwd == "direct":
             y = ops.conv2d(op, xc, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng_fwd == "wino_dil":
-            y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+            y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=act)
         elif eng_fwd == "thin":
             y = ops.conv3x3_thin(op, xc, w, (B, Cin, H, W), Cout)
         elif eng_fwd == "smallmap":
             y = ops.conv_smallmap(_smallmap_op(op), xc, w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         elif eng_fwd == "wino_s2":
-            y = ops.conv4x4s2_winograd(_s2_mode(op), xc, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
+            y = ops.conv4x4s2_winograd(_s2_mode(op), xc, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), math=math, out_dtype=act)
         else:
-            y = (F.conv_transpose2d(xc, w, None, stride, pad, 0, 1, dil) if transposed else F.conv2d(xc, w, None, stride, pad, dil))
+            y = _miopen_forward(xc, w, transposed, stride, pad, dil)
         ctx.save_for_backward(xc, w)
         ctx.geom = (transposed, k, stride, pad, dil, Cout)
+        ctx.math, ctx.bf16 = math, act == torch.bfloat16
+        if _check_hook is not None:
+            _check_hook("forward", eng_fwd, ctx.geom, (xc, w), y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         transposed, k, stride, pad, dil, Cout = ctx.geom
+        math, bf16 = ctx.math, ctx.bf16
         B, Cin, H, W = x.shape
         dy = dy.contiguous()
+        if bf16 and dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             op = ops.CONVT_BWD_DATA if transposed else ops.CONV_BWD_DATA
-            eng = select(op, B, Cin, H, W, Cout, k, stride, pad, dil)
+            eng = select(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16)
             if eng == "winograd":
-                dx = ops.conv3x3_winograd(op, dy, w, (B, Cin, H, W), Cout)
+                dx = ops.conv3x3_winograd(op, dy, w, (B, Cin, H, W), Cout, math=math, out_dtype=x.dtype)
             elif eng == "direct":
                 dx = ops.conv2d(op, dy, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
             elif eng == "wino_dil":
-                dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+                dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=x.dtype)
             elif eng == "thin":
                 dx = ops.conv3x3_thin(op, dy, w, (B, Cin, H, W), Cout)
             elif eng == "smallmap":
                 dx = ops.conv_smallmap(_smallmap_op(op), dy, w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
             elif eng == "wino_s2":
-                dx = ops.conv4x4s2_winograd(_s2_mode(op), dy, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
+                dx = ops.conv4x4s2_winograd(_s2_mode(op), dy, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), math=math, out_dtype=x.dtype)
             else:
-                dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
-                                                         [True, False, False])[0]
-        weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil) if ctx.needs_input_grad[1] else None
+                dx = _miopen_backward(dy, x, w, transposed, stride, pad, dil, [True, False, False])[0]
+                if dx.dtype != x.dtype:
+                    dx = dx.to(x.dtype)
+            if _check_hook is not None:
+                _check_hook("input_grad", eng, ctx.geom, (dy, x, w), dx)
+        weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16) if ctx.needs_input_grad[1] else None
         # data parallel: write the weight gradient straight into its slice of the armed gradient bucket (dist.py)
         sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2", "smallmap") else None
+        xw = x if (x.dtype == dy.dtype or weng in (None, "miopen")) else x.to(dy.dtype)      # a weight gradient reads both operands in one dtype
         if weng == "winograd":
-            dw = ops.conv3x3_winograd_wrw(transposed, x, dy, Cout, out=sink)
+            dw = ops.conv3x3_winograd_wrw(transposed, xw, dy, Cout, out=sink, math=math)
         elif weng == "wino_dil":
-            dw = ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, W), Cout, out=sink, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+            dw = ops.conv4x4_dilated_winograd(2, xw, dy, (B, Cin, H, W), Cout, out=sink, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math)
         elif weng == "smallmap":
             coarse, fine = (x, dy) if transposed else (dy, x)
             dw = ops.conv_smallmap(ops.SM_WRW, coarse, fine, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out=sink)
         elif weng == "wino_s2":
-            fine, coarse = (dy, x) if transposed else (x, dy)
-            dw = ops.conv4x4s2_winograd(ops.S2_WEIGHT_GRAD, fine, coarse, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out=sink)
+            fine, coarse = (dy, xw) if transposed else (xw, dy)
+            dw = ops.conv4x4s2_winograd(ops.S2_WEIGHT_GRAD, fine, coarse, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out=sink, math=math)
         elif ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1,
-                                                     [False, True, False])[1]
-        return dx, dw, None, None, None, None, None, None
+            dw = _miopen_backward(dy, x, w, transposed, stride, pad, dil, [False, True, False])[1]
+        if _check_hook is not None and dw is not None:
+            _check_hook("weight_grad", weng or "miopen", ctx.geom, (dy, x, w), dw)
+        return dx, dw, None, None, None, None, None, None, None, None
 
 
 def _geometry(m):
@@ -273,37 +321,45 @@ def _geometry(m):
 
 
 def conv_nobias(m, x, weight=None):
-    """m(x) without the bias (the fused epilogue kernels add it): HIP engine where `select` says so, else MIOpen."""
+    """m(x) without the bias (the fused epilogue kernels add it): HIP engine where `select` says so, else MIOpen.  fp32 activations:
+    every engine; bf16 activations (a bf16 tensor, or any input under bf16 autocast — BASELINE config 5): the Winograd engines, which
+    read / write bf16 and multiply split-bf16 operands on the bf16 matrix cores (`_MATH`); the weights stay fp32 parameters."""
     w = m.weight if weight is None else weight
     transposed = isinstance(m, nn.ConvTranspose2d)
     g = _geometry(m)
-    if g is not None and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 \
-            and not torch.is_autocast_enabled():
+    amp = _amp_bf16()
+    if g is not None and x.is_cuda and w.dtype == torch.float32 and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) \
+            and (amp or not torch.is_autocast_enabled()):
         k, stride, pad, dil = g
         B, Cin, H, W = x.shape
         Cout = w.shape[1] if transposed else w.shape[0]
         op = ops.CONVT_FWD if transposed else ops.CONV_FWD
-        eng = select(op, B, Cin, H, W, Cout, k, stride, pad, dil)
+        bf16 = amp or x.dtype == torch.bfloat16
+        act = torch.bfloat16 if bf16 else torch.float32
+        math = _MATH["bf16" if bf16 else "fp32"]
+        eng = select(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16)
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
         if needs_grad:
             # the backward may use a HIP engine even where the forward stays on MIOpen
             bop = ops.CONVT_BWD_DATA if transposed else ops.CONV_BWD_DATA
-            beng = select(bop, B, Cin, H, W, Cout, k, stride, pad, dil) if x.requires_grad else "miopen"
-            weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil) if w.requires_grad else "miopen"
+            beng = select(bop, B, Cin, H, W, Cout, k, stride, pad, dil, bf16) if x.requires_grad else "miopen"
+            weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16) if w.requires_grad else "miopen"
             if eng != "miopen" or beng != "miopen" or weng != "miopen":
-                return _HipConv.apply(x, w, transposed, k, stride, pad, dil, eng)
+                return _HipConv.apply(x, w, transposed, k, stride, pad, dil, eng, math, act)
         elif eng == "winograd":
-            return ops.conv3x3_winograd(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout)
+            return ops.conv3x3_winograd(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, math=math, out_dtype=act)
         elif eng == "direct":
             return ops.conv2d(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng == "wino_dil":
-            return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil))
+            return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil),
+                                                math=math, out_dtype=act)
         elif eng == "thin":
             return ops.conv3x3_thin(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout)
         elif eng == "smallmap":
             return ops.conv_smallmap(_smallmap_op(op), x.contiguous(), w.detach(), *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         elif eng == "wino_s2":
-            return ops.conv4x4s2_winograd(_s2_mode(op), x.contiguous(), w.detach(), B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
+            return ops.conv4x4s2_winograd(_s2_mode(op), x.contiguous(), w.detach(), B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil),
+                                          math=math, out_dtype=act)
     if transposed:
         return F.conv_transpose2d(x, w, None, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
     return F.conv2d(x, w, None, m.stride, m.padding, m.dilation, m.groups)

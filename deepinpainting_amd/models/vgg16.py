@@ -96,16 +96,19 @@ class Vgg16(torch.nn.Module):
             if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
                 pool = i + 2 < len(mods) and isinstance(mods[i + 2], nn.MaxPool2d) and x.size(2) % 2 == 0 and x.size(3) % 2 == 0
                 B, Cin, H, W = x.shape
-                if x.dtype == torch.float32 and not torch.is_autocast_enabled() and not m.weight.requires_grad and \
-                        hipconv.select(ops.CONV_FWD, B, Cin, H, W, m.out_channels, 3, 1, 1, 1) == "winograd":
-                    key = (m.weight.data_ptr(), m.weight._version, x.device)
+                bf16 = hipconv._amp_bf16() or x.dtype == torch.bfloat16
+                if (bf16 or not torch.is_autocast_enabled()) and not m.weight.requires_grad and \
+                        hipconv.select(ops.CONV_FWD, B, Cin, H, W, m.out_channels, 3, 1, 1, 1, bf16) == "winograd":
+                    math = hipconv._MATH["bf16" if bf16 else "fp32"]
+                    key = (m.weight.data_ptr(), m.weight._version, x.device, math)
                     cache = getattr(m, "_ipsr_wino_filter", None)
                     valid = cache is not None and cache[0] == key
                     if not valid:
                         cache = (key, ops.winograd_filter_cache(ops.CONV_FWD, Cin, m.out_channels, x.device))
                         m._ipsr_wino_filter = cache
                     x = ops.conv3x3_winograd(ops.CONV_FWD, x.contiguous(), m.weight, (B, Cin, H, W), m.out_channels, bias=m.bias,
-                                             epilogue="relu_pool" if pool else "relu", filter_cache=cache[1], filter_cache_valid=valid)
+                                             epilogue="relu_pool" if pool else "relu", filter_cache=cache[1], filter_cache_valid=valid,
+                                             math=math, out_dtype=torch.bfloat16 if bf16 else torch.float32)
                     i += 3 if pool else 2
                     continue
                 if x.dtype == torch.float32 and not torch.is_autocast_enabled() and not pool and \

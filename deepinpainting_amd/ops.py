@@ -331,6 +331,27 @@ def bias_relu_pool2(x, bias):
 
 CONV_FWD, CONV_BWD_DATA, CONVT_FWD, CONVT_BWD_DATA = 0, 1, 2, 3
 
+# arithmetic of the Winograd GEMMs (include/ipsr_hip.h, ipsr_conv3x3_winograd_mp): "fp32" = fp32 operands on the fp32 MFMA (the
+# reference's arithmetic, default); "bf16x3" / "bf16x6" = transformed operands split into 2 / 3 bf16 numbers, multiplied on the bf16
+# MFMA with fp32 accumulation (error ~1e-4 / ~1e-5 of the output scale; a plain bf16 convolution: ~2e-3)
+MATH_CODE = {None: 0, "fp32": 0, "bf16x3": 2, "bf16x6": 3}
+
+
+def _act(t, name):
+    """activation operand: contiguous fp32 or bf16 on the current device -> (tensor, is_bf16)"""
+    if not torch.is_tensor(t) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA/HIP tensor" % name)
+    _on_current_device(t, name)
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
+    return (t if t.is_contiguous() else t.contiguous()), t.dtype == torch.bfloat16
+
+
+def _io_code(in_bf16, out_dtype):
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("out_dtype must be float32 or bfloat16")
+    return int(bool(in_bf16)) | (2 if out_dtype == torch.bfloat16 else 0)
+
 
 def conv_out_dim(op, n, k, stride, pad, dil):
     if op in (CONV_FWD, CONV_BWD_DATA):
@@ -380,13 +401,17 @@ def winograd_filter_cache(op, Cin, Cout, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
-def conv3x3_winograd(op, inp, weight, in_shape, Cout, bias=None, epilogue=None, filter_cache=None, filter_cache_valid=False):
-    """k3 s1 p1 convolution / transposed convolution / their input gradients by Winograd F(4x4,3x3) (ipsr_conv3x3_winograd_ex).
+def conv3x3_winograd(op, inp, weight, in_shape, Cout, bias=None, epilogue=None, filter_cache=None, filter_cache_valid=False,
+                     math=None, out_dtype=None):
+    """k3 s1 p1 convolution / transposed convolution / their input gradients by Winograd F(4x4,3x3) (ipsr_conv3x3_winograd_mp).
     epilogue: None | "relu" (out = relu(conv + bias)) | "relu_pool" (... followed by the 2x2 max-pool; output [.,.,H/2,W/2]);
-    filter_cache: buffer from `winograd_filter_cache`; the transformed filter is written into it unless filter_cache_valid."""
+    filter_cache: buffer from `winograd_filter_cache`; the transformed filter is written into it unless filter_cache_valid (a
+    cache is only valid for the `math` it was filled under);
+    math: see MATH_CODE; inp may be fp32 or bf16, out_dtype (default: inp's dtype) likewise."""
     B, Cin, H, W = in_shape
-    inp = _req(inp, torch.float32, "conv input")
+    inp, in_bf = _act(inp, "conv input")
     weight = _req(weight, torch.float32, "conv weight")
+    out_dtype = out_dtype or inp.dtype
     fwd = op in (CONV_FWD, CONVT_FWD)
     want_in = (B, Cin, H, W) if fwd else (B, Cout, H, W)
     want_w = (Cout, Cin, 3, 3) if op in (CONV_FWD, CONV_BWD_DATA) else (Cin, Cout, 3, 3)
@@ -399,7 +424,7 @@ def conv3x3_winograd(op, inp, weight, in_shape, Cout, bias=None, epilogue=None, 
         raise RuntimeError("conv3x3_winograd: relu_pool needs even extents, got %dx%d" % (H, W))
     kout = Cout if fwd else Cin
     oshape = (B, kout, H // 2, W // 2) if epi == 2 else (B, kout, H, W)
-    out = torch.empty(oshape, dtype=torch.float32, device=inp.device)
+    out = torch.empty(oshape, dtype=out_dtype, device=inp.device)
     L = _lib.lib()
     nbytes = L.ipsr_conv3x3_winograd_workspace_bytes(op, B, Cin, H, W, Cout)
     if nbytes == 0:
@@ -407,9 +432,9 @@ def conv3x3_winograd(op, inp, weight, in_shape, Cout, bias=None, epilogue=None, 
     if filter_cache is not None and filter_cache.numel() != L.ipsr_conv3x3_winograd_filter_floats(op, Cin, Cout):
         raise RuntimeError("conv3x3_winograd: filter_cache has the wrong size")
     ws = _workspace(nbytes, inp.device)
-    _lib.check(L.ipsr_conv3x3_winograd_ex(op, inp.data_ptr(), weight.data_ptr(), _ptr(_f32(bias)), epi, _ptr(filter_cache),
-                                          int(bool(filter_cache_valid)), out.data_ptr(), B, Cin, H, W, Cout,
-                                          ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv3x3_winograd_ex")
+    _lib.check(L.ipsr_conv3x3_winograd_mp(op, inp.data_ptr(), weight.data_ptr(), _ptr(_f32(bias)), epi, _ptr(filter_cache),
+                                          int(bool(filter_cache_valid)), out.data_ptr(), B, Cin, H, W, Cout, MATH_CODE[math], _io_code(in_bf, out_dtype),
+                                          ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv3x3_winograd_mp")
     return out
 
 
@@ -430,29 +455,35 @@ def dilated_winograd_supported(mode, B, Cin, H, W, Cout, geom=GEOM_K4_S2_P3_D2):
     return _lib.lib().ipsr_conv4x4_winograd_workspace_bytes(geom, mode, B, Cin, H, W, Cout) > 0
 
 
-def conv4x4_dilated_winograd(mode, a, b, in_shape, Cout, out=None, geom=GEOM_K4_S2_P3_D2):
+def conv4x4_dilated_winograd(mode, a, b, in_shape, Cout, out=None, geom=GEOM_K4_S2_P3_D2, math=None, out_dtype=None):
     """Conv2d(k4, stride 2, pad 3, dilation 2) (geom 0) or Conv2d(k4, stride 1, pad 1) (geom 1) by Winograd F(3x3,4x4)
-    (ipsr_conv4x4_winograd): mode 0 forward (a = x, b = weight -> y), 1 backward-data (a = dy, b = weight -> dx), 2 weight
-    gradient (a = x, b = dy -> dw)."""
+    (ipsr_conv4x4_winograd_mp): mode 0 forward (a = x, b = weight -> y), 1 backward-data (a = dy, b = weight -> dx), 2 weight
+    gradient (a = x, b = dy -> dw, always fp32).  Activations fp32 or bf16; math: see MATH_CODE."""
     B, Cin, H, W = in_shape
-    a = _req(a, torch.float32, "operand a")
-    b = _req(b, torch.float32, "operand b")
+    a, a_bf = _act(a, "operand a")
+    if mode == 2:
+        b, b_bf = _act(b, "operand b")
+        if b_bf != a_bf:
+            raise TypeError("conv4x4_winograd: x and dy of a weight gradient must have the same dtype")
+    else:
+        b = _req(b, torch.float32, "weight")
+    res_dtype = torch.float32 if mode == 2 else (out_dtype or a.dtype)
     Ho, Wo = (H // 2, W // 2) if geom == GEOM_K4_S2_P3_D2 else (H - 1, W - 1)
     xs, ys, wsh = (B, Cin, H, W), (B, Cout, Ho, Wo), (Cout, Cin, 4, 4)
     want = {0: (xs, wsh, ys), 1: (ys, wsh, xs), 2: (xs, ys, wsh)}[mode]
     if tuple(a.shape) != want[0] or tuple(b.shape) != want[1]:
         raise RuntimeError("conv4x4_winograd mode %d: operands %s / %s do not match %s / %s" % (mode, tuple(a.shape), tuple(b.shape), want[0], want[1]))
-    if out is not None and (tuple(out.shape) != tuple(want[2]) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device):
-        raise RuntimeError("conv4x4_winograd: `out` must be a contiguous fp32 %s tensor on %s" % (tuple(want[2]), a.device))
+    if out is not None and (tuple(out.shape) != tuple(want[2]) or out.dtype != res_dtype or not out.is_contiguous() or out.device != a.device):
+        raise RuntimeError("conv4x4_winograd: `out` must be a contiguous %s %s tensor on %s" % (res_dtype, tuple(want[2]), a.device))
     if out is None:
-        out = torch.empty(want[2], dtype=torch.float32, device=a.device)
+        out = torch.empty(want[2], dtype=res_dtype, device=a.device)
     L = _lib.lib()
     nbytes = L.ipsr_conv4x4_winograd_workspace_bytes(geom, mode, B, Cin, H, W, Cout)
     if nbytes == 0:
         raise NotImplementedError("ipsr_conv4x4_winograd: geometry %d mode %d Cin=%d Cout=%d %dx%d is not implemented" % (geom, mode, Cin, Cout, H, W))
     ws = _workspace(nbytes, a.device)
-    _lib.check(L.ipsr_conv4x4_winograd(geom, mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout,
-                                       ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv4x4_winograd")
+    _lib.check(L.ipsr_conv4x4_winograd_mp(geom, mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout, MATH_CODE[math],
+                                          _io_code(a_bf, res_dtype), ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv4x4_winograd_mp")
     return out
 
 
@@ -463,27 +494,34 @@ def s2_winograd_supported(mode, B, Kc, Cf, nh, nw):
     return _lib.lib().ipsr_conv4x4s2_winograd_workspace_bytes(mode, B, Kc, Cf, nh, nw) > 0
 
 
-def conv4x4s2_winograd(mode, a, b, B, Kc, Cf, nh, nw, out=None):
-    """The k4 stride-2 pad-1 layers by Winograd F(5x5,2x2) on the polyphase components (ipsr_conv4x4s2_winograd).
+def conv4x4s2_winograd(mode, a, b, B, Kc, Cf, nh, nw, out=None, math=None, out_dtype=None):
+    """The k4 stride-2 pad-1 layers by Winograd F(5x5,2x2) on the polyphase components (ipsr_conv4x4s2_winograd_mp).
     fine = [B,Cf,2nh,2nw] (x of Conv2d, y of ConvTranspose2d), coarse = [B,Kc,nh,nw], weight = [Kc,Cf,4,4].
-    mode 0 fine -> coarse (a = fine, b = weight), 1 coarse -> fine (a = coarse, b = weight), 2 weight gradient (a = fine, b = coarse)."""
-    a = _req(a, torch.float32, "operand a")
-    b = _req(b, torch.float32, "operand b")
+    mode 0 fine -> coarse (a = fine, b = weight), 1 coarse -> fine (a = coarse, b = weight), 2 weight gradient (a = fine, b = coarse;
+    result fp32).  Activations fp32 or bf16; math: see MATH_CODE."""
+    a, a_bf = _act(a, "operand a")
+    if mode == 2:
+        b, b_bf = _act(b, "operand b")
+        if b_bf != a_bf:
+            raise TypeError("conv4x4s2_winograd: both operands of a weight gradient must have the same dtype")
+    else:
+        b = _req(b, torch.float32, "weight")
+    res_dtype = torch.float32 if mode == 2 else (out_dtype or a.dtype)
     fine, coarse, wsh = (B, Cf, 2 * nh, 2 * nw), (B, Kc, nh, nw), (Kc, Cf, 4, 4)
     want = {0: (fine, wsh, coarse), 1: (coarse, wsh, fine), 2: (fine, coarse, wsh)}[mode]
     if tuple(a.shape) != want[0] or tuple(b.shape) != want[1]:
         raise RuntimeError("conv4x4s2_winograd mode %d: operands %s / %s do not match %s / %s" % (mode, tuple(a.shape), tuple(b.shape), want[0], want[1]))
-    if out is not None and (tuple(out.shape) != tuple(want[2]) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device):
-        raise RuntimeError("conv4x4s2_winograd: `out` must be a contiguous fp32 %s tensor on %s" % (tuple(want[2]), a.device))
+    if out is not None and (tuple(out.shape) != tuple(want[2]) or out.dtype != res_dtype or not out.is_contiguous() or out.device != a.device):
+        raise RuntimeError("conv4x4s2_winograd: `out` must be a contiguous %s %s tensor on %s" % (res_dtype, tuple(want[2]), a.device))
     if out is None:
-        out = torch.empty(want[2], dtype=torch.float32, device=a.device)
+        out = torch.empty(want[2], dtype=res_dtype, device=a.device)
     L = _lib.lib()
     nbytes = L.ipsr_conv4x4s2_winograd_workspace_bytes(mode, B, Kc, Cf, nh, nw)
     if nbytes == 0:
         raise NotImplementedError("ipsr_conv4x4s2_winograd: mode %d Kc=%d Cf=%d %dx%d is not implemented" % (mode, Kc, Cf, nh, nw))
     ws = _workspace(nbytes, a.device)
-    _lib.check(L.ipsr_conv4x4s2_winograd(mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, Kc, Cf, nh, nw,
-                                         ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv4x4s2_winograd")
+    _lib.check(L.ipsr_conv4x4s2_winograd_mp(mode, a.data_ptr(), b.data_ptr(), out.data_ptr(), B, Kc, Cf, nh, nw, MATH_CODE[math],
+                                            _io_code(a_bf, res_dtype), ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv4x4s2_winograd_mp")
     return out
 
 
@@ -576,11 +614,14 @@ def conv_smallmap(op, a, b, B, R, Cq, Ho, Wo, Hf, Wf, k, stride, pad, dil, out=N
     return out
 
 
-def conv3x3_winograd_wrw(transposed, x, dy, Cout, out=None):
+def conv3x3_winograd_wrw(transposed, x, dy, Cout, out=None, math=None):
     """Weight gradient of a k3 s1 p1 Conv2d (transposed=False -> [Cout,Cin,3,3]) / ConvTranspose2d (True -> [Cin,Cout,3,3]).
-    out: optional contiguous fp32 tensor of that shape to write into (e.g. a slice of a gradient bucket)."""
-    x = _req(x, torch.float32, "conv input")
-    dy = _req(dy, torch.float32, "grad_output")
+    out: optional contiguous fp32 tensor of that shape to write into (e.g. a slice of a gradient bucket).  x / dy fp32 or bf16 (both
+    the same); the result is fp32; math: see MATH_CODE."""
+    x, x_bf = _act(x, "conv input")
+    dy, dy_bf = _act(dy, "grad_output")
+    if x_bf != dy_bf:
+        raise TypeError("conv3x3_winograd_wrw: x and dy must have the same dtype")
     B, Cin, H, W = x.shape
     if tuple(dy.shape) != (B, Cout, H, W):
         raise RuntimeError("conv3x3_winograd_wrw: grad_output %s does not match %s" % (tuple(dy.shape), (B, Cout, H, W)))
@@ -590,8 +631,8 @@ def conv3x3_winograd_wrw(transposed, x, dy, Cout, out=None):
     dw = out if out is not None else torch.empty(shape, dtype=torch.float32, device=x.device)
     L = _lib.lib()
     ws = _workspace(L.ipsr_conv3x3_winograd_wrw_workspace_bytes(int(transposed), B, Cin, H, W, Cout), x.device)
-    _lib.check(L.ipsr_conv3x3_winograd_wrw(int(transposed), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout,
-                                           ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv3x3_winograd_wrw")
+    _lib.check(L.ipsr_conv3x3_winograd_wrw_mp(int(transposed), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, MATH_CODE[math],
+                                              int(x_bf), ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv3x3_winograd_wrw_mp")
     return dw
 
 

@@ -333,6 +333,28 @@ int ipsr_profile_read_region(int region, float* ms /*[host]*/, int max_n);
  * 256 x capacity launches); `work` receives the flop count (2 x 36 x rows x columns x reduction, padded sizes) of each launch. */
 int ipsr_profile_read_region_work(int region, float* ms /*[host]*/, double* work /*[host]*/, int max_n);
 
+/* ---- mixed-precision forms of the Winograd convolutions (BASELINE config 5: "bf16 mixed precision (CDNA4 bf16 MFMA for patch-corr
+ * + convs)"; also an opt-in arithmetic for the fp32 nets) -------------------------------------------------------------------------
+ * Same operations, arguments and workspace queries as ipsr_conv3x3_winograd_ex / ipsr_conv3x3_winograd_wrw / ipsr_conv4x4_winograd /
+ * ipsr_conv4x4s2_winograd above (models/networks.py:220-259, 404-432, 470-495, 510-515; models/vgg16.py:9-21), plus:
+ *   math  0  fp32 operands on v_mfma_f32_32x32x2_f32 — the reference's arithmetic, what the entry points above run;
+ *         2  transformed operands SPLIT into two bf16 numbers (hi + lo, sum exact to 2^-16) and multiplied as hi*hi + hi*lo + lo*hi on
+ *            v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 MFMAs of 32 cycles per 16 channels instead of 8 of 64; error
+ *            ~1e-4 of the output scale (fp32 path: ~1e-5; a plain bf16 convolution: ~2e-3);
+ *         3  split into three bf16 numbers (exact to 2^-24), six products: the fp32 path's accuracy (measured equal) at ~0.6x its time.
+ *         Operands merely ROUNDED to bf16 are not offered: F(4x4,3x3) amplifies rounding ~100x (3-6 % error).
+ *   io    bit 0: the activation tensors READ (x / dy; both operands of a weight gradient) are bf16; bit 1: the activation tensor
+ *         WRITTEN is bf16.  Weights, biases, weight gradients, transforms and accumulation are always fp32. */
+int ipsr_conv3x3_winograd_mp(int op, const void* in, const float* weight, const float* bias, int epilogue, float* filter_cache,
+                             int filter_cache_valid, void* out, int B, int Cin, int H, int W, int Cout, int math, int io,
+                             void* ws, size_t ws_bytes, void* stream);
+int ipsr_conv3x3_winograd_wrw_mp(int transposed, const void* x, const void* dy, float* dw, int B, int Cin, int H, int W, int Cout,
+                                 int math, int io, void* ws, size_t ws_bytes, void* stream);
+int ipsr_conv4x4_winograd_mp(int geom, int mode, const void* a, const void* b, void* out, int B, int Cin, int H, int W, int Cout,
+                             int math, int io, void* ws, size_t ws_bytes, void* stream);
+int ipsr_conv4x4s2_winograd_mp(int mode, const void* a, const void* b, void* out, int B, int Kc, int Cf, int nh, int nw,
+                               int math, int io, void* ws, size_t ws_bytes, void* stream);
+
 /* How the reduction of the 36 Winograd GEMMs of a layer is cut over workgroups (csrc/winograd.hip, wino_choose_split): for a GEMM
  * of `rows` x `cols` (multiples of 128: produced channels x tiles, padded) with `reduction` (multiple of 16) terms,
  * out5 = {nsplit, stages per range, xi_split, nsplit_tail, stages per tail range}: the GEMMs of points xi < xi_split run in
@@ -342,6 +364,9 @@ int ipsr_profile_read_region_work(int region, float* ms /*[host]*/, double* work
  * hook above the only global state of the library, and like it off by default. */
 int ipsr_wino_gemm_split(int rows, int cols, int reduction, int* out5 /*[host]*/);
 int ipsr_debug_force_wino_split(int nsplit, int xi_split, int nsplit_tail);
+/* A/B switches for kernel variants (tools/exp_*.py): key in [0,16), value 0 = the shipped behaviour.  Same status as the
+ * override above: process-global, off by default, never set by the product path. */
+int ipsr_debug_set_option(int key, int value);
 
 #ifdef __cplusplus
 }

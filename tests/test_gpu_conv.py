@@ -298,6 +298,89 @@ def test_thin_3x3_layers_vs_fp64(kind, Ci, Co, H, W, B):
         assert tuple(dw.shape) == tuple(w.shape) and _rel(dw, dw64) <= 2e-5
 
 
+# ---- the training step's OWN shapes (BASELINE config 2: batch 8, 256x256) ------------------------------------------------------
+# (module, input H=W): the layers the step spends its time in, every Winograd family, all three passes.  References: the same
+# module in fp64 on the GPU (torch's native convolution) AND MIOpen fp32 on the same tensors.
+STEP_LAYERS = [
+    ("k3_512_32",      lambda: nn.Conv2d(512, 512, 3, 1, 1), 32),                      # VGG conv4_x, netG downconv_3: tiles 16 -> head/tail cut
+    ("k3T_1024_256_32", lambda: nn.ConvTranspose2d(1024, 256, 3, 1, 1), 32),           # netG upconv_3: tiles 8 -> head/tail cut
+    ("k3_256_64",      lambda: nn.Conv2d(256, 256, 3, 1, 1), 64),                      # VGG conv3_x
+    ("k3_128_128",     lambda: nn.Conv2d(128, 128, 3, 1, 1), 128),                     # VGG conv2_2
+    ("k4s2_256_512_32", lambda: nn.Conv2d(256, 512, 4, 2, 1), 32),                     # netP / netF down
+    ("k4s2T_512_128_32", lambda: nn.ConvTranspose2d(512, 128, 4, 2, 1), 32),           # netP / netG up
+    ("k4s2_64_128_128", lambda: nn.Conv2d(64, 128, 4, 2, 1), 128),                     # netD
+    ("k4d2_512_32",    lambda: nn.Conv2d(512, 512, 4, 2, 3, dilation=2), 32),          # netG dilated down
+    ("k4d2_128_128",   lambda: nn.Conv2d(128, 128, 4, 2, 3, dilation=2), 128),
+    ("k4s1_256_512_32", lambda: nn.Conv2d(256, 512, 4, 1, 1), 32),                     # netD stride-1
+    ("k3_64_256",      lambda: nn.Conv2d(64, 64, 3, 1, 1), 256),                       # VGG conv1_2
+    ("k3_64_128_128",  lambda: nn.Conv2d(64, 128, 3, 1, 1), 128),                      # VGG conv2_1
+    ("k4s2T_128_64_128", lambda: nn.ConvTranspose2d(128, 64, 4, 2, 1), 64),            # netP / netG outer up convolution
+]
+
+
+@pytest.mark.parametrize("name,make,H", STEP_LAYERS, ids=[t[0] for t in STEP_LAYERS])
+def test_step_shapes_batch8_all_three_passes(name, make, H):
+    """Forward, input gradient and weight gradient of the step's dominant layers at ITS batch (8) through the dispatcher's own
+    choice ("auto"), within 1e-4 of the result's scale of an fp64 evaluation and of MIOpen fp32 on the same tensors."""
+    from deepinpainting_amd.models import hipconv
+    torch.manual_seed(len(name) * 7 + H)
+    m = make().cuda()
+    with torch.no_grad():
+        m.weight.mul_(0.5)
+    B = 8
+    x = torch.randn(B, m.in_channels, H, H, device="cuda", requires_grad=True)
+    hipconv._FORCE = "auto"
+    try:
+        y = hipconv.conv_nobias(m, x)
+        dy = torch.randn_like(y)
+        dx, dw = torch.autograd.grad(y, (x, m.weight), dy)
+    finally:
+        hipconv._FORCE = None
+    tr = isinstance(m, nn.ConvTranspose2d)
+    f = (lambda a, w: F.conv_transpose2d(a, w, None, m.stride, m.padding, 0, 1, m.dilation)) if tr else (lambda a, w: F.conv2d(a, w, None, m.stride, m.padding, m.dilation))
+    xr, wr = x.detach().clone().requires_grad_(True), m.weight.detach().clone().requires_grad_(True)
+    ym = f(xr, wr)                                                    # MIOpen fp32
+    dxm, dwm = torch.autograd.grad(ym, (xr, wr), dy)
+    xd, wd = x.detach().double().requires_grad_(True), m.weight.detach().double().requires_grad_(True)
+    yd = f(xd, wd)                                                    # fp64
+    dxd, dwd = torch.autograd.grad(yd, (xd, wd), dy.double())
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    errs = dict(y=rel(y, yd), dx=rel(dx, dxd), dw=rel(dw, dwd), y_mi=rel(y, ym), dx_mi=rel(dx, dxm), dw_mi=rel(dw, dwm),
+                miopen_y=rel(ym, yd), miopen_dx=rel(dxm, dxd), miopen_dw=rel(dwm, dwd))
+    print(name, {k: "%.1e" % v for k, v in errs.items()})
+    for k in ("y", "dx", "dw"):
+        assert errs[k] <= 1e-4, (name, k, errs)
+        assert errs[k + "_mi"] <= 2e-4, (name, k, errs)              # two fp32 results, each within 1e-4 of the truth
+
+
+def test_step_shapes_take_both_reduction_cuts():
+    """The head/tail cut (GEMMs of the first 32 Winograd points uncut, the last 4 cut 2-4 ways) is what the 512-channel 32x32
+    layers of the step run on, the uniform cut what the weight gradients run on: the shapes of the test above reach both
+    (the round-2 tests reached neither at the step's batch)."""
+    import ctypes
+    from deepinpainting_amd import _lib
+    L = _lib.lib()
+
+    def split(rows, cols, red):
+        out = (ctypes.c_int * 5)()
+        _lib.check(L.ipsr_wino_gemm_split(rows, cols, red, ctypes.cast(out, ctypes.c_void_p)), "ipsr_wino_gemm_split")
+        return list(out)
+    # 512 -> 512 @32x32, batch 8: K = 512 rows, T = 8 * 8 * 8 = 512 tiles, reduction 512 channels
+    ns, sps, xs, nt, spt = split(512, 512, 512)
+    assert xs == 32 and ns == 1 and nt >= 2, "512@32x32 forward is expected on the head/tail cut, got %s" % ([ns, sps, xs, nt, spt],)
+    # ConvTranspose2d 1024 -> 256 @32x32: 256 rows, 512 tiles, reduction 1024
+    ns, sps, xs, nt, spt = split(256, 512, 1024)
+    assert xs == 32 and nt >= 2
+    # 256 @64x64 forward: 2 x 16 = 32 tiles of 128x128 per point -> uniform rule
+    ns2, _, xs2, nt2, _ = split(256, 2048, 256)
+    assert xs2 == 36 and ns2 == nt2
+    # a long reduction over few output tiles (weight gradient of 128 -> 128 @128x128: 8192 tiles) must be cut uniformly
+    ns3, _, xs3, nt3, _ = split(128, 128, 8192)
+    assert xs3 == 36 and ns3 == nt3 and ns3 > 1
+
+
 @pytest.mark.parametrize("engine", ["direct", "winograd", "auto"])
 def test_module_path_forward_and_gradients(engine):
     """models/hipconv.py: Conv2d / ConvTranspose2d modules through the dispatcher with one engine forced — output, input
@@ -331,6 +414,137 @@ def test_module_path_forward_and_gradients(engine):
                 assert torch.equal(y2, y.detach()), (engine, m)
     finally:
         hipconv._FORCE = None
+
+
+# ---- the split-bf16 arithmetic (BASELINE config 5's "bf16 MFMA for ... convs") --------------------------------------------------
+def _f64(f, x, w, dy):
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = f(xd, wd)
+    dx, dw = torch.autograd.grad(y, (xd, wd), dy.double())
+    return y.detach(), dx, dw
+
+
+def _relerr(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.parametrize("math,io_bf16", [("bf16x6", False), ("bf16x3", False), ("bf16x3", True), ("fp32", True)])
+def test_split_bf16_winograd_arithmetic_all_families(math, io_bf16):
+    """Every Winograd family (3x3 stride 1: Conv2d / ConvTranspose2d; 4x4 dilated and stride 1; 4x4 stride 2 polyphase) in all three
+    passes with the transformed operands split into bf16 planes and multiplied on the bf16 matrix cores — and with bf16
+    activation tensors in / out (config 5) — against fp64 on the GPU (of the bf16-rounded operands where io is bf16):
+        bf16x6 : the fp32 path's bound, 1e-4 of the result's scale        bf16x3 : 1e-3 (measured ~1.5e-4)
+        bf16 outputs: + the rounding of the result itself, 2^-8."""
+    from deepinpainting_amd import ops
+    tol = {"fp32": 1e-4, "bf16x6": 1e-4, "bf16x3": 1e-3}[math]
+    otol = tol + (2.0 ** -8 if io_bf16 else 0.0)
+    act = torch.bfloat16 if io_bf16 else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(17)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, device="cuda", generator=g) * scale).to(act)
+    # --- 3x3 stride 1
+    for tr, Cin, H, W, Cout, B in ((False, 64, 16, 16, 96, 2), (False, 128, 32, 32, 160, 3), (True, 64, 12, 20, 48, 2), (False, 48, 9, 13, 80, 2)):
+        x, dy = rnd(B, Cin, H, W), rnd(B, Cout, H, W)
+        w = torch.randn((Cin, Cout, 3, 3) if tr else (Cout, Cin, 3, 3), device="cuda", generator=g) * 0.1
+        f = (lambda a, ww: F.conv_transpose2d(a, ww, None, 1, 1)) if tr else (lambda a, ww: F.conv2d(a, ww, None, 1, 1))
+        y64, dx64, dw64 = _f64(f, x, w, dy)
+        fop, bop = (ops.CONVT_FWD, ops.CONVT_BWD_DATA) if tr else (ops.CONV_FWD, ops.CONV_BWD_DATA)
+        y = ops.conv3x3_winograd(fop, x, w, (B, Cin, H, W), Cout, math=math)
+        dx = ops.conv3x3_winograd(bop, dy, w, (B, Cin, H, W), Cout, math=math)
+        dw = ops.conv3x3_winograd_wrw(tr, x, dy, Cout, math=math)
+        assert y.dtype == act and dx.dtype == act and dw.dtype == torch.float32
+        assert _relerr(y, y64) <= otol and _relerr(dx, dx64) <= otol and _relerr(dw, dw64) <= tol, ("k3", tr, Cin, H, W, Cout, _relerr(y, y64), _relerr(dx, dx64), _relerr(dw, dw64))
+    # --- 4x4 dilated stride 2 (geom 0) and 4x4 stride 1 pad 1 (geom 1)
+    for geom, Cin, H, W, Cout, B in ((0, 128, 32, 32, 128, 2), (0, 32, 16, 16, 48, 2), (1, 64, 16, 16, 128, 2), (1, 32, 7, 10, 32, 3)):
+        st_, pad, dil = (2, 3, 2) if geom == 0 else (1, 1, 1)
+        Ho, Wo = (H // 2, W // 2) if geom == 0 else (H - 1, W - 1)
+        x, dy = rnd(B, Cin, H, W), rnd(B, Cout, Ho, Wo)
+        w = torch.randn(Cout, Cin, 4, 4, device="cuda", generator=g) * 0.1
+        y64, dx64, dw64 = _f64(lambda a, ww: F.conv2d(a, ww, None, st_, pad, dil), x, w, dy)
+        y = ops.conv4x4_dilated_winograd(0, x, w, (B, Cin, H, W), Cout, geom=geom, math=math)
+        dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=geom, math=math)
+        dw = ops.conv4x4_dilated_winograd(2, x, dy, (B, Cin, H, W), Cout, geom=geom, math=math)
+        assert _relerr(y, y64) <= otol and _relerr(dx, dx64) <= otol and _relerr(dw, dw64) <= tol, ("k4", geom, Cin, H, W, Cout, _relerr(y, y64), _relerr(dx, dx64), _relerr(dw, dw64))
+    # --- 4x4 stride 2 pad 1, read as a Conv2d (fine = x) — the ConvTranspose2d reading is the same three calls
+    for Kc, Cf, nh, nw, B in ((128, 64, 16, 16, 2), (64, 32, 8, 8, 3), (256, 128, 32, 32, 1), (48, 24, 11, 6, 1)):
+        fine, coarse = rnd(B, Cf, 2 * nh, 2 * nw), rnd(B, Kc, nh, nw)
+        w = torch.randn(Kc, Cf, 4, 4, device="cuda", generator=g) * 0.1
+        y64, dx64, dw64 = _f64(lambda a, ww: F.conv2d(a, ww, None, 2, 1), fine, w, coarse)
+        y = ops.conv4x4s2_winograd(ops.S2_FINE_TO_COARSE, fine, w, B, Kc, Cf, nh, nw, math=math)
+        dx = ops.conv4x4s2_winograd(ops.S2_COARSE_TO_FINE, coarse, w, B, Kc, Cf, nh, nw, math=math)
+        dw = ops.conv4x4s2_winograd(ops.S2_WEIGHT_GRAD, fine, coarse, B, Kc, Cf, nh, nw, math=math)
+        assert _relerr(y, y64) <= otol and _relerr(dx, dx64) <= otol and _relerr(dw, dw64) <= tol, ("s2", Kc, Cf, nh, nw, _relerr(y, y64), _relerr(dx, dx64), _relerr(dw, dw64))
+
+
+def test_every_engine_call_of_a_training_step_checked_in_situ(tmp_path):
+    """One full optimize_parameters() at BASELINE config 2's batch (8 x 256x256, dropout on, as bench.py runs it): EVERY
+    convolution call that goes through a HIP engine — forward, input gradient and weight gradient, on the tensors the step really
+    produces — is recomputed by MIOpen on the same operands and compared: within 1e-4 of the result's scale.  (A whole-net
+    gradient comparison cannot discriminate: netG's backward amplifies fp32 forward noise to 0.7 % between two MIOpen-only runs,
+    tests/test_gpu_model.py::test_all_four_nets_gradients_...; per call there is nothing to amplify.)  Also proves which engines
+    the step runs on."""
+    import contextlib
+    import io
+    import torch.nn.functional as F_
+    from deepinpainting_amd.models import hipconv
+    from deepinpainting_amd.options import Option
+    from deepinpainting_amd.models.models import create_model
+    opt = Option(gpu_ids=[0], batchSize=8, use_dropout=True, quiet=True, allow_random_vgg=True, checkpoints_dir=str(tmp_path))
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = create_model(opt)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    img = torch.rand(8, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    ref = torch.rand(8, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    mask = torch.zeros(1, 1, 256, 256, dtype=torch.bool, device="cuda")
+    mask[:, :, 64:192, 64:192] = 1
+    seen = {}
+
+    def hook(kind, engine, geom, operands, result):
+        if engine == "miopen":
+            return
+        transposed, k, stride, pad, dil, Cout = geom
+        with torch.no_grad():
+            if kind == "forward":
+                x, w = operands
+                want = F_.conv_transpose2d(x, w, None, stride, pad, 0, 1, dil) if transposed else F_.conv2d(x, w, None, stride, pad, dil)
+            else:
+                dy, x, w = operands
+                which = [kind == "input_grad", kind == "weight_grad", False]
+                out = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], transposed, [0, 0], 1, which)
+                want = out[0] if kind == "input_grad" else out[1]
+            scale = float(want.abs().max())
+            err = float((result.float() - want).abs().max()) / max(scale, 1e-30)
+        key = (kind, engine, tuple(operands[-2].shape) if kind != "forward" else tuple(operands[0].shape), tuple(w.shape), stride, pad, dil)
+        seen[key] = max(seen.get(key, 0.0), err)
+
+    for step in range(2):               # the second step runs on weights Adam has moved (real, non-initial statistics)
+        hipconv._check_hook = hook if step == 1 else None
+        try:
+            m.set_input(img, mask, ref)
+            m.set_ref_latent()
+            m.set_gt_latent()
+            m.optimize_parameters()
+        finally:
+            hipconv._check_hook = None
+    torch.cuda.synchronize()
+    engines = {}
+    for (kind, engine, xs, ws_, st, pd, dl), err in sorted(seen.items(), key=lambda kv: -kv[1]):
+        engines.setdefault((kind, engine), []).append(err)
+    worst = sorted(seen.items(), key=lambda kv: -kv[1])[:12]
+    print("engine calls checked: %d distinct (kind, engine, shape)" % len(seen))
+    for (kind, engine), errs in sorted(engines.items()):
+        print("  %-12s %-9s %3d shapes, worst %.1e" % (kind, engine, len(errs), max(errs)))
+    for key, err in worst:
+        print("  worst: %.2e %s" % (err, key))
+    assert len(seen) >= 60
+    for need in (("forward", "winograd"), ("input_grad", "winograd"), ("weight_grad", "winograd"), ("forward", "wino_s2"), ("input_grad", "wino_s2"),
+                 ("weight_grad", "wino_s2"), ("forward", "wino_dil"), ("input_grad", "wino_dil"), ("weight_grad", "wino_dil"),
+                 ("weight_grad", "smallmap"), ("forward", "smallmap"), ("input_grad", "smallmap"), ("input_grad", "direct")):
+        assert need in engines, "the step did not run %s on the %s engine" % need
+    bad = [(k, e) for k, e in seen.items() if not e <= 1e-4]
+    assert not bad, bad
 
 
 def test_dispatcher_rules_and_refusals():
@@ -382,7 +596,9 @@ def test_dispatcher_rules_and_refusals():
 
 
 def test_vgg_and_unet_outputs_unchanged_by_the_engines():
-    """The whole VGG16 feature pass and a netG forward/backward with the HIP engines against the same nets on MIOpen only:
+    """The whole VGG16 feature pass and a netP (unet_256) forward/backward with the HIP engines — the direct implicit GEMM forced
+    everywhere, then the dispatcher's own choices — against the same nets on MIOpen only (netG with the IPSR layer and netD / netF:
+    tests/test_gpu_model.py::test_all_four_nets_gradients_auto_engines_vs_miopen_with_one_truncation):
     features within 1e-4 of their scale, parameter gradients within 1e-3 of their own scale plus 1e-4 of the largest
     gradient's (fp32 summation-order noise through 16 levels of convolution + InstanceNorm backward, which cancels the large
     components: the small gradients of the outer levels sit on that noise floor)."""
@@ -410,7 +626,7 @@ def test_vgg_and_unet_outputs_unchanged_by_the_engines():
         netP = networks.define_G(3, 3, 64, 'unet_256', opt, mask, 'instance', False, 'normal', [0], 0.02)[0]
     img = torch.rand(2, 3, 256, 256, device="cuda") * 2 - 1
     grads = {}
-    for eng in ("miopen", "direct"):
+    for eng in ("miopen", "direct", "auto"):
         hipconv._FORCE = eng
         try:
             netP.zero_grad()
@@ -421,5 +637,6 @@ def test_vgg_and_unet_outputs_unchanged_by_the_engines():
     # (a conv bias in front of an InstanceNorm has an exactly-zero true gradient: what is left there is rounding noise of the
     # size of the largest gradients' last bits, hence the global term)
     gmax = max(float(b.abs().max()) for b in grads["miopen"])
-    for a, b in zip(grads["direct"], grads["miopen"]):
-        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-4 * gmax
+    for eng in ("direct", "auto"):          # the one-launch implicit GEMM everywhere; the dispatcher's own per-shape choices
+        for a, b in zip(grads[eng], grads["miopen"]):
+            assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-4 * gmax, eng
