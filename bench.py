@@ -199,7 +199,7 @@ def _per_sample_case(device, iters=10):
             "shape": "[%d,%d,%d,%d], M per sample %d..%d (incl. the autograd wrapper)" % (BATCH, C_FEAT, H_FEAT, H_FEAT, min(Ms), max(Ms))}
 
 
-def cpu_baseline(sample_batch=2, steps=3):
+def cpu_baseline(sample_batch=BATCH, steps=1):
     """The CPU twin on this host's cores: same trainer class, PyTorch-CPU convs, oracle-backed IPSR layer."""
     from deepinpainting_amd.options import Option
     from oracle import cpu_model, ipsr_oracle as orc
@@ -220,16 +220,20 @@ def cpu_baseline(sample_batch=2, steps=3):
     x = np.abs(rs.standard_normal((BATCH, C_FEAT, H_FEAT, H_FEAT))).astype(np.float32)
     rf = np.maximum(rs.standard_normal((BATCH, C_FEAT, H_FEAT, H_FEAT)), 0).astype(np.float32)
     mpi = model.CSA_model[0].mask_point_idx
-    t1 = time.perf_counter()
-    f = orc.forward(x, rf, mpi)
-    orc.backward(x, mpi, f.attn_rows, f.bwd_index, 1.0)
-    layer_ms = (time.perf_counter() - t1) * 1e3
+    layer = []
+    for i in range(4):                          # one warm-up call (OpenMP thread start-up, page faults), then the median of three
+        t1 = time.perf_counter()
+        f = orc.forward(x, rf, mpi)
+        orc.backward(x, mpi, f.attn_rows, f.bwd_index, 1.0)
+        if i:
+            layer.append((time.perf_counter() - t1) * 1e3)
+    layer_ms = statistics.median(layer)
     return {
         "value": round(sample_batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-        "sample": "%d full training step(s) at batch %d (same 256x256 workload, oracle-backed IPSR layer + "
+        "sample": "%d full training step(s) at batch %d — the GPU figure's own batch — (same 256x256 workload, oracle-backed IPSR layer + "
                   "PyTorch-CPU convs, torch %s, %d threads): %.1f s" % (steps, sample_batch, torch.__version__, cores, dt),
         "ipsr_layer_ms": round(layer_ms, 2),
-        "ipsr_layer_shape": "[%d,%d,%d,%d], M=%d, forward+backward, oracle C restatement (OpenMP over samples / column blocks)" % (BATCH, C_FEAT, H_FEAT, H_FEAT, len(mpi)),
+        "ipsr_layer_shape": "[%d,%d,%d,%d], M=%d, forward+backward, oracle C restatement (OpenMP over samples / column blocks), warm median of 3" % (BATCH, C_FEAT, H_FEAT, H_FEAT, len(mpi)),
     }
 
 
@@ -333,9 +337,11 @@ def main():
         train_step(model, img, mask, ref)
     torch.cuda.synchronize()
     ncap = 256 * gsteps
-    gms, gwork = (ctypes.c_float * ncap)(), (ctypes.c_double * ncap)()
-    ng = lib.ipsr_profile_read_region_work(3, ctypes.cast(gms, ctypes.c_void_p), ctypes.cast(gwork, ctypes.c_void_p), ncap)
+    gms, gwork, guse = (ctypes.c_float * ncap)(), (ctypes.c_double * ncap)(), (ctypes.c_double * ncap)()
+    ng = lib.ipsr_profile_read_region_work2(3, ctypes.cast(gms, ctypes.c_void_p), ctypes.cast(gwork, ctypes.c_void_p),
+                                            ctypes.cast(guse, ctypes.c_void_p), ncap)
     gemm_ms, gemm_flops = sum(gms[i] for i in range(ng)), sum(gwork[i] for i in range(ng))
+    gemm_useful = sum(guse[i] for i in range(ng))
     if os.environ.get("IPSR_BENCH_GEMM_DUMP"):          # one line per launch: ms, flops, TFLOP/s (for tuning the tile/split choice)
         with open(os.environ["IPSR_BENCH_GEMM_DUMP"], "w") as fh:
             for i in range(ng):
@@ -368,6 +374,30 @@ def main():
                   "ms_per_step": round(strict_elapsed / ksteps * 1e3, 3), "flops_per_image": REF_FLOPS_PER_IMAGE,
                   "note": "opt.strict_reference=True: the reference's sequence incl. the duplicate VGG pass, VGG slice 4 of "
                           "the generated image and the discriminator gradients of backward_G (dead work, bit-identical live values)"}
+
+    # the same step with the Winograd GEMMs on split-bf16 operands (bf16 MFMA, fp32 accumulate) — separately labelled, NEVER the
+    # headline: bf16x3 = hi + lo planes (error ~1e-4 of a convolution's output scale), bf16x6 = three planes (the fp32 path's accuracy)
+    alt = None
+    if args.dtype == "f32" and args.conv_math == "fp32" and world == 1 and os.environ.get("IPSR_BENCH_NO_ALT", "0") != "1" \
+            and os.environ.get("IPSR_BENCH_STEP_ONLY", "0") != "1":
+        from deepinpainting_amd.models import hipconv
+        alt = {}
+        for math in ("bf16x3", "bf16x6"):
+            hipconv.set_conv_math(fp32=math)
+            for _ in range(2):
+                train_step(model, img, mask, ref)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            ksteps = max(3, min(10, args.steps))
+            for _ in range(ksteps):
+                train_step(model, img, mask, ref)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - ts
+            alt[math] = {"value": round(args.batch * ksteps / dt, 3), "unit": "images/sec", "ms_per_step": round(dt / ksteps * 1e3, 3), "steps": ksteps}
+        hipconv.set_conv_math(fp32="fp32")
+        alt["note"] = ("opt.conv_math: transformed Winograd operands split into 2 / 3 bf16 numbers, multiplied on v_mfma_f32_32x32x16_bf16 with fp32 "
+                       "accumulation; measured convolution error vs fp64: fp32 path 1.4e-5, bf16x6 1.4e-5, bf16x3 1.4e-4 of the output scale "
+                       "(tests/test_gpu_conv.py::test_split_bf16_winograd_arithmetic_all_families).  Not the headline arithmetic.")
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -435,18 +465,27 @@ def main():
         # the convolutions' own matrix-core kernel: every launch of ipsr::wino_gemm_kernel (the 36 GEMMs of the Winograd
         # F(4x4,3x3) / F(3x3,4x4) convolutions: VGG16, netG's 3x3 and dilated 4x4 layers, forward / input / weight gradients)
         # inside the timed steps; flops = the multiplies the kernel executes (4x fewer than the direct convolutions it replaces)
-        "conv_roofline": {"kernel": "ipsr::wino_gemm_kernel (fp32 MFMA, 36 GEMMs per convolution)", "bound": "mfma",
-                          "achieved": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2) if ng else None, "peak": PEAK_FP32_MFMA_TFLOPS,
-                          "unit": "TFLOP/s", "frac": round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ng else None,
+        # `achieved` / `frac`: USEFUL flops (unpadded channels / tiles) over the kernel's time; `executed_*`: the flops the kernel
+        # really issues (rows / columns rounded up to the 128 x 128 tile — the difference is arithmetic on zero padding)
+        "conv_roofline": {"kernel": "ipsr::wino_gemm_kernel (fp32 MFMA, 36 GEMMs per convolution)" if (args.dtype == "f32" and args.conv_math == "fp32")
+                          else "ipsr::wino_gemm_split_kernel (bf16 MFMA on split operands; fp32-MFMA peak kept as the yardstick)", "bound": "mfma",
+                          "achieved": round(gemm_useful / (gemm_ms * 1e-3) / 1e12, 2) if ng else None, "peak": PEAK_FP32_MFMA_TFLOPS,
+                          "unit": "TFLOP/s", "frac": round(gemm_useful / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ng else None,
+                          "executed_tflops": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2) if ng else None,
+                          "executed_frac": round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ng else None,
+                          "padding_share_of_executed_flops": round(1.0 - gemm_useful / gemm_flops, 4) if ng and gemm_flops else None,
                           "launches_timed": ng, "launches_per_step": round(ng / gsteps, 1),
                           "kernel_ms_per_step": round(gemm_ms / gsteps, 3),
-                          "direct_equivalent_tflops": round(4.0 * gemm_flops / (gemm_ms * 1e-3) / 1e12, 1) if ng else None},
+                          "flop_saving_vs_direct": "F(4x4,3x3) and F(3x3,4x4): 4.0x; polyphase F(5x5,2x2): 2.78x (per family, not applied here)"},
         "step_roofline": {"bound": "mfma", "flops_per_image": STEP_FLOPS_PER_IMAGE,
-                          "achieved": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                          "unit": "TFLOP/s per GPU", "frac": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                          "note": "direct-convolution flop count of the step as executed; this repo's Winograd F(4x4,3x3)/F(3x3,4x4) kernels and "
-                                  "MIOpen's F(2x2,3x3)/F(3x3,2x2) execute fewer real multiplies than this count"}
+                          "achieved_direct_equivalent": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                          "unit": "TFLOP/s per GPU",
+                          "direct_equivalent_frac": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                          "note": "NOT a hardware fraction: the DIRECT-convolution flop count of the step as executed, over time.  The Winograd "
+                                  "kernels (this repo's F(4x4,3x3) / F(3x3,4x4) / F(5x5,2x2), MIOpen's F(2x2,3x3)) execute 2.25-4x fewer "
+                                  "multiplies than this count, so the figure could exceed 1"}
         if args.dtype == "f32" else None,
+        "alt_arithmetic": alt,
         "strict_reference": strict,
         "losses_last_step": {k: round(v, 4) for k, v in errs.items()},
     }

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ipsr_profile_read": (c_int, [c_void_p, c_int]),
     "ipsr_profile_read_region": (c_int, [c_int, c_void_p, c_int]),
     "ipsr_profile_read_region_work": (c_int, [c_int, c_void_p, c_void_p, c_int]),
+    "ipsr_profile_read_region_work2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "ipsr_conv3x3_winograd_mp": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_void_p, c_size_t, c_void_p]),
     "ipsr_conv3x3_winograd_wrw_mp": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

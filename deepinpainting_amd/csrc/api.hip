@@ -40,7 +40,8 @@ int check_launch(const char* what)
 constexpr int N_REGIONS = 4;
 struct EvRing {
     hipEvent_t* ev = nullptr;      // 2*capacity events: start0, stop0, start1, ...
-    double* work = nullptr;        // per entry: work units the caller attached (flops), 0 if none
+    double* work = nullptr;        // per entry: work units the caller attached (flops as EXECUTED, padded sizes), 0 if none
+    double* work2 = nullptr;       // per entry: the USEFUL part of that work (unpadded sizes)
     int cap = 0, n = 0;
     bool open = false;
 };
@@ -54,12 +55,13 @@ void profile_mark_start(hipStream_t st, int region)
     r.open = true;
 }
 
-void profile_mark_stop(hipStream_t st, int region, double work)
+void profile_mark_stop(hipStream_t st, int region, double work, double work2)
 {
     EvRing& r = g_ring[region];
     if (!r.open) return;
     (void)hipEventRecord(r.ev[2 * r.n + 1], st);
     r.work[r.n] = work;
+    r.work2[r.n] = work2;
     r.open = false;
     ++r.n;
 }
@@ -147,6 +149,7 @@ int ipsr_profile_enable_mask(int capacity, unsigned region_mask)
         for (int i = 0; i < 2 * r.cap; ++i) (void)hipEventDestroy(r.ev[i]);
         delete[] r.ev;
         delete[] r.work;
+        delete[] r.work2;
         r = EvRing();
     }
     if (capacity <= 0) return IPSR_OK;
@@ -155,6 +158,7 @@ int ipsr_profile_enable_mask(int capacity, unsigned region_mask)
         EvRing& r = g_ring[ri];
         const int cap_r = ri == 3 ? 256 * capacity : capacity;        // tens of GEMM launches per training step
         r.work = new double[(size_t)cap_r];
+        r.work2 = new double[(size_t)cap_r];
         r.ev = new hipEvent_t[2 * (size_t)cap_r];
         for (int i = 0; i < 2 * cap_r; ++i)
             if (hipEventCreate(&r.ev[i]) != hipSuccess) return fail(IPSR_ERR_LAUNCH, "ipsr_profile_enable: hipEventCreate failed");
@@ -182,14 +186,19 @@ int ipsr_profile_read_region(int region, float* ms, int max_n)
 
 int ipsr_profile_read(float* ms, int max_n) { return ipsr_profile_read_region(0, ms, max_n); }
 
-int ipsr_profile_read_region_work(int region, float* ms, double* work, int max_n)
+int ipsr_profile_read_region_work2(int region, float* ms, double* work, double* useful, int max_n)
 {
     if (!ms || !work || max_n < 0 || region < 0 || region >= N_REGIONS) return fail(IPSR_ERR_INVALID, "ipsr_profile_read_region_work: bad arguments");
     EvRing& r = g_ring[region];
     const int avail = r.n;
-    for (int i = 0; i < avail && i < max_n; ++i) work[i] = r.work[i];
+    for (int i = 0; i < avail && i < max_n; ++i) {
+        work[i] = r.work[i];
+        if (useful) useful[i] = r.work2[i];
+    }
     return ipsr_profile_read_region(region, ms, max_n);
 }
+
+int ipsr_profile_read_region_work(int region, float* ms, double* work, int max_n) { return ipsr_profile_read_region_work2(region, ms, work, nullptr, max_n); }
 
 size_t ipsr_feat_mask_workspace_bytes(int H, int W, int layers)
 {

@@ -265,41 +265,43 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-        // piece p of stage s: p < NP/2 -> A rows, else B rows (index the __shared__ array directly: the builtin needs a
-        // pointer the compiler KNOWS is LDS)
-        auto dma_piece = [&](int s, int p) {
+        // piece p: p < NP/2 -> A rows, else B rows (index the __shared__ array directly: the builtin needs a pointer the compiler
+        // KNOWS is LDS).  One pointer per piece, advanced by a constant per stage; the prefetch is UNCONDITIONAL — past the last
+        // stage it re-reads the last one into a slot nobody reads again — so the loop body has no branch and the number of DMAs
+        // in flight is the same in every iteration: one constant vmcnt (measured on the Winograd GEMM, the same pipeline: -8 %).
+        const float* gp[NP];
+        int loff[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
             const bool isA = p < NP / 2;
             const int pair = wave + 4 * (isA ? p : p - NP / 2);
-            const int slot = (s & (FNBUF - 1)) * (2 * FBK * BM) + (isA ? 0 : FBK * BM) + pair * 2 * BM;
-            const size_t row = (size_t)s * FBK + 2 * pair + dma_row;
-            const float* g = isA ? (A + row * ld + k0 + dma_col) : (R + row * ld + q0 + dma_col);
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)&lds[slot], 16, 0, 0);
+            loff[p] = (isA ? 0 : FBK * BM) + pair * 2 * BM;
+            const size_t row = (size_t)2 * pair + dma_row;
+            gp[p] = isA ? (A + row * ld + k0 + dma_col) : (R + row * ld + q0 + dma_col);
+        }
+        const size_t stage_stride = (size_t)FBK * ld;
+        auto dma_piece = [&](int p, int slot, bool more) {
+            __builtin_amdgcn_global_load_lds((gptr_t)gp[p], (lptr_t)&lds[slot * (2 * FBK * BM) + loff[p]], 16, 0, 0);
+            gp[p] += more ? stage_stride : 0;
         };
-        auto wait_stage = [&](int younger) {      // `younger` = stages whose DMA was issued after the one needed now
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-
+        constexpr int AHEAD = FNBUF - 1;
+        int issued = 0, pf_slot = 0;
         // prologue: stages 0,1,2 in flight; stage 0 must have landed before the first compute
 #pragma unroll
-        for (int p = 0; p < NP; ++p) dma_piece(0, p);
-        if (nstage > 1) {
+        for (int a2 = 0; a2 < AHEAD; ++a2) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) dma_piece(1, p);
+            for (int p = 0; p < NP; ++p) dma_piece(p, pf_slot, issued + 1 < nstage);
+            ++issued;
+            pf_slot = (pf_slot + 1) & (FNBUF - 1);
         }
-        if (nstage > 2) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) dma_piece(2, p);
-        }
-        wait_stage(min(2, nstage - 1));
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NP) : "memory");
         __builtin_amdgcn_s_barrier();
 
         for (int s = 0; s < nstage; ++s) {
             const int cur = s & (FNBUF - 1);
             // slot (s+3)%4 was last read in stage s-1, which every wave has left (barrier); its pieces are spread
             // over this stage's k-steps
-            const bool prefetch = s + 3 < nstage;
+            const bool more = issued + 1 < nstage;
             const float* ta = tiles + (size_t)cur * (2 * FBK * BM) + h * BM + wm * 32 + r;
             const float* tb = tiles + (size_t)cur * (2 * FBK * BM) + FBK * BM + h * BM + wn * 32 + r;
             float fa0[3], fa1[3], fb0[3], fb1[3];
@@ -312,7 +314,7 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
                     const int ro = (kk + 1) * 2 * BM;
                     fa0[ns] = ta[ro]; fa1[ns] = ta[ro + 64]; fb0[ns] = tb[ro]; fb1[ns] = tb[ro + 64];
                 }
-                if (prefetch && (kk % ((FBK / 2) / NP)) == 0) dma_piece(s + 3, kk / ((FBK / 2) / NP));
+                if ((kk % ((FBK / 2) / NP)) == 0) dma_piece(kk / ((FBK / 2) / NP), pf_slot, more);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb0[cs], acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb1[cs], acc[0][1], 0, 0, 0);
@@ -320,11 +322,15 @@ corr_argmax_fast_kernel(const float* __restrict__ xn, const float* __restrict__ 
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cs], fb1[cs], acc[1][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // stage s+1 must have landed: its NP pieces are older than those of stages s+2 and s+3
-            wait_stage(min(s + 3, nstage - 1) - (s + 1));
+            ++issued;
+            pf_slot = (pf_slot + 1) & (FNBUF - 1);
+            // stage s+1 has landed once all but the two youngest stages' pieces are done
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NP) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+        // the redundant tail prefetches wrote slots that the next k-tile's prologue refills: they must have landed first
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // epilogue of this k-tile: fold 2x16 rows into the running (max, argmax) of the lane's 2 columns.
         // Rows are visited in ascending k and only a strictly larger value replaces -> lowest k on ties.

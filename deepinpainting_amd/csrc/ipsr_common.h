@@ -16,7 +16,7 @@ int check_launch(const char* what);
 
 // opt-in event bracketing of the dominant kernel (see ipsr_profile_enable in ipsr_hip.h)
 void profile_mark_start(hipStream_t st, int region = 0);
-void profile_mark_stop(hipStream_t st, int region = 0, double work = 0.0);
+void profile_mark_stop(hipStream_t st, int region = 0, double work = 0.0, double work2 = 0.0);
 
 // tuning switches (ipsr_debug_set_option in ipsr_hip.h): A/B aids, every key defaults to the shipped behaviour
 int debug_option(int key);

@@ -786,7 +786,9 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_split_kernel(const un
 }
 
 // launches the 36 GEMMs in the arithmetic `math`: 0 = fp32 operands on v_mfma_f32_32x32x2_f32; 2 / 3 = split bf16 operands
-static void launch_wino_gemm(int math, const void* A, const void* Bv, int red, int rows, int cols, const WinoSplit& sp, float* Mo, hipStream_t st)
+// `useful`: the multiply-adds of the UNPADDED problem x 2 (rows / cols / reduction before rounding up to the tile sizes)
+static void launch_wino_gemm(int math, const void* A, const void* Bv, int red, int rows, int cols, const WinoSplit& sp, float* Mo, hipStream_t st,
+                             double useful = 0.0)
 {
     const int kt = rows / WG_BM, tt = cols / WG_BN;
     const unsigned grid = sp.workgroups(kt * tt);
@@ -797,7 +799,7 @@ static void launch_wino_gemm(int math, const void* A, const void* Bv, int red, i
         wino_gemm_split_kernel<3><<<grid, WG_THREADS, 0, st>>>(static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(Bv), red, rows, cols, kt, tt, sp, Mo);
     else
         wino_gemm_kernel<<<grid, WG_THREADS, 0, st>>>(static_cast<const float*>(A), static_cast<const float*>(Bv), red, rows, cols, kt, tt, sp, Mo);
-    profile_mark_stop(st, 3, 72.0 * red * rows * cols);
+    profile_mark_stop(st, 3, 72.0 * red * rows * cols, useful);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -920,7 +922,7 @@ int launch_winograd(const void* x, const float* w, void* y, int B, int C, int K,
         });
     });
     if (int rc = check_launch("wino_input_kernel")) return rc;
-    launch_wino_gemm(ar.math, U, V, C, p.Kp, p.Tp, p.sp, Mo, st);
+    launch_wino_gemm(ar.math, U, V, C, p.Kp, p.Tp, p.sp, Mo, st, 72.0 * C * K * p.T);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     const dim3 og(cdiv(p.T, 256), K);
     with_type(ar.out_bf16, [&](auto* tag) {
@@ -980,7 +982,7 @@ int launch_winograd_wrw(const void* et, const void* dt, float* dW, int B, int K,
     });
     if (int rc = check_launch("wino_wrw_window_kernel")) return rc;
     // M[xi][k][c] = sum_t Et[xi][t][k] * Vt[xi][t][c]: the same GEMM with the tiles as the reduction
-    launch_wino_gemm(ar.math, Et, Vt, p.Tp, p.Kp, p.Cp, p.sp, Mw, st);
+    launch_wino_gemm(ar.math, Et, Vt, p.Tp, p.Kp, p.Cp, p.sp, Mw, st, 72.0 * p.T * K * C);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     wino_wrw_output_kernel<<<dim3(cdiv(C, 256), K), 256, 0, st>>>(Mw, p.sp, K, C, p.Kp, p.Cp, dW);
     return check_launch("wino_wrw_output_kernel");
@@ -1253,7 +1255,7 @@ int launch_winograd_dil(int geom, int mode, const void* a, const void* b2, void*
             });
         });
         if (int rc = check_launch("wino_window_kernel")) return rc;
-        launch_wino_gemm(ar.math, A, Bv, red, p.Kp, p.Tp, p.sp, Mo, st);
+        launch_wino_gemm(ar.math, A, Bv, red, p.Kp, p.Tp, p.sp, Mo, st, 72.0 * red * prod * p.T);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
         with_type(ar.out_bf16, [&](auto* tag) {
             using T = ELEM_T(tag);
@@ -1273,7 +1275,7 @@ int launch_winograd_dil(int geom, int mode, const void* a, const void* b2, void*
         });
     });
     if (int rc = check_launch("wino_window_kernel")) return rc;
-    launch_wino_gemm(ar.math, A, Bv, p.Tp, p.Kp, p.Cp, p.sp, Mo, st);
+    launch_wino_gemm(ar.math, A, Bv, p.Tp, p.Kp, p.Cp, p.sp, Mo, st, 72.0 * p.T * Cout * Cin);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     wino_wrw_output4_kernel<<<dim3(cdiv(Cin, 256), Cout), 256, 0, st>>>(Mo, p.sp, Cout, Cin, p.Kp, p.Cp, static_cast<float*>(out));
     return check_launch("wino_wrw_output4_kernel");
@@ -1678,7 +1680,7 @@ int launch_winograd_s2(int mode, const void* a, const void* b2, void* out, int B
             });
         });
         if (int rc = check_launch("wino5_window_kernel")) return rc;
-        launch_wino_gemm(ar.math, A, Bv, p.red, p.Kp, p.Tp, p.sp, Mo, st);
+        launch_wino_gemm(ar.math, A, Bv, p.red, p.Kp, p.Tp, p.sp, Mo, st, 72.0 * p.red * (mode == 0 ? Kc : 4 * Cf) * p.T);
         if (int rc = check_launch("wino_gemm_kernel")) return rc;
         with_type(ar.out_bf16, [&](auto* tag) {
             using T = ELEM_T(tag);
@@ -1697,7 +1699,7 @@ int launch_winograd_s2(int mode, const void* a, const void* b2, void* out, int B
         });
     });
     if (int rc = check_launch("wino5_window_kernel")) return rc;
-    launch_wino_gemm(ar.math, A, Bv, p.Tp, p.Kp, p.Cp, p.sp, Mo, st);
+    launch_wino_gemm(ar.math, A, Bv, p.Tp, p.Kp, p.Cp, p.sp, Mo, st, 72.0 * p.T * Kc * 4 * Cf);
     if (int rc = check_launch("wino_gemm_kernel")) return rc;
     wino_wrw_output2_kernel<<<dim3(cdiv(Cf, 256), Kc, 4), 256, 0, st>>>(Mo, p.sp, Kc, Cf, p.Kp, p.Cp, static_cast<float*>(out));
     return check_launch("wino_wrw_output2_kernel");

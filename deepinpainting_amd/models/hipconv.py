@@ -68,7 +68,27 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     the rules query the library (workspace probes), ~150 convolution calls per training step ask.
     bf16: the activations are bf16 tensors — only the Winograd engines read / write those; every other shape takes MIOpen."""
     eng = _select(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0") + os.environ.get("IPSR_NO_THIN", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
-    return eng if (not bf16 or eng in _BF16_ENGINES) else "miopen"
+    return eng if (not bf16 or _bf16_wins(eng, Cin, H, W, Cout)) else "miopen"
+
+
+def _bf16_wins(eng, Cin, H, W, Cout):
+    """bf16 activations (BASELINE config 5).  MIOpen's bf16 implicit GEMMs run ~490 TF and need no transform passes; the Winograd
+    engines here must SPLIT their operands (F(4x4,3x3) amplifies rounding ~100x), so their intermediates stay fp32-wide: 4.5x the
+    bf16 activation bytes each way.  They win where the channel count amortises that (profiles/r03_bf16_layers.txt, batch 16, forward
+    + both gradients against MIOpen incl. its layout transposes and weight casts): the 3x3 layers with >= 512 channels on one side at
+    <= 32x32 (0.72-0.79x), the dilated 4x4 layers with >= 256 channels at <= 64x64 (0.70-0.90x), netD's 4x4 stride-1 layer (0.95x);
+    they lose on larger maps and on the whole 4x4 stride-2 family (1.1-1.7x) — those stay on MIOpen.  IPSR_BF16_ENGINES=all|none
+    overrides (A/B timing)."""
+    force = os.environ.get("IPSR_BF16_ENGINES", "")
+    if eng not in _BF16_ENGINES or force == "none":
+        return False
+    if force == "all":
+        return True
+    if eng == "winograd":
+        return H * W <= 1024 and max(Cin, Cout) >= 512
+    if eng == "wino_dil":
+        return H * W <= 4096 and min(Cin, Cout) >= 256
+    return False
 
 
 @functools.lru_cache(maxsize=4096)
@@ -185,7 +205,7 @@ def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     """-> the engine for the weight gradient of one layer (profiles/r02_hipconv_k3_wrw.txt: F(3x3,4x4) is 2.0-2.4x
     MIOpen from 256 channels up on maps of 16x16..64x64; on larger maps its tile-major transforms lose to MIOpen)."""
     eng = _select_wrw(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0"), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
-    return eng if (not bf16 or eng in _BF16_ENGINES) else "miopen"
+    return eng if (not bf16 or _bf16_wins(eng, Cin, H, W, Cout)) else "miopen"
 
 
 @functools.lru_cache(maxsize=4096)

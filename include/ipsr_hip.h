@@ -332,6 +332,9 @@ int ipsr_profile_read_region(int region, float* ms /*[host]*/, int max_n);
 /* region 3 = every launch of the Winograd GEMM kernel (csrc/winograd.hip, the convolutions' matrix-core kernel; its ring holds
  * 256 x capacity launches); `work` receives the flop count (2 x 36 x rows x columns x reduction, padded sizes) of each launch. */
 int ipsr_profile_read_region_work(int region, float* ms /*[host]*/, double* work /*[host]*/, int max_n);
+/* the same with `useful` = the flops of the UNPADDED problem of each launch (produced channels / tiles / reduction before they are
+ * rounded up to the 128 x 128 x 16 tile): work - useful is arithmetic on zero padding */
+int ipsr_profile_read_region_work2(int region, float* ms /*[host]*/, double* work /*[host]*/, double* useful /*[host]*/, int max_n);
 
 /* ---- mixed-precision forms of the Winograd convolutions (BASELINE config 5: "bf16 mixed precision (CDNA4 bf16 MFMA for patch-corr
  * + convs)"; also an opt-in arithmetic for the fp32 nets) -------------------------------------------------------------------------
