@@ -13,9 +13,14 @@ from deepinpainting_amd.models.models import create_model  # noqa: E402
 from deepinpainting_amd.options import Option  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-for engine in ("auto", "miopen"):
-    hipconv._FORCE = engine
-    opt = Option(gpu_ids=[0], batchSize=8, use_dropout=False, quiet=True, allow_random_vgg=True, checkpoints_dir="/tmp/ipsr_loss_ck")
+# (label, conv engine, conv_math for fp32 activations, bf16 autocast)
+RUNS = [("auto", "auto", "fp32", False), ("miopen", "miopen", "fp32", False)]
+if len(sys.argv) > 2 and sys.argv[2] == "math":          # the split-bf16 arithmetics and BASELINE config 5 against the fp32 run
+    RUNS = [("fp32", "auto", "fp32", False), ("bf16x6", "auto", "bf16x6", False), ("bf16x3", "auto", "bf16x3", False), ("amp-bf16", "auto", "fp32", True)]
+for engine, force, math, amp in RUNS:
+    hipconv._FORCE = force
+    opt = Option(gpu_ids=[0], batchSize=8, use_dropout=False, quiet=True, allow_random_vgg=True, checkpoints_dir="/tmp/ipsr_loss_ck",
+                 conv_math=math, amp_bf16=amp)
     torch.manual_seed(1234)
     with contextlib.redirect_stdout(io.StringIO()):
         model = create_model(opt)
@@ -26,7 +31,7 @@ for engine in ("auto", "miopen"):
             e = model.get_current_errors()
             vals = {k: float(v) for k, v in e.items()}
             bad = any(v != v or abs(v) == float("inf") for v in vals.values())
-            print("%-6s step %3d  " % (engine, step) + "  ".join("%s %.4f" % (k, v) for k, v in vals.items()) + ("  NON-FINITE" if bad else ""), flush=True)
+            print("%-8s step %3d  " % (engine, step) + "  ".join("%s %.4f" % (k, v) for k, v in vals.items()) + ("  NON-FINITE" if bad else ""), flush=True)
     del model
     torch.cuda.empty_cache()
 hipconv._FORCE = None
