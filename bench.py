@@ -282,7 +282,7 @@ def main():
     torch.backends.cudnn.benchmark = os.environ.get("IPSR_BENCH_MIOPEN_FIND", "0") == "1"
 
     opt = Option(gpu_ids=[local_rank], batchSize=args.batch, use_dropout=True, quiet=True, allow_random_vgg=True,
-                 batch_vgg=os.environ.get("IPSR_BENCH_BATCH_VGG", "0") == "1", amp_bf16=(args.dtype == "bf16"), conv_math=args.conv_math,
+                 batch_vgg=os.environ.get("IPSR_BENCH_BATCH_VGG", "0") == "1", batch_disc=os.environ.get("IPSR_BENCH_BATCH_DISC", "1") == "1", amp_bf16=(args.dtype == "bf16"), conv_math=args.conv_math,
                  checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
     torch.manual_seed(1234)                       # identical init on every rank (rank 0 is broadcast anyway)
     model = quiet(create_model, opt)

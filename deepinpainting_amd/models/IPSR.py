@@ -19,6 +19,9 @@ What is new (none of it changes results):
     512-channel convolutions of slice 4 were computed and dropped (same switch);
   * backward_G runs with the discriminators' parameters frozen: the gradients it would leave in netD / netF are cleared
     unused by the next optimize_parameters (:269-270) (same switch);
+  * backward_D sends the fake and the real batch through netD (and netF) in ONE pass of 2B samples (`opt.batch_disc`, default on;
+    the reference makes two passes, :196-199): same predictions, the weight gradients become one sum over 2B samples instead of
+    two sums added by autograd — fp32 summation order only (+2 % images/s);
   * bias / InstanceNorm / activation between the convolutions run as fused HIP kernels (models/fused.py), the frozen
     VGG's bias / ReLU / max-pool likewise (models/vgg16.py) — same values up to fp32 rounding;
   * data parallelism: with torch.distributed initialised (one process per GPU, RCCL) the gradients are
@@ -45,6 +48,7 @@ class IPSR(BaseModel):
         self.isTrain = opt.isTrain
         self.strict_reference = bool(getattr(opt, 'strict_reference', False))
         self.batch_vgg = bool(getattr(opt, 'batch_vgg', False))
+        self.batch_disc = bool(getattr(opt, 'batch_disc', True))       # backward_D: fake + real through netD / netF in one 2B pass
         # BASELINE config 5: convolutions under bf16 autocast (CDNA4 bf16 MFMA); the IPSR layer, the InnerCos taps and all
         # losses stay fp32.  Off by default — the reference is fp32.
         self.amp_bf16 = bool(getattr(opt, 'amp_bf16', False))
@@ -261,10 +265,20 @@ class IPSR(BaseModel):
         real_AB = self.real_B
 
         with self._amp():
-            self.pred_fake = self.netD(fake_AB.detach()).float()
-            self.pred_real = self.netD(real_AB).float()
-            self.pred_fake_F = self.netF(self.gt_latent_fake.relu3_3.detach()).float()
-            self.pred_real_F = self.netF(self.gt_latent_real.relu3_3).float()
+            if self.batch_disc and not self.strict_reference:
+                # fake and real batch through each discriminator in ONE pass of 2B samples: InstanceNorm is per sample and the
+                # convolutions per sample, so every prediction is the same number; the weight gradients become one sum over 2B
+                # samples instead of two sums added by autograd (fp32 summation order, nothing else)
+                nb = fake_AB.size(0)
+                both = self.netD(torch.cat((fake_AB.detach(), real_AB), 0)).float()
+                self.pred_fake, self.pred_real = both[:nb], both[nb:]
+                both = self.netF(torch.cat((self.gt_latent_fake.relu3_3.detach(), self.gt_latent_real.relu3_3), 0)).float()
+                self.pred_fake_F, self.pred_real_F = both[:nb], both[nb:]
+            else:
+                self.pred_fake = self.netD(fake_AB.detach()).float()
+                self.pred_real = self.netD(real_AB).float()
+                self.pred_fake_F = self.netF(self.gt_latent_fake.relu3_3.detach()).float()
+                self.pred_real_F = self.netF(self.gt_latent_real.relu3_3).float()
         self.loss_D_fake = self.criterionGAN(self.pred_fake, self.pred_real, True)
         self.loss_F_fake = self.criterionGAN(self.pred_fake_F, self.pred_real_F, True)
 
