@@ -196,8 +196,10 @@ def test_batched_discriminator_pass_gives_the_same_gradients(tmp_path):
         m.backward_D()
         got[bd] = ([p.grad.clone() for net in (m.netD, m.netF) for p in net.parameters()], float(m.loss_D_fake), float(m.loss_F_fake))
     assert got[True][1] == pytest.approx(got[False][1], rel=1e-6) and got[True][2] == pytest.approx(got[False][2], rel=1e-6)
+    gmax = max(float(b.abs().max()) for b in got[False][0])
     for a, b in zip(got[True][0], got[False][0]):
-        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9          # measured 1.6e-5: fp32 summation order
+        # measured 1.6e-5: fp32 summation order; biases in front of an InstanceNorm have an exactly-zero true gradient (noise of ~1e-6 x gmax)
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-5 * gmax
 
 
 def test_trainer_step_matches_reference(trainer):
