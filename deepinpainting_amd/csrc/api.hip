@@ -132,7 +132,7 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 10; }
+int ipsr_abi_version(void) { return 11; }
 
 int ipsr_debug_set_option(int key, int value)
 {
@@ -461,24 +461,24 @@ int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gam
 
 int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, const float* bias, const float* gamma,
                                const float* mean, const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16,
-                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream)
+                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream)
 {
     if (!dy || !y || !x || !mean || !rstd || !dx) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: null pointer");
     if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: bad argument");
     if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(x, io_bf16) || !aligned_io(dx, io_bf16)))
         return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: tensors are not vector aligned");
-    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p,
+    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p, sums,
                                    static_cast<hipStream_t>(stream));
 }
 
 int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx,
-                           float* dbias_p, void* stream)
+                           float* dbias_p, float* sums, void* stream)
 {
     if (!dy || !y || !dx) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: null pointer");
     if (B < 1 || C < 1 || HW < 1 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: bad argument");
     if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(dx, io_bf16)))
         return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: tensors are not vector aligned");
-    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, static_cast<hipStream_t>(stream));
+    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, sums, static_cast<hipStream_t>(stream));
 }
 
 size_t innercos_workspace_bytes(int B, int Cuse, int N) { return innercos_ws_bytes(B, Cuse, N); }

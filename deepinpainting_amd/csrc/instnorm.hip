@@ -8,10 +8,13 @@
 //     forward   z = x + bias[c];  mean, var over the plane;  y = act((z - mean) * rstd * gamma[c] + beta[c])      1 R + 1 W
 //     backward  dz = dy * act'(y);  xh = (x + bias - mean) * rstd;  s1 = sum dz, s2 = sum dz*xh;
 //               dx = gamma * rstd * (dz - s1/HW - xh * s2/HW);                                                    3 R + 1 W
-//               per-plane partials: dgamma += s2, dbeta += s1, dbias += sum dx   (summed over the batch by the host)
+//               per-plane partials: dgamma += s2, dbeta += s1, dbias += sum dx
+//               batch sums: the LAST of a channel's B planes to finish (a per-channel ticket) adds the B partials in
+//               fixed order b = 0..B-1 -> deterministic, and no separate reduction launch per layer
 // HBM-bound.  Planes up to 128x128 (16384 elements) — the largest normalised map of the reference's nets at 256x256.
 // fp32 tolerance vs torch (different summation order): ~1e-6 relative, asserted in tests/test_gpu_model.py.
 #include "ipsr_common.h"
+#include <atomic>
 
 namespace ipsr {
 
@@ -29,6 +32,39 @@ __device__ __forceinline__ float block_sum(float v, float* red)
 #pragma unroll
     for (int i = 1; i < T / 64; ++i) t += red[i];
     return t;
+}
+
+// Per-channel tickets for the batch reduction.  A launch takes one row of the pool (round robin on the host), so launches that
+// overlap on different streams do not share counters; the plane that draws ticket B-1 resets the counter for the next user.
+constexpr int TICKET_POOL = 32, TICKET_MAXC = 2048;
+__device__ unsigned g_tickets[TICKET_POOL][TICKET_MAXC];
+
+// Store a plane's partial so that another XCD can read it: a device-scope (write-through) store — NOT a device-scope release
+// fence, which on this chip writes back the whole L2 (measured: +100 us per launch when every plane's workgroup did one).
+__device__ __forceinline__ void st_partial(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Called by every thread of a plane's workgroup after thread 0 stored the plane's partials part[k][b][c] with st_partial (k < nk
+// arrays at stride B*C).  The workgroup that arrives last for channel c writes sums[k][c] = sum_b part[k][b][c].
+// Ordering: thread 0 waits for its write-through stores to be acknowledged (vmcnt(0)) before it draws the ticket, so whoever
+// draws B-1 finds every partial at the device-coherent level; it reads them with device-scope loads (no stale L2 / L1 line).
+__device__ __forceinline__ void batch_sum_by_last_plane(float* const* part, int nk, float* __restrict__ sums, unsigned* ticket, int B,
+                                                        int C, int c, int* last_s)
+{
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the write-through partial stores have been acknowledged
+        const unsigned old = __hip_atomic_fetch_add(ticket + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *last_s = old == (unsigned)(B - 1);
+        if (old == (unsigned)(B - 1)) __hip_atomic_store(ticket + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*last_s && (int)threadIdx.x < nk) {
+        const float* p = part[threadIdx.x];
+        if (p) {
+            float t = 0.0f;
+            for (int b = 0; b < B; ++b) t += __hip_atomic_load(p + (size_t)b * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sums[(size_t)threadIdx.x * C + c] = t;
+        }
+    }
 }
 
 __device__ __forceinline__ float act_fwd(float v, int act, float slope)
@@ -130,9 +166,11 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
                                                              const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                              const float* __restrict__ rstd_in, int act, float slope, int C, int HW,
                                                              IO* __restrict__ dx, float* __restrict__ dgamma_p,
-                                                             float* __restrict__ dbeta_p, float* __restrict__ dbias_p)
+                                                             float* __restrict__ dbeta_p, float* __restrict__ dbias_p,
+                                                             float* __restrict__ sums, unsigned* __restrict__ ticket)
 {
     __shared__ float red[4];
+    __shared__ int last_s;
     const int plane = blockIdx.x, c = plane % C, tid = threadIdx.x;
     const float bv = bias ? bias[c] : 0.0f;
     const float mean = mean_in[plane], rstd = rstd_in[plane];
@@ -207,18 +245,24 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
     }
     sdx = block_sum<T>(sdx, red);
     if (tid == 0) {
-        if (dgamma_p) dgamma_p[plane] = s2;
-        if (dbeta_p) dbeta_p[plane] = s1;
-        if (dbias_p) dbias_p[plane] = sdx;
+        if (dgamma_p) st_partial(dgamma_p + plane, s2);
+        if (dbeta_p) st_partial(dbeta_p + plane, s1);
+        if (dbias_p) st_partial(dbias_p + plane, sdx);
+    }
+    if (sums) {
+        float* const part[3] = {dgamma_p, dbeta_p, dbias_p};
+        batch_sum_by_last_plane(part, 3, sums, ticket, gridDim.x / C, C, c, &last_s);
     }
 }
 
 // act(x + bias) backward: dx = dy * act'(y), per-plane partial of the bias gradient
 template <typename IO>
 __global__ void __launch_bounds__(256) bias_act_bwd_kernel(const IO* __restrict__ dy, const IO* __restrict__ y, int act, float slope,
-                                                           int HW, IO* __restrict__ dx, float* __restrict__ dbias_p)
+                                                           int HW, IO* __restrict__ dx, float* __restrict__ dbias_p, int C,
+                                                           float* __restrict__ sums, unsigned* __restrict__ ticket)
 {
     __shared__ float red[4];
+    __shared__ int last_s;
     const int plane = blockIdx.x, tid = threadIdx.x;
     const size_t off = (size_t)plane * HW;
     float s = 0.0f;
@@ -241,7 +285,21 @@ __global__ void __launch_bounds__(256) bias_act_bwd_kernel(const IO* __restrict_
         }
     }
     s = block_sum<256>(s, red);
-    if (tid == 0 && dbias_p) dbias_p[plane] = s;
+    if (tid == 0 && dbias_p) st_partial(dbias_p + plane, s);
+    if (sums) {
+        float* const part[1] = {dbias_p};
+        batch_sum_by_last_plane(part, 1, sums, ticket, gridDim.x / C, C, plane % C, &last_s);
+    }
+}
+
+// one row of the ticket pool per launch; null when the caller wants the partials only
+static unsigned* next_ticket_row(const float* sums)
+{
+    static std::atomic<unsigned> turn{0};
+    if (!sums) return nullptr;
+    unsigned* base = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
+    return base + (size_t)(turn.fetch_add(1) % TICKET_POOL) * TICKET_MAXC;
 }
 
 constexpr int IN_MAX_HW = 16384;
@@ -272,28 +330,34 @@ int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma
 
 int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const float* bias, const float* gamma, const float* mean,
                             const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dgamma_p,
-                            float* dbeta_p, float* dbias_p, hipStream_t st)
+                            float* dbeta_p, float* dbias_p, float* sums, hipStream_t st)
 {
     if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: plane of %d elements > %d", HW, IN_MAX_HW);
+    if (sums && C > TICKET_MAXC) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: batch sums for %d channels > %d", C, TICKET_MAXC);
+    unsigned* ticket = next_ticket_row(sums);
+    if (sums && !ticket) return fail(IPSR_ERR_LAUNCH, "ipsr_instnorm_act_backward: ticket pool address");
     const int planes = B * C;
     if (io_bf16)
         IN_DISPATCH(instnorm_act_bwd_kernel, bf16_t, static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y),
-                    static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p);
+                    static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket);
     else
         IN_DISPATCH(instnorm_act_bwd_kernel, float, static_cast<const float*>(dy), static_cast<const float*>(y),
-                    static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p);
+                    static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket);
     return check_launch("instnorm_act_bwd_kernel");
 }
 
 int launch_bias_act_bwd(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dbias_p,
-                        hipStream_t st)
+                        float* sums, hipStream_t st)
 {
+    if (sums && (C > TICKET_MAXC || !dbias_p)) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_bias_act_backward: batch sums need the partials and <= %d channels", TICKET_MAXC);
+    unsigned* ticket = next_ticket_row(sums);
+    if (sums && !ticket) return fail(IPSR_ERR_LAUNCH, "ipsr_bias_act_backward: ticket pool address");
     if (io_bf16)
         bias_act_bwd_kernel<bf16_t><<<B * C, 256, 0, st>>>(static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y), act, slope, HW,
-                                                           static_cast<bf16_t*>(dx), dbias_p);
+                                                           static_cast<bf16_t*>(dx), dbias_p, C, sums, ticket);
     else
         bias_act_bwd_kernel<float><<<B * C, 256, 0, st>>>(static_cast<const float*>(dy), static_cast<const float*>(y), act, slope, HW,
-                                                          static_cast<float*>(dx), dbias_p);
+                                                          static_cast<float*>(dx), dbias_p, C, sums, ticket);
     return check_launch("bias_act_bwd_kernel");
 }
 

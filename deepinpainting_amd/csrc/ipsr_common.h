@@ -211,9 +211,9 @@ int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma
                             int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, hipStream_t st);
 int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const float* bias, const float* gamma, const float* mean,
                             const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dgamma_p,
-                            float* dbeta_p, float* dbias_p, hipStream_t st);
+                            float* dbeta_p, float* dbias_p, float* sums, hipStream_t st);
 int launch_bias_act_bwd(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dbias_p,
-                        hipStream_t st);
+                        float* sums, hipStream_t st);
 
 size_t innercos_ws_bytes(int B, int Cuse, int N);
 int launch_innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,

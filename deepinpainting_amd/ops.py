@@ -267,6 +267,9 @@ def instnorm_act_forward(x, bias, gamma, beta, eps, act, slope):
     return y, mean, rstd
 
 
+SUMS_MAX_CHANNELS = 2048       # csrc/instnorm.hip TICKET_MAXC: widest layer whose batch sums come out of the backward launch itself
+
+
 def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_affine, need_bias):
     """-> (dx, dgamma [C] | None, dbeta [C] | None, dbias [C] | None)."""
     dy, bf = _req_io(dy.to(x.dtype), "grad_output")
@@ -274,11 +277,13 @@ def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_af
     hw = x.numel() // (B * C)
     dx = torch.empty_like(x)
     part = torch.empty((3, B, C), dtype=torch.float32, device=x.device)
+    # the batch sums of the per-plane partials are written by the same launch (the last plane of each channel to finish)
+    sums = torch.empty((3, C), dtype=torch.float32, device=x.device) if C <= SUMS_MAX_CHANNELS else None
     _lib.check(_lib.lib().ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)),
                                                      mean.data_ptr(), rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
-                                                     dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(), _stream()),
-               "ipsr_instnorm_act_backward")
-    s = part.sum(1)                                     # batch reduction of the per-plane partials: one tiny kernel
+                                                     dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
+                                                     _ptr(sums), _stream()), "ipsr_instnorm_act_backward")
+    s = sums if sums is not None else part.sum(1)
     return dx, (s[0] if need_affine else None), (s[1] if need_affine else None), (s[2] if need_bias else None)
 
 
@@ -288,9 +293,10 @@ def bias_act_backward(dy, y, act, slope, need_bias):
     hw = y.numel() // (B * C)
     dx = torch.empty_like(y)
     part = torch.empty((B, C), dtype=torch.float32, device=y.device) if need_bias else None
+    sums = torch.empty(C, dtype=torch.float32, device=y.device) if need_bias and C <= SUMS_MAX_CHANNELS else None
     _lib.check(_lib.lib().ipsr_bias_act_backward(dy.data_ptr(), y.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf, dx.data_ptr(),
-                                                 _ptr(part), _stream()), "ipsr_bias_act_backward")
-    return dx, (part.sum(0) if need_bias else None)
+                                                 _ptr(part), _ptr(sums), _stream()), "ipsr_bias_act_backward")
+    return dx, ((sums if sums is not None else part.sum(0)) if need_bias else None)
 
 
 def cat_relu_forward(y, x):

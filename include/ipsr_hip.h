@@ -181,17 +181,20 @@ int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, 
  * autograd backward: one pass forward (1 read + 1 write), one pass backward (3 reads + 1 write), one (sample, channel)
  * plane of HW <= 16384 elements per workgroup.  act: 0 none, 1 ReLU, 2 LeakyReLU(slope); bias/gamma/beta may be NULL.
  *   forward : z = x + bias[c]; y = act((z - mean) * rstd * gamma[c] + beta[c]); mean/rstd [B*C] are kept for backward
- *   backward: dx [B,C,HW]; per-plane partials dgamma_p/dbeta_p/dbias_p [B*C] (any may be NULL) — the caller sums them
- *             over the batch.  `y` is the forward OUTPUT (the activation's derivative is taken from its sign).
- *   ipsr_bias_act_backward: backward of ipsr_bias_act: dx = dy * act'(y), dbias_p[b*C+c] = sum of dx over the plane. */
+ *   backward: dx [B,C,HW]; per-plane partials dgamma_p/dbeta_p/dbias_p [B*C] (any may be NULL).  `sums` [3,C] (NULL = the
+ *             caller sums the partials itself): sums[k][c] = sum over b = 0..B-1, in that order, of the k-th partial array
+ *             (rows of a NULL array are left untouched) — written by the last of channel c's B planes to finish, inside the
+ *             same launch; C <= 2048.  `y` is the forward OUTPUT (the activation's derivative is taken from its sign).
+ *   ipsr_bias_act_backward: backward of ipsr_bias_act: dx = dy * act'(y), dbias_p[b*C+c] = sum of dx over the plane;
+ *             `sums` [C] as above (needs dbias_p). */
 int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gamma, const float* beta, float eps,
                               int act, float slope, int B, int C, int HW, int io_bf16,
                               void* y, float* mean, float* rstd, void* stream);
 int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, const float* bias, const float* gamma,
                                const float* mean, const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16,
-                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, void* stream);
+                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream);
 int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16,
-                           void* dx, float* dbias_p, void* stream);
+                           void* dx, float* dbias_p, float* sums, void* stream);
 
 /* ---- convolutions of the surrounding nets ---------------------------------------------------------------
  * replaces nn.Conv2d / nn.ConvTranspose2d (bias-free part; the bias rides in the fused epilogues above) of the U-Nets,

@@ -920,6 +920,56 @@ def test_fused_instnorm_act_vs_torch(shape, act, affine, with_bias):
         assert float((a - b).abs().max()) <= 5e-5 * scale, (a.shape, float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 128, 128), (8, 512, 4, 4), (3, 7, 5, 9), (1, 2048, 2, 2), (16, 128, 31, 31)])
+def test_fused_backward_batch_sums_come_from_the_same_launch(shape):
+    """dgamma / dbeta / dbias [C] are written by the last of a channel's B planes to finish (csrc/instnorm.hip,
+    batch_sum_by_last_plane): bit-identical to adding the per-plane partials in the order b = 0..B-1, call after call (the
+    per-channel tickets reset themselves; 80 calls wrap the pool of 32 rows) and on two streams at once."""
+    from deepinpainting_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    B, C, H, W = shape
+    x = torch.randn(shape, device="cuda", generator=g)
+    dy = torch.randn(shape, device="cuda", generator=g)
+    bias, gamma, beta = (torch.randn(C, device="cuda", generator=g) for _ in range(3))
+    y, mean, rstd = ops.instnorm_act_forward(x, bias, gamma, beta, 1e-5, "leaky", 0.2)
+
+    def run(stream):
+        dx = torch.empty_like(x)
+        part = torch.empty((3, B, C), device="cuda")
+        sums = torch.full((3, C), float("nan"), device="cuda")
+        _lib.check(L.ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), bias.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                                rstd.data_ptr(), 2, 0.2, B, C, H * W, 0, dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(),
+                                                part[2].data_ptr(), sums.data_ptr(), stream.cuda_stream), "ipsr_instnorm_act_backward")
+        return dx, part, sums
+
+    def ordered(part):
+        t = torch.zeros_like(part[..., 0, :])
+        for b in range(B):
+            t = t + part[..., b, :]
+        return t
+
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    side.wait_stream(main)
+    outs = []
+    for i in range(40):
+        outs.append(run(main))
+        with torch.cuda.stream(side):
+            outs.append(run(side))
+    torch.cuda.synchronize()
+    for dx, part, sums in outs:
+        assert torch.equal(sums, ordered(part))
+        assert torch.equal(dx, outs[0][0]) and torch.equal(part, outs[0][1])
+    # the bias-only epilogue (VGG / outermost layers) shares the mechanism
+    for i in range(3):
+        dxb = torch.empty_like(x)
+        pb = torch.empty((B, C), device="cuda")
+        sb = torch.full((C,), float("nan"), device="cuda")
+        _lib.check(L.ipsr_bias_act_backward(dy.data_ptr(), y.data_ptr(), 2, 0.2, B, C, H * W, 0, dxb.data_ptr(), pb.data_ptr(), sb.data_ptr(),
+                                            main.cuda_stream), "ipsr_bias_act_backward")
+        assert torch.equal(sb, ordered(pb))
+
+
 def test_fused_bias_act_autograd_vs_torch():
     from deepinpainting_amd.models.fused import _BiasAct
     g = torch.Generator(device="cuda").manual_seed(8)
