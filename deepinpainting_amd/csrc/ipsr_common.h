@@ -70,21 +70,6 @@ struct CorrPartials {
     int ksplit;
 };
 
-// The masked positions as the device knows them: one index row for the batch (stride 0) or one row per sample, with an optional
-// per-sample count (clamped to the capacity M).
-struct MaskRef {
-    const int32_t* mpi;
-    int stride;
-    const int32_t* mcount;
-    int M;
-};
-// What is left of a correlation whose first launch covered only the q-tiles that hold masked positions (corr_fast_body.h).
-struct CorrRest {
-    const float* xn; const float* ref;
-    int C, N, ld, qtiles, ksplit, ktiles, kt_per_wg;    // qtiles == 0: nothing left
-    float* pval; int32_t* pidx;
-};
-
 // Total order of (value, patch index) candidates, torch.max semantics (util/MaxCoord.py:23): the larger value wins, a NaN
 // counts as larger than every number, equal values (or two NaNs) resolve to the lower index.  Total = the arg-max is an
 // in-range index for EVERY input (all -inf, all NaN ...), never the 0x7fffffff start value.
