@@ -11,7 +11,8 @@
 //               per-plane partials: dgamma += s2, dbeta += s1, dbias += sum dx
 //               batch sums: the LAST of a channel's B planes to finish (a per-channel ticket) adds the B partials in
 //               fixed order b = 0..B-1 -> deterministic, and no separate reduction launch per layer
-// HBM-bound.  Planes up to 128x128 (16384 elements) — the largest normalised map of the reference's nets at 256x256.
+// HBM-bound.  Planes up to 128x128 (16384 elements) live in the registers of 256 threads; the one larger normalised map of
+// the reference's nets at 256x256 (netG's outermost level, 64 x 256 x 256) takes 512 threads x 128 elements per plane.
 // fp32 tolerance vs torch (different summation order): ~1e-6 relative, asserted in tests/test_gpu_model.py.
 #include "ipsr_common.h"
 #include <atomic>
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const IO* __restric
                                                              float eps, int act, float slope, int C, int HW,
                                                              IO* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out)
 {
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int plane = blockIdx.x, c = plane % C, tid = threadIdx.x;
     const float bv = bias ? bias[c] : 0.0f;
     const IO* xp = x + (size_t)plane * HW;
@@ -160,7 +161,10 @@ __global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const IO* __restric
     if (tid == 0) { mean_out[plane] = mean; rstd_out[plane] = rstd; }
 }
 
-template <typename IO, int T, int NE, bool VEC>
+// REX (planes of more than 16384 elements: 512 threads x 128 elements): dz alone stays in registers and the second pass reads
+// x again (the plane is 256 KB and comes back from L2 / Infinity Cache) — holding xh as well would take 256 + registers per
+// lane.  Same expressions, same bits.
+template <typename IO, int T, int NE, bool VEC, bool REX = false>
 __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restrict__ dy, const IO* __restrict__ y,
                                                              const IO* __restrict__ x, const float* __restrict__ bias,
                                                              const float* __restrict__ gamma, const float* __restrict__ mean_in,
@@ -169,13 +173,14 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
                                                              float* __restrict__ dbeta_p, float* __restrict__ dbias_p,
                                                              float* __restrict__ sums, unsigned* __restrict__ ticket)
 {
-    __shared__ float red[4];
+    static_assert(!REX || VEC, "the re-reading variant exists for vector-aligned planes only");
+    __shared__ float red[16];
     __shared__ int last_s;
     const int plane = blockIdx.x, c = plane % C, tid = threadIdx.x;
     const float bv = bias ? bias[c] : 0.0f;
     const float mean = mean_in[plane], rstd = rstd_in[plane];
     const size_t off = (size_t)plane * HW;
-    float dz[NE], xh[NE];
+    float dz[NE], xh[REX ? 4 : NE];
     float s1 = 0.0f, s2 = 0.0f;
     if (VEC) {
         const int n4 = HW >> 2;
@@ -196,7 +201,7 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
                 s2 = __builtin_fmaf(a.z, h.z, s2); s2 = __builtin_fmaf(a.w, h.w, s2);
             }
             dz[4 * k] = a.x; dz[4 * k + 1] = a.y; dz[4 * k + 2] = a.z; dz[4 * k + 3] = a.w;
-            xh[4 * k] = h.x; xh[4 * k + 1] = h.y; xh[4 * k + 2] = h.z; xh[4 * k + 3] = h.w;
+            if (!REX) { xh[4 * k] = h.x; xh[4 * k + 1] = h.y; xh[4 * k + 2] = h.z; xh[4 * k + 3] = h.w; }
         }
     } else {
 #pragma unroll
@@ -223,11 +228,19 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
         for (int k = 0; k < NE / 4; ++k) {
             const int i = k * T + tid;
             if (i < n4) {
+                float4 h;
+                if (REX) {
+                    const float4 xv = ld4(x + off, i);
+                    h.x = ((xv.x + bv) - mean) * rstd; h.y = ((xv.y + bv) - mean) * rstd;
+                    h.z = ((xv.z + bv) - mean) * rstd; h.w = ((xv.w + bv) - mean) * rstd;
+                } else {
+                    h = make_float4(xh[4 * k], xh[4 * k + 1], xh[4 * k + 2], xh[4 * k + 3]);
+                }
                 float4 o;
-                o.x = g * ((dz[4 * k] - m1) - xh[4 * k] * m2);
-                o.y = g * ((dz[4 * k + 1] - m1) - xh[4 * k + 1] * m2);
-                o.z = g * ((dz[4 * k + 2] - m1) - xh[4 * k + 2] * m2);
-                o.w = g * ((dz[4 * k + 3] - m1) - xh[4 * k + 3] * m2);
+                o.x = g * ((dz[4 * k] - m1) - h.x * m2);
+                o.y = g * ((dz[4 * k + 1] - m1) - h.y * m2);
+                o.z = g * ((dz[4 * k + 2] - m1) - h.z * m2);
+                o.w = g * ((dz[4 * k + 3] - m1) - h.w * m2);
                 sdx += (o.x + o.y) + (o.z + o.w);
                 st4(dx + off, i, o);
             }
@@ -302,7 +315,8 @@ static unsigned* next_ticket_row(const float* sums)
     return base + (size_t)(turn.fetch_add(1) % TICKET_POOL) * TICKET_MAXC;
 }
 
-constexpr int IN_MAX_HW = 16384;
+constexpr int IN_MAX_HW = 65536;       // 256 x 256: the outermost norm of netG (planes above 16384 must be vector aligned)
+constexpr int IN_MAX_HW_REG = 16384;   // largest plane a 256-thread workgroup holds in registers
 
 // Launch shape: wave-sized workgroups for small planes, 256 threads above; a thread holds at most 64 elements.
 #define IN_DISPATCH(KERNEL, IO, ...)                                                                                    \
@@ -319,6 +333,16 @@ int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma
 {
     if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: plane of %d elements > %d", HW, IN_MAX_HW);
     const int planes = B * C;
+    if (HW > IN_MAX_HW_REG) {
+        if (HW & 3) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: a plane of %d elements (> %d) must be a multiple of 4", HW, IN_MAX_HW_REG);
+        if (io_bf16)
+            instnorm_act_fwd_kernel<bf16_t, 512, 128, true><<<planes, 512, 0, st>>>(static_cast<const bf16_t*>(x), bias, gamma, beta, eps, act, slope,
+                                                                                   C, HW, static_cast<bf16_t*>(y), mean, rstd);
+        else
+            instnorm_act_fwd_kernel<float, 512, 128, true><<<planes, 512, 0, st>>>(static_cast<const float*>(x), bias, gamma, beta, eps, act, slope,
+                                                                                  C, HW, static_cast<float*>(y), mean, rstd);
+        return check_launch("instnorm_act_fwd_kernel");
+    }
     if (io_bf16)
         IN_DISPATCH(instnorm_act_fwd_kernel, bf16_t, static_cast<const bf16_t*>(x), bias, gamma, beta, eps, act, slope, C, HW,
                     static_cast<bf16_t*>(y), mean, rstd);
@@ -337,6 +361,18 @@ int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const 
     unsigned* ticket = next_ticket_row(sums);
     if (sums && !ticket) return fail(IPSR_ERR_LAUNCH, "ipsr_instnorm_act_backward: ticket pool address");
     const int planes = B * C;
+    if (HW > IN_MAX_HW_REG) {
+        if (HW & 3) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: a plane of %d elements (> %d) must be a multiple of 4", HW, IN_MAX_HW_REG);
+        if (io_bf16)
+            instnorm_act_bwd_kernel<bf16_t, 512, 128, true, true><<<planes, 512, 0, st>>>(
+                static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW,
+                static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket);
+        else
+            instnorm_act_bwd_kernel<float, 512, 128, true, true><<<planes, 512, 0, st>>>(
+                static_cast<const float*>(dy), static_cast<const float*>(y), static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW,
+                static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket);
+        return check_launch("instnorm_act_bwd_kernel");
+    }
     if (io_bf16)
         IN_DISPATCH(instnorm_act_bwd_kernel, bf16_t, static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y),
                     static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket);

@@ -169,7 +169,8 @@ class FusedSequential(nn.Sequential):
                 else:
                     y, bias, j = x, None, i + 1
                 hw = y.size(2) * y.size(3)
-                if hw > ops.INSTNORM_MAX_PLANE or hw < 2 or not y.is_contiguous() or y.dtype not in (torch.float32, torch.bfloat16):
+                if hw > ops.INSTNORM_MAX_PLANE or (hw > 16384 and hw % 4) or hw < 2 or not y.is_contiguous() \
+                        or y.dtype not in (torch.float32, torch.bfloat16):
                     if conv:                       # too large for the plane-in-registers kernel: plain modules
                         y = y + m.bias.view(1, -1, 1, 1)
                     x = norm(y)

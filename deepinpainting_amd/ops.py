@@ -246,7 +246,7 @@ def bias_act_(x, bias, act="relu", slope=0.2):
 
 
 ACT_CODE = {"none": 0, "relu": 1, "leaky": 2}
-INSTNORM_MAX_PLANE = 16384
+INSTNORM_MAX_PLANE = 65536       # planes above 16384 elements must be a multiple of 4 (csrc/instnorm.hip)
 
 
 def _ptr(t):

@@ -880,7 +880,8 @@ def test_vgg16_fused_glue_bit_identical():
 
 
 @pytest.mark.parametrize("shape,act,affine,with_bias", [((2, 5, 7, 9), "leaky", True, True),       # odd plane: scalar path
-                                                        ((8, 64, 128, 128), "relu", True, True),   # largest plane (64/thread)
+                                                        ((8, 64, 128, 128), "relu", True, True),   # largest plane held by 256 threads
+                                                        ((2, 64, 256, 256), "leaky", True, True),  # netG's outermost norm: 512 threads x 128
                                                         ((2, 16, 64, 64), "none", True, False),
                                                         ((3, 32, 31, 31), "leaky", True, True),    # netD's 31x31 map
                                                         ((2, 512, 4, 4), "relu", False, True),     # netF: no affine
@@ -920,7 +921,7 @@ def test_fused_instnorm_act_vs_torch(shape, act, affine, with_bias):
         assert float((a - b).abs().max()) <= 5e-5 * scale, (a.shape, float((a - b).abs().max()), scale)
 
 
-@pytest.mark.parametrize("shape", [(8, 64, 128, 128), (8, 512, 4, 4), (3, 7, 5, 9), (1, 2048, 2, 2), (16, 128, 31, 31)])
+@pytest.mark.parametrize("shape", [(8, 64, 128, 128), (8, 512, 4, 4), (3, 7, 5, 9), (1, 2048, 2, 2), (16, 128, 31, 31), (2, 16, 256, 256)])
 def test_fused_backward_batch_sums_come_from_the_same_launch(shape):
     """dgamma / dbeta / dbias [C] are written by the last of a channel's B planes to finish (csrc/instnorm.hip,
     batch_sum_by_last_plane): bit-identical to adding the per-plane partials in the order b = 0..B-1, call after call (the
