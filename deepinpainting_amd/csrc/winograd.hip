@@ -1512,34 +1512,48 @@ __global__ void __launch_bounds__(256) wino5_output_kernel(const float* __restri
         }
 }
 
-// mode 1: phase ph = blockIdx.z of tile t and fine channel k (GEMM row ph*K + k) -> its 25 pixels of y [B,K,2n_h,2n_w]:
-// y[2(5ty+m) - ey][2(5tx+m') - ex] = (A5^T M_ph A5)[m][m']  wherever the coarse index 5t + m - e lies in [0, n).
-// One phase per thread (not the four of a tile): four times the threads in flight — these launches are latency bound.
+// mode 1: the four phases of tile t and fine channel k (GEMM rows ph*K + k) -> the 10 x 10 block of y [B,K,2n_h,2n_w] they
+// interleave into:  y[2(5ty+m) - ey][2(5tx+m') - ex] = (A5^T M_ph A5)[m][m']  wherever the coarse index 5t + m - e lies in [0, n),
+// i.e. the block starts at (10ty - 1, 10tx - 1).  One phase per thread (wave = phase, lane = one of 64 consecutive tiles: the 36
+// loads of a lane are coalesced over t); the results meet in LDS and leave as ROWS — 64 tiles x 10 columns of one fine row per
+// sweep, contiguous wherever the tiles are neighbours — instead of 25 stores per thread at 8-byte pitch inside a 40-byte thread
+// stride (1.7-2.4 TB/s effective).  Measured per layer (profiles/r03_hipconv_k4s2.txt): ConvTranspose2d forward 64 -> 64 @128 -> 256
+// 0.299 -> 0.210 ms, 128 -> 128 @64 0.161 -> 0.132, Conv2d input gradient 64 <- 128 @128 0.109 -> 0.096.  The same trick on the
+// dense 5 x 5 / 3 x 3 output tiles (5 or 3 consecutive floats per thread and row already) measured no gain and was not kept.
+constexpr int W5R_TILES = 64;
 template <typename TOUT>
-__global__ void __launch_bounds__(256) wino5_output_phase_kernel(const float* __restrict__ Mo, WinoSplit split, int B, int K, int Kp, int nh, int nw,
-                                                                 int TY, int TX, int Tp, TOUT* __restrict__ y)
+__global__ void __launch_bounds__(256) wino5_output_rows_kernel(const float* __restrict__ Mo, WinoSplit split, int B, int K, int Kp, int nh, int nw,
+                                                                int TY, int TX, int Tp, TOUT* __restrict__ y)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    __shared__ float blk[W5R_TILES][101];                     // [tile][10 x 10], odd pitch: lane-per-tile writes hit distinct banks
+    __shared__ int org_y[W5R_TILES], org_x[W5R_TILES], org_b[W5R_TILES];
+    const int tl = threadIdx.x & 63, ph = threadIdx.x >> 6, ey = ph >> 1, ex = ph & 1;
+    const int t0 = blockIdx.x * W5R_TILES, t = t0 + tl, k = blockIdx.y;
     const int T = B * TY * TX;
-    if (t >= T) return;
-    const int b = t / (TY * TX), rem = t - b * TY * TX;
-    const int ty = rem / TX, tx = rem - ty * TX;
-    const int Wy = 2 * nw;
-    TOUT* yp = y + ((size_t)b * K + k) * (size_t)(2 * nh) * Wy;
-    const int ph = blockIdx.z, ey = ph >> 1, ex = ph & 1;
-    float m[6][6], o[5][5];
-    wino_load_sum(Mo, split, (size_t)Kp * Tp, (size_t)(ph * K + k) * Tp + t, m);
-    wino_at5_2d(m, o);
+    if (t < T) {
+        float m[6][6], o[5][5];
+        wino_load_sum(Mo, split, (size_t)Kp * Tp, (size_t)(ph * K + k) * Tp + t, m);
+        wino_at5_2d(m, o);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int iy = 5 * ty + i - ey;
-        if (iy < 0 || iy >= nh) continue;
-        TOUT* row = yp + (size_t)(2 * iy + ey) * Wy + ex;
+        for (int i = 0; i < 5; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int ix = 5 * tx + j - ex;
-            if (ix >= 0 && ix < nw) st1(row, (size_t)(2 * ix), o[i][j]);
+            for (int j = 0; j < 5; ++j) blk[tl][(2 * i - ey + 1) * 10 + (2 * j - ex + 1)] = o[i][j];
+        if (ph == 0) {
+            const int b = t / (TY * TX), rem = t - b * TY * TX;
+            const int ty = rem / TX, tx = rem - ty * TX;
+            org_b[tl] = b; org_y[tl] = 10 * ty - 1; org_x[tl] = 10 * tx - 1;
         }
+    }
+    __syncthreads();
+    const int Hy = 2 * nh, Wy = 2 * nw;
+    const int ntile = min(W5R_TILES, T - t0);
+    for (int e = threadIdx.x; e < 10 * 10 * W5R_TILES; e += 256) {
+        const int r = e / (10 * W5R_TILES), xs = e - r * (10 * W5R_TILES);
+        const int tile = xs / 10, c = xs - tile * 10;
+        if (tile >= ntile) continue;
+        const int fy = org_y[tile] + r, fx = org_x[tile] + c;
+        if (fy < 0 || fy >= Hy || fx < 0 || fx >= Wy) continue;
+        st1(y + ((size_t)org_b[tile] * K + k) * (size_t)Hy * Wy, (size_t)fy * Wy + fx, blk[tile][r * 10 + c]);
     }
 }
 
@@ -1685,7 +1699,7 @@ int launch_winograd_s2(int mode, const void* a, const void* b2, void* out, int B
         with_type(ar.out_bf16, [&](auto* tag) {
             using T = ELEM_T(tag);
             if (mode == 0) wino5_output_kernel<T><<<dim3(cdiv(p.T, 256), Kc), 256, 0, st>>>(Mo, p.sp, B, Kc, p.Kp, nh, nw, p.TY, p.TX, p.Tp, static_cast<T*>(out));
-            else wino5_output_phase_kernel<T><<<dim3(cdiv(p.T, 256), Cf, 4), 256, 0, st>>>(Mo, p.sp, B, Cf, p.Kp, nh, nw, p.TY, p.TX, p.Tp, static_cast<T*>(out));
+            else wino5_output_rows_kernel<T><<<dim3(cdiv(p.T, W5R_TILES), Cf), 256, 0, st>>>(Mo, p.sp, B, Cf, p.Kp, nh, nw, p.TY, p.TX, p.Tp, static_cast<T*>(out));
         });
         return check_launch("wino5_output_kernel");
     }

@@ -114,7 +114,7 @@ def _select(mode, _nosm, op, B, Cin, H, W, Cout, k, stride, pad, dil):
         return "smallmap"        # innermost levels (<= 32 positions per batch): the weight tensor streamed once into MFMA operands
     if mode == "auto":
         g = _s2_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
-        if g is not None and _s2_wins(g) and ops.s2_winograd_supported(_s2_mode(op), B, *g):
+        if g is not None and _s2_wins(g, _s2_mode(op)) and ops.s2_winograd_supported(_s2_mode(op), B, *g):
             return "wino_s2"     # 4x4 stride-2 layers: polyphase Winograd F(5x5,2x2)
     # auto: measured rules (MI355X, batch 8; profiles/r02_hipconv_k3.txt, r02_hipconv_all.txt)
     if wino_ok and H * W >= 256 and max(cred, kout) >= 128 and min(cred, kout) >= 64:
@@ -139,10 +139,13 @@ def _s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
     return Cout, Cin, H // 2, W // 2
 
 
-def _s2_wins(geom):
-    """Measured (profiles/r02_hipconv_k4s2.txt, batch 8): F(5x5,2x2) beats MIOpen by 5-30 % from 128 coarse / 64 fine channels up
-    on coarse grids of 16..64; it loses on 8x8 and below (too few tiles) and on the 64-channel 128x128 layer (transform bound)."""
+def _s2_wins(geom, mode=None):
+    """Measured (profiles/r03_hipconv_k4s2.txt, batch 8): F(5x5,2x2) beats MIOpen by 5-35 % from 128 coarse / 64 fine channels up
+    on coarse grids of 16..64; it loses on 8x8 and below (too few tiles).  The 64-channel 128x128 layer is transform bound: only
+    its coarse-to-fine pass (ConvTranspose2d forward), whose output transform writes whole rows, is ahead (0.210 vs 0.226 ms)."""
     Kc, Cf, nh, nw = geom
+    if mode == ops.S2_COARSE_TO_FINE and Kc >= 64 and Cf >= 64 and 16 <= min(nh, nw) and max(nh, nw) <= 128:
+        return True
     return Kc >= 128 and Cf >= 64 and 16 <= min(nh, nw) and max(nh, nw) <= 64
 
 
