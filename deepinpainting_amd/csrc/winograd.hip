@@ -531,10 +531,18 @@ __global__ void __launch_bounds__(256) wino_wrw_output_kernel(const float* __res
 // nsplit > 1: the reduction is cut into nsplit ranges of `sps` stages; range `ks` writes its own partial Mo + ks*36*Kp*Tp (summed,
 // in order, by the output transform).  Small layers have too few 128x128 tiles to fill 256 CUs x 2 otherwise (36 x 4 x 1 = 144
 // workgroups for a 512-channel 16x16 map), and tile counts just above a multiple of 512 leave a nearly empty second round.
+// BM = rows (produced channels) per workgroup tile: 128, or 64 for the layers that produce 64 channels (VGG conv1_2, the outermost
+// U-Net levels) — padding those to 128 rows made half of the GEMM's flops, and half of the M it writes, zeros.  With 64 rows a wave
+// owns 32 rows x {32, +64} columns: one A fragment and one ds_read2st64 of B per two MFMAs, three DMA pieces per wave and stage
+// (one of A: four 256-byte rows, two of B).
+template <int BM>
 __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* __restrict__ U, const float* __restrict__ V, int C, int Kp, int Tp,
                                                                   int ktiles, int ttiles, WinoSplit split, float* __restrict__ Mo)
 {
-    __shared__ __attribute__((aligned(16))) float lds[WG_NBUF * 2 * WG_BK * WG_BM];
+    static_assert(BM == 128 || BM == 64, "row tile");
+    constexpr int SLOT = WG_BK * (BM + WG_BN);                 // floats per ring slot: A [16][BM] then B [16][128]
+    constexpr int MI = BM / 64;                                // 32-row fragments per wave
+    __shared__ __attribute__((aligned(16))) float lds[WG_NBUF * SLOT];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -552,39 +560,46 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
     const int xi0 = L / per_xi, rem = L - xi0 * per_xi;
     const int xi = xi0 + (is_tail ? split.xi_split : 0);
     const int ks = rem % nsplit, kt = (rem / nsplit) % ktiles, tt = rem / (nsplit * ktiles);
-    const int k0 = kt * WG_BM, t0 = tt * WG_BN;
+    const int k0 = kt * BM, t0 = tt * WG_BN;
     const int s_lo = ks * sps;
     const float* A = U + (size_t)xi * C * Kp + (size_t)s_lo * WG_BK * Kp;
     const float* Bm = V + (size_t)xi * C * Tp + (size_t)s_lo * WG_BK * Tp;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int nstage = min(C / WG_BK - s_lo, sps);        // stages of this workgroup (>= 1)
-    constexpr int NP = WG_BK / 4;                         // DMA pieces (1 KiB = 2 rows) per wave per stage: 2 of A, 2 of B
+    // DMA pieces of 1 KiB per wave and stage.  BM = 128: 2 of A + 2 of B, each two 512-byte rows (lane -> row parity, 16-byte
+    // column).  BM = 64: 1 of A = four 256-byte rows (lane -> row lane>>4, column lane&15) + 2 of B.
+    constexpr int NPA = BM == 128 ? 2 : 1, NP = NPA + 2;
     constexpr int AHEAD = WG_NBUF - 1;
     // One pointer per DMA piece, advanced by a constant per stage; the prefetch is unconditional (past the last stage it re-reads
     // the last one into a slot nobody reads again): no branch in the loop body and one constant vmcnt (see wino_gemm_split_kernel).
-    const int dma_row = lane >> 5, dma_col = (lane & 31) * 4;
     const float* gp[NP];
     int loff[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const bool isA = p < NP / 2;
-        const int pair = wave + 4 * (isA ? p : p - NP / 2);
-        loff[p] = (isA ? 0 : WG_BK * WG_BM) + pair * 2 * WG_BM;
-        const size_t row = (size_t)2 * pair + dma_row;
-        gp[p] = isA ? (A + row * Kp + k0 + dma_col) : (Bm + row * Tp + t0 + dma_col);
+        const bool isA = p < NPA;
+        if (isA && BM == 64) {
+            const int row = 4 * wave + (lane >> 4);                       // 16 rows of 64 floats: wave w owns rows 4w..4w+3
+            loff[p] = 4 * wave * BM;
+            gp[p] = A + (size_t)row * Kp + k0 + (lane & 15) * 4;
+        } else {
+            const int pair = wave + 4 * (isA ? p : p - NPA);
+            loff[p] = (isA ? 0 : WG_BK * BM) + pair * 2 * 128;
+            const size_t row = (size_t)2 * pair + (lane >> 5);
+            gp[p] = isA ? (A + row * Kp + k0 + (lane & 31) * 4) : (Bm + row * Tp + t0 + (lane & 31) * 4);
+        }
     }
     const size_t strideA = (size_t)WG_BK * Kp, strideB = (size_t)WG_BK * Tp;
     auto dma_piece = [&](int p, int slot, bool more) {
-        __builtin_amdgcn_global_load_lds((gptr_t)gp[p], (lptr_t)&lds[slot * (2 * WG_BK * WG_BM) + loff[p]], 16, 0, 0);
-        gp[p] += more ? (p < NP / 2 ? strideA : strideB) : 0;
+        __builtin_amdgcn_global_load_lds((gptr_t)gp[p], (lptr_t)&lds[slot * SLOT + loff[p]], 16, 0, 0);
+        gp[p] += more ? (p < NPA ? strideA : strideB) : 0;
     };
     int issued = 0, pf_slot = 0;
 #pragma unroll
@@ -600,23 +615,28 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & (WG_NBUF - 1);
         const bool more = issued + 1 < nstage;
-        const float* ta = lds + (size_t)cur * (2 * WG_BK * WG_BM) + h * WG_BM + wm * 32 + r;
-        const float* tb = lds + (size_t)cur * (2 * WG_BK * WG_BM) + WG_BK * WG_BM + h * WG_BM + wn * 32 + r;
-        float fa0[3], fa1[3], fb0[3], fb1[3];
-        fa0[0] = ta[0]; fa1[0] = ta[64]; fb0[0] = tb[0]; fb1[0] = tb[64];
+        const float* ta = lds + (size_t)cur * SLOT + h * BM + wm * 32 + r;
+        const float* tb = lds + (size_t)cur * SLOT + WG_BK * BM + h * WG_BN + wn * 32 + r;
+        float fa[MI][3], fb0[3], fb1[3];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i][0] = ta[64 * i];
+        fb0[0] = tb[0]; fb1[0] = tb[64];
 #pragma unroll
         for (int kk = 0; kk < WG_BK / 2; ++kk) {
             const int cs = kk % 3, nx = (kk + 1) % 3;
             if (kk + 1 < WG_BK / 2) {
-                const int ro = (kk + 1) * 2 * WG_BM;
-                fa0[nx] = ta[ro]; fa1[nx] = ta[ro + 64]; fb0[nx] = tb[ro]; fb1[nx] = tb[ro + 64];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i][nx] = ta[(kk + 1) * 2 * BM + 64 * i];
+                fb0[nx] = tb[(kk + 1) * 2 * WG_BN]; fb1[nx] = tb[(kk + 1) * 2 * WG_BN + 64];
             }
-            if ((kk % ((WG_BK / 2) / NP)) == 0) dma_piece(kk / ((WG_BK / 2) / NP), pf_slot, more);
+            // the stage's DMA pieces are spread over its k-steps (4 pieces: every second step; 3: steps 0, 3, 6)
+            if (NP == 4 ? (kk % 2 == 0) : (kk % 3 == 0 && kk / 3 < NP)) dma_piece(NP == 4 ? kk / 2 : kk / 3, pf_slot, more);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb0[cs], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cs], fb1[cs], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cs], fb0[cs], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cs], fb1[cs], acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][cs], fb0[cs], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][cs], fb1[cs], acc[i][1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         ++issued;
@@ -632,7 +652,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_kernel(const float* _
     for (int jn = 0; jn < 2; ++jn) {
         const int t = t0 + wn * 32 + jn * 64 + r;
 #pragma unroll
-        for (int im = 0; im < 2; ++im)
+        for (int im = 0; im < MI; ++im)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = k0 + wm * 32 + im * 64 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -787,18 +807,25 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wino_gemm_split_kernel(const un
 
 // launches the 36 GEMMs in the arithmetic `math`: 0 = fp32 operands on v_mfma_f32_32x32x2_f32; 2 / 3 = split bf16 operands
 // `useful`: the multiply-adds of the UNPADDED problem x 2 (rows / cols / reduction before rounding up to the tile sizes)
+// Rows (produced channels) of the GEMM operand U / of M as stored: a multiple of 128, or exactly 64 for the 64-channel layers in
+// fp32 arithmetic (wino_gemm_kernel<64>); math < 0 = "whatever arithmetic" for workspace sizing (the larger padding).
+static int wino_rows_padded(int K, int math) { return (math == 0 && K <= 64) ? 64 : (K + WG_BM - 1) / WG_BM * WG_BM; }
+static int wino_row_tiles(int Kp) { return Kp == 64 ? 1 : Kp / WG_BM; }
+
 static void launch_wino_gemm(int math, const void* A, const void* Bv, int red, int rows, int cols, const WinoSplit& sp, float* Mo, hipStream_t st,
                              double useful = 0.0)
 {
-    const int kt = rows / WG_BM, tt = cols / WG_BN;
+    const int kt = wino_row_tiles(rows), tt = cols / WG_BN;
     const unsigned grid = sp.workgroups(kt * tt);
     profile_mark_start(st, 3);
     if (math == 2)
         wino_gemm_split_kernel<2><<<grid, WG_THREADS, 0, st>>>(static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(Bv), red, rows, cols, kt, tt, sp, Mo);
     else if (math == 3)
         wino_gemm_split_kernel<3><<<grid, WG_THREADS, 0, st>>>(static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(Bv), red, rows, cols, kt, tt, sp, Mo);
+    else if (rows == 64)
+        wino_gemm_kernel<64><<<grid, WG_THREADS, 0, st>>>(static_cast<const float*>(A), static_cast<const float*>(Bv), red, rows, cols, kt, tt, sp, Mo);
     else
-        wino_gemm_kernel<<<grid, WG_THREADS, 0, st>>>(static_cast<const float*>(A), static_cast<const float*>(Bv), red, rows, cols, kt, tt, sp, Mo);
+        wino_gemm_kernel<128><<<grid, WG_THREADS, 0, st>>>(static_cast<const float*>(A), static_cast<const float*>(Bv), red, rows, cols, kt, tt, sp, Mo);
     profile_mark_stop(st, 3, 72.0 * red * rows * cols, useful);
 }
 
@@ -869,17 +896,17 @@ template <typename F> static inline void with_type(bool bf16, F&& f)
 
 struct WinoPlan { int TY, TX, T, Tp, Kp; WinoSplit sp; size_t u_floats, v_floats, m_floats, total_bytes; };
 
-static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p)
+static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p, int math)
 {
     if (C % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "winograd: %d reduction channels are not a multiple of %d", C, WG_BK);
     p->TY = (H + 3) / 4; p->TX = (W + 3) / 4;
     p->T = B * p->TY * p->TX;
     p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;
-    p->Kp = (K + WG_BM - 1) / WG_BM * WG_BM;
+    p->Kp = wino_rows_padded(K, math);
     p->u_floats = (size_t)36 * C * p->Kp * 3 / 2;          // room for three bf16 planes (the split arithmetic with NPL = 3)
     p->v_floats = (size_t)36 * C * p->Tp * 3 / 2;
     const size_t m1 = (size_t)36 * p->Kp * p->Tp;
-    p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), C / WG_BK, m1 * 4);
+    p->sp = wino_choose_split(36 * wino_row_tiles(p->Kp) * (p->Tp / WG_BN), C / WG_BK, m1 * 4);
     p->m_floats = m1 * p->sp.slabs();
     p->total_bytes = align_up(p->u_floats * 4, 256) + align_up(p->v_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
     return IPSR_OK;
@@ -887,9 +914,9 @@ static int wino_plan(int B, int C, int K, int H, int W, WinoPlan* p)
 
 size_t winograd_ws_bytes(int B, int C, int K, int H, int W)
 {
-    WinoPlan p;
-    if (wino_plan(B, C, K, H, W, &p) != IPSR_OK) return 0;
-    return p.total_bytes;
+    WinoPlan p, q;                                    // whatever arithmetic the call will ask for
+    if (wino_plan(B, C, K, H, W, &p, -1) != IPSR_OK || wino_plan(B, C, K, H, W, &q, 0) != IPSR_OK) return 0;
+    return p.total_bytes > q.total_bytes ? p.total_bytes : q.total_bytes;
 }
 
 size_t winograd_filter_floats(int C, int K) { return (size_t)36 * C * ((K + WG_BM - 1) / WG_BM * WG_BM) * 3 / 2; }
@@ -902,7 +929,7 @@ int launch_winograd(const void* x, const float* w, void* y, int B, int C, int K,
                     float* u_cache = nullptr, int u_valid = 0, ConvArith ar = ConvArith{0, false, false})
 {
     WinoPlan p;
-    if (int rc = wino_plan(B, C, K, H, W, &p)) return rc;
+    if (int rc = wino_plan(B, C, K, H, W, &p, ar.math)) return rc;
     if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
     if (epilogue < 0 || epilogue > 2 || (epilogue == 2 && ((H | W) & 1)))
         return fail(IPSR_ERR_INVALID, "winograd: epilogue %d on a %dx%d map", epilogue, H, W);
@@ -937,17 +964,17 @@ int launch_winograd(const void* x, const float* w, void* y, int B, int C, int K,
 
 struct WinoWrwPlan { int TY, TX, T, Tp, Kp, Cp; WinoSplit sp; size_t e_floats, v_floats, m_floats, total_bytes; };
 
-static int wino_wrw_plan(int B, int K, int C, int H, int W, WinoWrwPlan* p)
+static int wino_wrw_plan(int B, int K, int C, int H, int W, WinoWrwPlan* p, int math)
 {
     p->TY = (H + 3) / 4; p->TX = (W + 3) / 4;
     p->T = B * p->TY * p->TX;
     p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;            // reduction of the GEMM: a multiple of 16 (and of the 16-tile blocks)
-    p->Kp = (K + WG_BM - 1) / WG_BM * WG_BM;
+    p->Kp = wino_rows_padded(K, math);
     p->Cp = (C + WG_BN - 1) / WG_BN * WG_BN;
     p->e_floats = (size_t)36 * p->Tp * p->Kp * 3 / 2;            // room for three bf16 planes
     p->v_floats = (size_t)36 * p->Tp * p->Cp * 3 / 2;
     const size_t m1 = (size_t)36 * p->Kp * p->Cp;
-    p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
+    p->sp = wino_choose_split(36 * wino_row_tiles(p->Kp) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
     p->m_floats = m1 * p->sp.slabs();
     p->total_bytes = align_up(p->e_floats * 4, 256) + align_up(p->v_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
     return IPSR_OK;
@@ -955,9 +982,10 @@ static int wino_wrw_plan(int B, int K, int C, int H, int W, WinoWrwPlan* p)
 
 size_t winograd_wrw_ws_bytes(int B, int K, int C, int H, int W)
 {
-    WinoWrwPlan p;
-    wino_wrw_plan(B, K, C, H, W, &p);
-    return p.total_bytes;
+    WinoWrwPlan p, q;
+    wino_wrw_plan(B, K, C, H, W, &p, -1);
+    wino_wrw_plan(B, K, C, H, W, &q, 0);
+    return p.total_bytes > q.total_bytes ? p.total_bytes : q.total_bytes;
 }
 
 // dW[K][C][3][3] = sum over tiles:  tile operand `et` [B,K,H,W] (4x4 tiles), window operand `dt` [B,C,H,W] (6x6 windows)
@@ -965,7 +993,7 @@ int launch_winograd_wrw(const void* et, const void* dt, float* dW, int B, int K,
                         ConvArith ar = ConvArith{0, false, false})
 {
     WinoWrwPlan p;
-    wino_wrw_plan(B, K, C, H, W, &p);
+    wino_wrw_plan(B, K, C, H, W, &p, ar.math);
     if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "winograd wrw: workspace %zu < %zu", ws_bytes, p.total_bytes);
     if (!arith_ok(ar)) return fail(IPSR_ERR_INVALID, "winograd wrw: arithmetic %d", ar.math);
     Carver cv(ws, ws_bytes);
@@ -1172,7 +1200,7 @@ struct DilPlan { int Ho, Wo, Gy, Gx, TY, TX, T, Tp, Kp, Cp; WinoSplit sp; size_t
 // of dx; geom 1: grid = H x W; reduce Cout, produce Cin); 2: weight gradient (tiles of dy, reduction over tiles).
 // geom 0: Conv2d(k4 s2 p3 d2), output H/2 x W/2.   geom 1: Conv2d(k4 s1 p1) — netD's fourth convolution, models/networks.py:483-489
 // — output (H-1) x (W-1): the same 4-tap stride-1 correlation, on the image itself (X[i] = x[i - 1]).
-static int dil_plan(int geom, int mode, int B, int Cin, int H, int W, int Cout, DilPlan* p)
+static int dil_plan(int geom, int mode, int B, int Cin, int H, int W, int Cout, DilPlan* p, int math)
 {
     if (geom != 0 && geom != 1) return fail(IPSR_ERR_INVALID, "4x4 winograd: geometry %d", geom);
     if (geom == 0 && ((H | W) & 1)) return fail(IPSR_ERR_UNSUPPORTED, "dilated winograd: odd extent %dx%d", H, W);
@@ -1183,22 +1211,22 @@ static int dil_plan(int geom, int mode, int B, int Cin, int H, int W, int Cout, 
     p->T = B * p->TY * p->TX;
     p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;
     if (mode == 2) {
-        p->Kp = (Cout + WG_BM - 1) / WG_BM * WG_BM;
+        p->Kp = wino_rows_padded(Cout, math);
         p->Cp = (Cin + WG_BN - 1) / WG_BN * WG_BN;
         p->a_floats = (size_t)36 * p->Tp * p->Kp * 3 / 2;        // room for three bf16 planes (split arithmetic)
         p->b_floats = (size_t)36 * p->Tp * p->Cp * 3 / 2;
         const size_t m1 = (size_t)36 * p->Kp * p->Cp;
-        p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
+        p->sp = wino_choose_split(36 * wino_row_tiles(p->Kp) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
         p->m_floats = m1 * p->sp.slabs();
     } else {
         const int red = mode == 0 ? Cin : Cout, prod = mode == 0 ? Cout : Cin;
         if (red % WG_BK != 0) return fail(IPSR_ERR_UNSUPPORTED, "4x4 winograd: %d reduction channels are not a multiple of %d", red, WG_BK);
-        p->Kp = (prod + WG_BM - 1) / WG_BM * WG_BM;
+        p->Kp = wino_rows_padded(prod, math);
         p->Cp = red;
         p->a_floats = (size_t)36 * red * p->Kp * 3 / 2;
         p->b_floats = (size_t)36 * red * p->Tp * 3 / 2;
         const size_t m1 = (size_t)36 * p->Kp * p->Tp;
-        p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), red / WG_BK, m1 * 4);
+        p->sp = wino_choose_split(36 * wino_row_tiles(p->Kp) * (p->Tp / WG_BN), red / WG_BK, m1 * 4);
         p->m_floats = m1 * p->sp.slabs();
     }
     p->total_bytes = align_up(p->a_floats * 4, 256) + align_up(p->b_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
@@ -1207,9 +1235,9 @@ static int dil_plan(int geom, int mode, int B, int Cin, int H, int W, int Cout, 
 
 size_t winograd_dil_ws_bytes(int geom, int mode, int B, int Cin, int H, int W, int Cout)
 {
-    DilPlan p;
-    if (dil_plan(geom, mode, B, Cin, H, W, Cout, &p) != IPSR_OK) return 0;
-    return p.total_bytes;
+    DilPlan p, q;
+    if (dil_plan(geom, mode, B, Cin, H, W, Cout, &p, -1) != IPSR_OK || dil_plan(geom, mode, B, Cin, H, W, Cout, &q, 0) != IPSR_OK) return 0;
+    return p.total_bytes > q.total_bytes ? p.total_bytes : q.total_bytes;
 }
 
 template <bool TMAJOR, int MODE, typename T>
@@ -1226,7 +1254,7 @@ int launch_winograd_dil(int geom, int mode, const void* a, const void* b2, void*
                         void* ws, size_t ws_bytes, hipStream_t st, ConvArith ar = ConvArith{0, false, false})
 {
     DilPlan p;
-    if (int rc = dil_plan(geom, mode, B, Cin, H, W, Cout, &p)) return rc;
+    if (int rc = dil_plan(geom, mode, B, Cin, H, W, Cout, &p, ar.math)) return rc;
     if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "4x4 winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
     if (!arith_ok(ar)) return fail(IPSR_ERR_INVALID, "4x4 winograd: arithmetic %d", ar.math);
     const int Ho = p.Ho, Wo = p.Wo;
@@ -1618,7 +1646,7 @@ __global__ void __launch_bounds__(256) wino_wrw_output2_kernel(const float* __re
 
 struct S2Plan { int TY, TX, T, Tp, Kp, Cp, red; WinoSplit sp; size_t a_floats, b_floats, m_floats, total_bytes; };
 
-static int s2_plan(int mode, int B, int Kc, int Cf, int nh, int nw, S2Plan* p)
+static int s2_plan(int mode, int B, int Kc, int Cf, int nh, int nw, S2Plan* p, int math)
 {
     if (mode < 0 || mode > 2) return fail(IPSR_ERR_INVALID, "4x4 stride-2 winograd: mode %d", mode);
     p->TY = mode == 1 ? (nh + 5) / 5 : (nh + 4) / 5;
@@ -1627,24 +1655,24 @@ static int s2_plan(int mode, int B, int Kc, int Cf, int nh, int nw, S2Plan* p)
     p->Tp = (p->T + WG_BN - 1) / WG_BN * WG_BN;
     size_t m1;
     if (mode == 2) {
-        p->Kp = (Kc + WG_BM - 1) / WG_BM * WG_BM;
+        p->Kp = wino_rows_padded(Kc, math);
         p->Cp = (4 * Cf + WG_BN - 1) / WG_BN * WG_BN;
         p->red = p->Tp;
         p->a_floats = (size_t)36 * p->Tp * p->Kp * 3 / 2;
         p->b_floats = (size_t)36 * p->Tp * p->Cp * 3 / 2;
         m1 = (size_t)36 * p->Kp * p->Cp;
-        p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
+        p->sp = wino_choose_split(36 * wino_row_tiles(p->Kp) * (p->Cp / WG_BN), p->Tp / WG_BK, m1 * 4);
     } else {
         p->red = mode == 0 ? 4 * Cf : Kc;
         if (p->red % WG_BK != 0)
             return fail(IPSR_ERR_UNSUPPORTED, "4x4 stride-2 winograd: reduction length %d is not a multiple of %d", p->red, WG_BK);
         const int prod = mode == 0 ? Kc : 4 * Cf;
-        p->Kp = (prod + WG_BM - 1) / WG_BM * WG_BM;
+        p->Kp = wino_rows_padded(prod, math);
         p->Cp = p->red;
         p->a_floats = (size_t)36 * p->red * p->Kp * 3 / 2;
         p->b_floats = (size_t)36 * p->red * p->Tp * 3 / 2;
         m1 = (size_t)36 * p->Kp * p->Tp;
-        p->sp = wino_choose_split(36 * (p->Kp / WG_BM) * (p->Tp / WG_BN), p->red / WG_BK, m1 * 4);
+        p->sp = wino_choose_split(36 * wino_row_tiles(p->Kp) * (p->Tp / WG_BN), p->red / WG_BK, m1 * 4);
     }
     p->m_floats = m1 * p->sp.slabs();
     p->total_bytes = align_up(p->a_floats * 4, 256) + align_up(p->b_floats * 4, 256) + align_up(p->m_floats * 4, 256) + 256;
@@ -1653,9 +1681,9 @@ static int s2_plan(int mode, int B, int Kc, int Cf, int nh, int nw, S2Plan* p)
 
 size_t winograd_s2_ws_bytes(int mode, int B, int Kc, int Cf, int nh, int nw)
 {
-    S2Plan p;
-    if (s2_plan(mode, B, Kc, Cf, nh, nw, &p) != IPSR_OK) return 0;
-    return p.total_bytes;
+    S2Plan p, q;
+    if (s2_plan(mode, B, Kc, Cf, nh, nw, &p, -1) != IPSR_OK || s2_plan(mode, B, Kc, Cf, nh, nw, &q, 0) != IPSR_OK) return 0;
+    return p.total_bytes > q.total_bytes ? p.total_bytes : q.total_bytes;
 }
 
 // fine [B,Cf,2nh,2nw], coarse [B,Kc,nh,nw], w / dW [Kc][Cf][4][4].
@@ -1664,7 +1692,7 @@ int launch_winograd_s2(int mode, const void* a, const void* b2, void* out, int B
                        void* ws, size_t ws_bytes, hipStream_t st, ConvArith ar = ConvArith{0, false, false})
 {
     S2Plan p;
-    if (int rc = s2_plan(mode, B, Kc, Cf, nh, nw, &p)) return rc;
+    if (int rc = s2_plan(mode, B, Kc, Cf, nh, nw, &p, ar.math)) return rc;
     if (ws_bytes < p.total_bytes) return fail(IPSR_ERR_WORKSPACE, "4x4 stride-2 winograd: workspace %zu < %zu", ws_bytes, p.total_bytes);
     if (!arith_ok(ar)) return fail(IPSR_ERR_INVALID, "4x4 stride-2 winograd: arithmetic %d", ar.math);
     // the split filter transform stores whole 8-channel blocks per phase (form 0) / whole 32-column blocks per phase (form 1):

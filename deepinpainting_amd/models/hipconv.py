@@ -103,8 +103,10 @@ def _select(mode, _nosm, op, B, Cin, H, W, Cout, k, stride, pad, dil):
     if mode == "direct":
         return "direct" if ops.conv2d_supported(op, B, Cin, H, W, Cout, k, stride, pad, dil) else "miopen"
     if mode == "auto" and _is_dilated4(k, stride, pad, dil) and op in (ops.CONV_FWD, ops.CONV_BWD_DATA) \
-            and cred % 16 == 0 and min(Cin, Cout) >= 128 and 32 <= H <= 128 and H % 2 == 0 and W % 2 == 0:
-        return "wino_dil"        # netG's dilated down convolution: F(3x3,4x4), 1.4-2.0x MIOpen (profiles/r02_hipconv_k3_v3.txt)
+            and cred % 16 == 0 and min(Cin, Cout) >= 64 and 32 <= H <= 256 and H % 2 == 0 and W % 2 == 0:
+        # netG's dilated down convolution: F(3x3,4x4), 1.4-2.0x MIOpen (profiles/r02_hipconv_k3_v3.txt); since the GEMM has a
+        # 64-row tile also the outermost 64 -> 64 @256x256 level (0.171 / 0.193 vs 0.230 / 0.261 ms, profiles/r03_hipconv_k3.txt)
+        return "wino_dil"
     if mode == "auto" and _is_k4s1(k, stride, pad, dil) and op in (ops.CONV_FWD, ops.CONV_BWD_DATA) \
             and cred % 16 == 0 and min(Cin, Cout) >= 128 and 16 <= H <= 128:
         return "wino_dil"        # netD's 4x4 stride-1 convolution: the same F(3x3,4x4) pipeline on the image itself
@@ -116,8 +118,9 @@ def _select(mode, _nosm, op, B, Cin, H, W, Cout, k, stride, pad, dil):
         g = _s2_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
         if g is not None and _s2_wins(g, _s2_mode(op)) and ops.s2_winograd_supported(_s2_mode(op), B, *g):
             return "wino_s2"     # 4x4 stride-2 layers: polyphase Winograd F(5x5,2x2)
-    # auto: measured rules (MI355X, batch 8; profiles/r02_hipconv_k3.txt, r02_hipconv_all.txt)
-    if wino_ok and H * W >= 256 and max(cred, kout) >= 128 and min(cred, kout) >= 64:
+    # auto: measured rules (MI355X, batch 8; profiles/r03_hipconv_k3.txt).  64 produced channels run on the GEMM's 64-row tile:
+    # 64 -> 64 @256x256 (VGG conv1_2, forward and input gradient) 0.311 vs MIOpen's 0.378 ms
+    if wino_ok and H * W >= 256 and min(cred, kout) >= 64 and (max(cred, kout) >= 128 or kout == 64):
         return "winograd"
     if k == 4 and stride == 2 and dil == 2 and op == ops.CONV_BWD_DATA and Cin >= 128 and 16 <= H <= 128:
         return "direct"          # dilated 4x4 stride-2 input gradient: 8-12 % faster than MIOpen's f3x2_dilation2 + transposes

@@ -315,6 +315,9 @@ STEP_LAYERS = [
     ("k3_64_256",      lambda: nn.Conv2d(64, 64, 3, 1, 1), 256),                       # VGG conv1_2
     ("k3_64_128_128",  lambda: nn.Conv2d(64, 128, 3, 1, 1), 128),                      # VGG conv2_1
     ("k4s2T_128_64_128", lambda: nn.ConvTranspose2d(128, 64, 4, 2, 1), 64),            # netP / netG outer up convolution
+    ("k3T_256_64_128", lambda: nn.ConvTranspose2d(256, 64, 3, 1, 1), 128),             # netG upconv_1: 64 produced channels -> the GEMM's 64-row tile
+    ("k4d2_64_256",    lambda: nn.Conv2d(64, 64, 4, 2, 3, dilation=2), 256),           # netG outermost dilated down convolution (64-row tile)
+    ("k4s2T_64_64_128", lambda: nn.ConvTranspose2d(64, 64, 4, 2, 1), 128),             # netG outermost up convolution: row-writing output transform
 ]
 
 
@@ -553,14 +556,16 @@ def test_dispatcher_rules_and_refusals():
     sel = hipconv.select
     assert sel(ops.CONV_FWD, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd"          # VGG conv4_x / netG level 32x32
     assert sel(ops.CONVT_BWD_DATA, 8, 1024, 32, 32, 256, 3, 1, 1, 1) == "winograd"
-    assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 3, 1, 1, 1) == "miopen"            # 64 -> 64 at 256x256: traffic-bound, MIOpen wins
+    assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 3, 1, 1, 1) == "winograd"          # 64 -> 64 at 256x256 (VGG conv1_2): the GEMM's 64-row tile
+    assert hipconv.select_wrw(False, 8, 64, 256, 256, 64, 3, 1, 1, 1) == "miopen"    # its weight gradient stays: the tile-major transforms lose
     assert sel(ops.CONV_FWD, 8, 3, 256, 256, 64, 3, 1, 1, 1) == "thin"               # VGG conv1_1: vector-ALU pass
     assert sel(ops.CONV_BWD_DATA, 8, 3, 256, 256, 64, 3, 1, 1, 1) == "thin" and sel(ops.CONVT_FWD, 8, 128, 256, 256, 3, 3, 1, 1, 1) == "thin"
     assert sel(ops.CONV_FWD, 8, 6, 256, 256, 64, 3, 1, 1, 1) == "miopen"             # 6 -> 64: MIOpen is faster
     assert sel(ops.CONV_FWD, 8, 512, 4, 4, 512, 3, 1, 1, 1) == "miopen"              # tiny maps
     assert sel(ops.CONV_BWD_DATA, 8, 512, 32, 32, 512, 4, 2, 3, 2) == "wino_dil"         # netG dilated down convolution
     assert sel(ops.CONV_FWD, 8, 128, 128, 128, 128, 4, 2, 3, 2) == "wino_dil"
-    assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 4, 2, 3, 2) == "miopen"
+    assert sel(ops.CONV_FWD, 8, 64, 256, 256, 64, 4, 2, 3, 2) == "wino_dil"          # outermost dilated level on the 64-row tile
+    assert hipconv.select_wrw(False, 8, 64, 256, 256, 64, 4, 2, 3, 2) == "miopen"
     assert sel(ops.CONV_BWD_DATA, 8, 512, 16, 16, 512, 4, 2, 3, 2) == "direct"
     assert hipconv.select_wrw(False, 8, 256, 64, 64, 256, 4, 2, 3, 2) == "wino_dil"
     assert sel(ops.CONV_FWD, 8, 256, 32, 32, 512, 4, 1, 1, 1) == "wino_dil"              # netD's 4x4 stride-1 convolution
