@@ -346,6 +346,24 @@ def _geometry(m):
     return ks[0], st[0], pd[0], dl[0]
 
 
+def any_engine(m, x):
+    """True when at least one pass of m(x) would run on a HIP engine (so the caller should split the bias off and come through
+    conv_nobias); False = all three passes are MIOpen's and the plain module call loses nothing."""
+    g = _geometry(m)
+    if g is None or not x.is_cuda or x.dim() != 4 or m.weight.dtype != torch.float32 or x.dtype not in (torch.float32, torch.bfloat16) \
+            or (torch.is_autocast_enabled() and not _amp_bf16()):
+        return False
+    transposed = isinstance(m, nn.ConvTranspose2d)
+    k, stride, pad, dil = g
+    B, Cin, H, W = x.shape
+    Cout = m.weight.shape[1] if transposed else m.weight.shape[0]
+    bf16 = _amp_bf16() or x.dtype == torch.bfloat16
+    fop, bop = (ops.CONVT_FWD, ops.CONVT_BWD_DATA) if transposed else (ops.CONV_FWD, ops.CONV_BWD_DATA)
+    return select(fop, B, Cin, H, W, Cout, k, stride, pad, dil, bf16) != "miopen" \
+        or select(bop, B, Cin, H, W, Cout, k, stride, pad, dil, bf16) != "miopen" \
+        or select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16) != "miopen"
+
+
 def conv_nobias(m, x, weight=None):
     """m(x) without the bias (the fused epilogue kernels add it): HIP engine where `select` says so, else MIOpen.  fp32 activations:
     every engine; bf16 activations (a bf16 tensor, or any input under bf16 autocast — BASELINE config 5): the Winograd engines, which
