@@ -207,6 +207,143 @@ __global__ void __launch_bounds__(256) thin_wrw_reduce_kernel(const float* __res
     G[idx] = acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Conv2d with ONE output channel, stride 1 (netD's last layer, 512 -> 1, k4 p1 on 31x31: models/networks.py:489-495; batch 16 in
+// backward_D, 8 in backward_G).  252 MFLOP against 31.5 MB of input: a stream, which MIOpen's generic paths take 80-145 us
+// (forward) and 75-127 us (weight gradient) for.  Both passes here walk input planes through LDS (zero halo of `pad`, so the taps
+// need no bounds checks), a thread owning 4 adjacent output pixels of one row (Ho * ceil(Wo/4) <= 256 pixel groups):
+//   forward   workgroup = (sample, chunk of ONE_CCH channels): y_part[b][chunk][oy][ox] = sum over the chunk's channels (ascending)
+//             of sum_{r,s<K} w[c][r][s] x[b][c][oy+r-P][ox+s-P]; a second tiny launch adds the chunks in order
+//   weight    workgroup = one channel: dw[c][r][s] = sum_b sum_{oy,ox} dy[b][oy][ox] x[b][c][oy+r-P][ox+s-P], samples ascending,
+//   gradient  then the lanes (butterfly) and the four waves in order
+// (the input gradient, 1 -> 512, stays on MIOpen: 38 us).  Fixed summation orders: deterministic.
+constexpr int ONE_CCH = 8;             // channels per workgroup: 64 chunks x B workgroups keep several per CU in flight (each is a chain of plane loads)
+
+template <int K>
+__global__ void __launch_bounds__(256) one_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
+                                                      int C, int H, int W, int Ho, int Wo, int P, int nchunk)
+{
+    extern __shared__ float sm[];                    // two padded planes [(H+2P)][(W+2P)], then the chunk's weights [ONE_CCH][K*K]
+    const int Hp = H + 2 * P, Wp = W + 2 * P, psz = Hp * Wp;
+    float* plane[2] = {sm, sm + psz};
+    float* wl = sm + 2 * psz;
+    const int chunk = blockIdx.x, b = blockIdx.y, c0 = chunk * ONE_CCH;
+    const int nc = min(ONE_CCH, C - c0);
+    for (int i = threadIdx.x; i < 2 * psz; i += 256) sm[i] = 0.0f;          // the halo stays zero, the interior is overwritten
+    for (int i = threadIdx.x; i < nc * K * K; i += 256) wl[i] = w[(size_t)c0 * K * K + i];
+    const int ngx = (Wo + 3) / 4;
+    const int oy = threadIdx.x / ngx, ox0 = (threadIdx.x - oy * ngx) * 4;
+    const bool live = oy < Ho;
+    const float* xb = x + ((size_t)b * C + c0) * H * W;
+    __syncthreads();
+    auto stage = [&](int ci, float* dst) {
+        const float* xp = xb + (size_t)ci * H * W;
+        for (int i = threadIdx.x; i < H * W; i += 256) { const int yy = i / W, xx = i - yy * W; dst[(yy + P) * Wp + xx + P] = xp[i]; }
+    };
+    stage(0, plane[0]);
+    __syncthreads();
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int ci = 0; ci < nc; ++ci) {
+        const float* pl = plane[ci & 1];
+        if (ci + 1 < nc) stage(ci + 1, plane[(ci + 1) & 1]);
+        if (live) {
+            const float* wc = wl + ci * (K * K);
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                float v[K + 3];
+                const float* row = pl + (oy + r) * Wp + ox0;
+#pragma unroll
+                for (int j = 0; j < K + 3; ++j) v[j] = ox0 + j < Wp ? row[j] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    const float wv = wc[r * K + q];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[p] = __builtin_fmaf(wv, v[p + q], acc[p]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        float* dst = part + (((size_t)b * nchunk + chunk) * Ho + oy) * Wo + ox0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (ox0 + p < Wo) dst[p] = acc[p];
+    }
+}
+
+__global__ void __launch_bounds__(256) one_fwd_sum_kernel(const float* __restrict__ part, float* __restrict__ y, int n_out, int hw, int nchunk)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    const int b = i / hw, p = i - b * hw;
+    const float* src = part + (size_t)b * nchunk * hw + p;
+    float t = src[0];
+    for (int j = 1; j < nchunk; ++j) t += src[(size_t)j * hw];
+    y[i] = t;
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) one_wrw_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                      int B, int C, int H, int W, int Ho, int Wo, int P)
+{
+    extern __shared__ float sm[];                    // two padded planes of x[b][c], two planes of dy[b], then the wave sums
+    const int Hp = H + 2 * P, Wp = W + 2 * P, psz = Hp * Wp, gsz = Ho * Wo;
+    float* plane[2] = {sm, sm + psz};
+    float* gpl[2] = {sm + 2 * psz, sm + 2 * psz + gsz};
+    float* red = sm + 2 * psz + 2 * gsz;             // [4][K*K]
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * psz; i += 256) sm[i] = 0.0f;
+    const int ngx = (Wo + 3) / 4;
+    const int oy = threadIdx.x / ngx, ox0 = (threadIdx.x - oy * ngx) * 4;
+    const bool live = oy < Ho;
+    __syncthreads();
+    auto stage = [&](int b, int slot) {
+        const float* xp = x + ((size_t)b * C + c) * H * W;
+        for (int i = threadIdx.x; i < H * W; i += 256) { const int yy = i / W, xx = i - yy * W; plane[slot][(yy + P) * Wp + xx + P] = xp[i]; }
+        const float* gp = dy + (size_t)b * gsz;
+        for (int i = threadIdx.x; i < gsz; i += 256) gpl[slot][i] = gp[i];
+    };
+    stage(0, 0);
+    __syncthreads();
+    float acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* pl = plane[b & 1];
+        const float* gl = gpl[b & 1];
+        if (b + 1 < B) stage(b + 1, (b + 1) & 1);
+        if (live) {
+            float g[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) g[p] = ox0 + p < Wo ? gl[oy * Wo + ox0 + p] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                float v[K + 3];
+                const float* row = pl + (oy + r) * Wp + ox0;
+#pragma unroll
+                for (int j = 0; j < K + 3; ++j) v[j] = ox0 + j < Wp ? row[j] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < K; ++q)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[r * K + q] = __builtin_fmaf(g[p], v[p + q], acc[r * K + q]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
+        if (lane == 0) red[wave * (K * K) + t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K)
+        dw[(size_t)c * K * K + threadIdx.x] = ((red[threadIdx.x] + red[K * K + threadIdx.x]) + red[2 * K * K + threadIdx.x]) + red[3 * K * K + threadIdx.x];
+}
+
 }  // namespace ipsr
 
 using namespace ipsr;
@@ -265,6 +402,46 @@ int ipsr_conv3x3_thin_wrw(const float* big, const float* small, float* g, int B,
     if (int rc = check_launch("thin_wrw_kernel")) return rc;
     thin_wrw_reduce_kernel<<<cdiv(Cb * Cs * 9, 256), 256, 0, st>>>(part, g, B, Cb, Cs, (int)(grid.x * grid.y));
     return check_launch("thin_wrw_reduce_kernel");
+}
+
+size_t ipsr_conv_to_one_workspace_bytes(int B, int C, int H, int W, int K, int pad)
+{
+    const int Ho = H + 2 * pad - K + 1, Wo = W + 2 * pad - K + 1;
+    if (B < 1 || C < 1 || pad < 0 || Ho < 1 || Wo < 1 || (K != 3 && K != 4) || Ho * cdiv(Wo, 4) > 256) return 0;
+    return align_up((size_t)B * cdiv(C, ONE_CCH) * Ho * Wo * sizeof(float), 256) + 256;
+}
+
+int ipsr_conv_to_one(int op, const float* x, const float* other, float* out, int B, int C, int H, int W, int K, int pad,
+                     void* ws, size_t ws_bytes, void* stream)
+{
+    if (!x || !other || !out) return fail(IPSR_ERR_INVALID, "ipsr_conv_to_one: null pointer");
+    const int Ho = H + 2 * pad - K + 1, Wo = W + 2 * pad - K + 1;
+    const size_t need = ipsr_conv_to_one_workspace_bytes(B, C, H, W, K, pad);
+    if (need == 0) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_to_one: %dx%d k=%d p=%d is not implemented (k in {3,4}, at most 256 groups of 4 output pixels)", H, W, K, pad);
+    if (B > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_to_one: batch %d", B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t psz = (size_t)(H + 2 * pad) * (W + 2 * pad);
+    if (op == 0) {                                    // forward: other = w [1][C][K][K], out = y [B][1][Ho][Wo]
+        if (!ws || ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "ipsr_conv_to_one: workspace %zu < %zu", ws_bytes, need);
+        const int nchunk = cdiv(C, ONE_CCH);
+        const size_t lds = (2 * psz + (size_t)ONE_CCH * K * K) * sizeof(float);
+        if (lds > 64 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_to_one: a %dx%d plane exceeds the LDS staging buffers", H, W);
+        float* part = static_cast<float*>(ws);
+        const dim3 grid(nchunk, B);
+        if (K == 4) one_fwd_kernel<4><<<grid, 256, lds, st>>>(x, other, part, C, H, W, Ho, Wo, pad, nchunk);
+        else one_fwd_kernel<3><<<grid, 256, lds, st>>>(x, other, part, C, H, W, Ho, Wo, pad, nchunk);
+        if (int rc = check_launch("one_fwd_kernel")) return rc;
+        one_fwd_sum_kernel<<<cdiv(B * Ho * Wo, 256), 256, 0, st>>>(part, out, B * Ho * Wo, Ho * Wo, nchunk);
+        return check_launch("one_fwd_sum_kernel");
+    }
+    if (op == 2) {                                    // weight gradient: other = dy [B][1][Ho][Wo], out = dw [1][C][K][K]
+        const size_t lds = (2 * psz + 2 * (size_t)Ho * Wo + 4 * K * K) * sizeof(float);
+        if (lds > 64 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_to_one: a %dx%d plane exceeds the LDS staging buffers", H, W);
+        if (K == 4) one_wrw_kernel<4><<<C, 256, lds, st>>>(x, other, out, B, C, H, W, Ho, Wo, pad);
+        else one_wrw_kernel<3><<<C, 256, lds, st>>>(x, other, out, B, C, H, W, Ho, Wo, pad);
+        return check_launch("one_wrw_kernel");
+    }
+    return fail(IPSR_ERR_INVALID, "ipsr_conv_to_one: op %d (0 forward, 2 weight gradient)", op);
 }
 
 }  // extern "C"

@@ -20,6 +20,8 @@ Three engines per (operation, geometry), chosen by `select()` from measurements 
   "direct"    csrc/conv_gemm.hip  one-launch implicit GEMM, NCHW in/out (every k3/k4, stride 1/2, dilated and transposed
                                   geometry of the nets, forward and backward-data): at parity with MIOpen (~100 TF), used
                                   where it measured >= 7 % faster
+  "one"       csrc/thin_conv.hip  Conv2d with ONE output channel, stride 1 (netD's last layer, 512 -> 1 on 31x31): forward and weight
+                                  gradient as one pass over the input
   "miopen"    torch               everything else
 Weight gradients: Winograd F(3x3,4x4) (csrc/winograd.hip) for the 3x3 stride-1 layers with >= 256 channels on 16x16..64x64
 maps (2.0-2.4x MIOpen), MIOpen otherwise (`select_wrw`).
@@ -110,6 +112,8 @@ def _select(mode, _nosm, op, B, Cin, H, W, Cout, k, stride, pad, dil):
     if mode == "auto" and _is_k4s1(k, stride, pad, dil) and op in (ops.CONV_FWD, ops.CONV_BWD_DATA) \
             and cred % 16 == 0 and min(Cin, Cout) >= 128 and 16 <= H <= 128:
         return "wino_dil"        # netD's 4x4 stride-1 convolution: the same F(3x3,4x4) pipeline on the image itself
+    if mode == "auto" and op == ops.CONV_FWD and Cout == 1 and Cin >= 64 and ops.conv_to_one_supported(B, Cin, H, W, k, stride, pad, dil):
+        return "one"             # netD's last layer (512 -> 1): a single pass over the input, 15 vs 80-143 us
     if mode == "auto" and _thin_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
         return "thin"            # 3/6-channel side at full resolution: one pass over the wide tensor on the vector ALUs
     if mode == "auto" and _smallmap_data_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
@@ -216,6 +220,8 @@ def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
 
 @functools.lru_cache(maxsize=4096)
 def _select_wrw(mode, _nosm, transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
+    if mode == "auto" and not transposed and Cout == 1 and Cin >= 64 and ops.conv_to_one_supported(B, Cin, H, W, k, stride, pad, dil):
+        return "one"
     if mode == "auto" and not transposed and _is_dilated4(k, stride, pad, dil) and min(Cin, Cout) >= 128 and 32 <= H <= 128 \
             and H % 2 == 0 and W % 2 == 0:
         return "wino_dil"
@@ -269,6 +275,8 @@ class _HipConv(torch.autograd.Function):
             y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=act)
         elif eng_fwd == "thin":
             y = ops.conv3x3_thin(op, xc, w, (B, Cin, H, W), Cout)
+        elif eng_fwd == "one":
+            y = ops.conv_to_one(xc, w, pad)
         elif eng_fwd == "smallmap":
             y = ops.conv_smallmap(_smallmap_op(op), xc, w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         elif eng_fwd == "wino_s2":
@@ -315,12 +323,14 @@ class _HipConv(torch.autograd.Function):
                 _check_hook("input_grad", eng, ctx.geom, (dy, x, w), dx)
         weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16) if ctx.needs_input_grad[1] else None
         # data parallel: write the weight gradient straight into its slice of the armed gradient bucket (dist.py)
-        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2", "smallmap") else None
+        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2", "smallmap", "one") else None
         xw = x if (x.dtype == dy.dtype or weng in (None, "miopen")) else x.to(dy.dtype)      # a weight gradient reads both operands in one dtype
         if weng == "winograd":
             dw = ops.conv3x3_winograd_wrw(transposed, xw, dy, Cout, out=sink, math=math)
         elif weng == "wino_dil":
             dw = ops.conv4x4_dilated_winograd(2, xw, dy, (B, Cin, H, W), Cout, out=sink, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math)
+        elif weng == "one":
+            dw = ops.conv_to_one_wrw(x, dy, k, pad, out=sink)
         elif weng == "smallmap":
             coarse, fine = (x, dy) if transposed else (dy, x)
             dw = ops.conv_smallmap(ops.SM_WRW, coarse, fine, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out=sink)
@@ -399,6 +409,8 @@ def conv_nobias(m, x, weight=None):
                                                 math=math, out_dtype=act)
         elif eng == "thin":
             return ops.conv3x3_thin(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout)
+        elif eng == "one":
+            return ops.conv_to_one(x.contiguous(), w.detach(), pad)
         elif eng == "smallmap":
             return ops.conv_smallmap(_smallmap_op(op), x.contiguous(), w.detach(), *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
         elif eng == "wino_s2":

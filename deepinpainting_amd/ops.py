@@ -540,6 +540,42 @@ def thin_supported(op, Cin, H, W, Cout):
     return o in (3, 6) and W % 4 == 0 and i * o * 36 <= 48 * 1024 and i >= 16
 
 
+def conv_to_one_supported(B, Cin, H, W, k, stride, pad, dil):
+    """nn.Conv2d(Cin, 1, k, 1, pad) as ipsr_conv_to_one takes it (csrc/thin_conv.hip): a workspace probe, no kernel is launched."""
+    if stride != 1 or dil != 1 or pad < 0 or k not in (3, 4):
+        return False
+    return _lib.lib().ipsr_conv_to_one_workspace_bytes(B, Cin, H, W, k, pad) > 0 and (2 * (H + 2 * pad) * (W + 2 * pad) + 2 * H * W + 64) * 4 <= 64 * 1024
+
+
+def conv_to_one(x, w, pad):
+    """y = conv2d(x, w, stride 1, padding pad) for w [1,C,K,K]: one pass over x (netD's last layer)."""
+    x = _req(x, torch.float32, "input")
+    w = _req(w, torch.float32, "weight")
+    B, C, H, W = x.shape
+    K = int(w.shape[-1])
+    if tuple(w.shape) != (1, C, K, K):
+        raise RuntimeError("conv_to_one: weight %s does not match %d input channels / one output" % (tuple(w.shape), C))
+    y = torch.empty((B, 1, H + 2 * pad - K + 1, W + 2 * pad - K + 1), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = _workspace(L.ipsr_conv_to_one_workspace_bytes(B, C, H, W, K, int(pad)), x.device)
+    _lib.check(L.ipsr_conv_to_one(0, x.data_ptr(), w.data_ptr(), y.data_ptr(), B, C, H, W, K, int(pad), ws.data_ptr(), ws.numel(), _stream()),
+               "ipsr_conv_to_one")
+    return y
+
+
+def conv_to_one_wrw(x, dy, K, pad, out=None):
+    """dW [1,C,K,K] of the same layer: one pass over x."""
+    x = _req(x, torch.float32, "input")
+    dy = _req(dy, torch.float32, "grad_output")
+    B, C, H, W = x.shape
+    if tuple(dy.shape) != (B, 1, H + 2 * pad - K + 1, W + 2 * pad - K + 1):
+        raise RuntimeError("conv_to_one_wrw: grad_output %s does not match input %s, k=%d, pad=%d" % (tuple(dy.shape), tuple(x.shape), K, pad))
+    dw = out if out is not None else torch.empty((1, C, K, K), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ipsr_conv_to_one(2, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, C, H, W, K, int(pad), None, 0, _stream()),
+               "ipsr_conv_to_one")
+    return dw
+
+
 def conv3x3_thin(op, inp, weight, in_shape, Cout, bias=None, relu=False, out=None):
     """k3 s1 p1 Conv2d / ConvTranspose2d forward or backward-data with a 3- or 6-channel side (ipsr_conv3x3_thin).  `in_shape` =
     the module's input (B, Cin, H, W); `inp` is x for the forward ops and dy for the backward-data ops; bias / ReLU only few -> many."""

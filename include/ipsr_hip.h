@@ -299,6 +299,16 @@ int ipsr_conv_smallmap(int op, const float* a, const float* b, float* out, int B
 int ipsr_conv3x3_thin(int op, const float* in, const float* w, const float* bias, int relu, float* out, int B, int I, int O, int H, int W,
                       long so, long si, int flip, void* stream);
 size_t ipsr_conv3x3_thin_wrw_workspace_bytes(int B, int Cb, int Cs, int H, int W);
+/* ipsr_conv_to_one: nn.Conv2d(C, 1, K, stride 1, padding pad) — netD's last layer (models/networks.py:489-495, 512 -> 1, k4 p1 on
+ * 31x31) — as one pass over the input (252 MFLOP against 31.5 MB: a stream).  x [B,C,H,W] fp32, K in {3, 4}.
+ *   op 0 forward:          other = w [1,C,K,K],    out = y [B,1,Ho,Wo],  Ho = H + 2 pad - K + 1
+ *   op 2 weight gradient:  other = dy [B,1,Ho,Wo], out = dw [1,C,K,K]
+ * Fixed summation orders (deterministic).  The input gradient (1 -> C) is left to the caller's library.  Planes of at most 256
+ * groups of 4 output pixels (Ho * ceil(Wo / 4) <= 256); ipsr_conv_to_one_workspace_bytes returns 0 for anything else.  The forward
+ * needs that workspace (per-chunk partial sums), the weight gradient none. */
+size_t ipsr_conv_to_one_workspace_bytes(int B, int C, int H, int W, int K, int pad);
+int ipsr_conv_to_one(int op, const float* x, const float* other, float* out, int B, int C, int H, int W, int K, int pad,
+                     void* ws, size_t ws_bytes, void* stream);
 int ipsr_conv3x3_thin_wrw(const float* big, const float* small, float* g, int B, int Cb, int Cs, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K9  InnerCos / InnerCos2 feature-consistency loss ----------------------------------------

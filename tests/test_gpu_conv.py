@@ -301,6 +301,41 @@ def test_thin_3x3_layers_vs_fp64(kind, Ci, Co, H, W, B):
 # ---- the training step's OWN shapes (BASELINE config 2: batch 8, 256x256) ------------------------------------------------------
 # (module, input H=W): the layers the step spends its time in, every Winograd family, all three passes.  References: the same
 # module in fp64 on the GPU (torch's native convolution) AND MIOpen fp32 on the same tensors.
+@pytest.mark.parametrize("B,C,H,W,K,pad", [(16, 512, 31, 31, 4, 1), (8, 512, 31, 31, 4, 1), (3, 70, 9, 11, 3, 1), (2, 64, 20, 47, 4, 1), (1, 64, 5, 5, 4, 0)])
+def test_conv_with_one_output_channel(B, C, H, W, K, pad):
+    """ipsr_conv_to_one (netD's last layer, nn.Conv2d(512, 1, 4, 1, 1) on 31x31): forward and weight gradient against fp64, within
+    fp32 summation noise (5e-6 of the result's scale), and through the module path (dispatcher -> "one", bias by the bias kernel)."""
+    from deepinpainting_amd import ops
+    from deepinpainting_amd.models import hipconv
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + C)
+    x = torch.randn(B, C, H, W, device="cuda", generator=g)
+    w = torch.randn(1, C, K, K, device="cuda", generator=g) * 0.05
+    y = ops.conv_to_one(x, w, pad)
+    yd = F.conv2d(x.double(), w.double(), None, 1, pad)
+    assert y.shape == yd.shape
+    assert float((y.double() - yd).abs().max()) <= 5e-6 * float(yd.abs().max())
+    dy = torch.randn(y.shape, device="cuda", generator=g)
+    dw = ops.conv_to_one_wrw(x, dy, K, pad)
+    dwd = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    assert float((dw.double() - dwd).abs().max()) <= 5e-6 * float(dwd.abs().max())
+    if C >= 64:
+        m = nn.Conv2d(C, 1, K, 1, pad).cuda()
+        xr = x.clone().requires_grad_(True)
+        hipconv._FORCE = "auto"
+        try:
+            assert hipconv.select(ops.CONV_FWD, B, C, H, W, 1, K, 1, pad, 1) == "one"
+            ym = hipconv.conv_nobias(m, xr)
+            gx, gw = torch.autograd.grad(ym, (xr, m.weight), dy)
+        finally:
+            hipconv._FORCE = None
+        xq = x.clone().requires_grad_(True)
+        yq = F.conv2d(xq, m.weight, None, 1, pad)
+        qx, qw = torch.autograd.grad(yq, (xq, m.weight), dy)
+        torch.testing.assert_close(ym, yq, rtol=1e-4, atol=1e-4 * float(yq.abs().max()))
+        torch.testing.assert_close(gw, qw, rtol=1e-4, atol=1e-4 * float(qw.abs().max()))
+        torch.testing.assert_close(gx, qx, rtol=1e-4, atol=1e-4 * float(qx.abs().max()))
+
+
 STEP_LAYERS = [
     ("k3_512_32",      lambda: nn.Conv2d(512, 512, 3, 1, 1), 32),                      # VGG conv4_x, netG downconv_3: tiles 16 -> head/tail cut
     ("k3T_1024_256_32", lambda: nn.ConvTranspose2d(1024, 256, 3, 1, 1), 32),           # netG upconv_3: tiles 8 -> head/tail cut
@@ -571,7 +606,7 @@ def test_dispatcher_rules_and_refusals():
     assert sel(ops.CONV_FWD, 8, 256, 32, 32, 512, 4, 1, 1, 1) == "wino_dil"              # netD's 4x4 stride-1 convolution
     assert sel(ops.CONV_BWD_DATA, 8, 256, 32, 32, 512, 4, 1, 1, 1) == "wino_dil"
     assert hipconv.select_wrw(False, 8, 256, 32, 32, 512, 4, 1, 1, 1) == "wino_dil"
-    assert sel(ops.CONV_FWD, 8, 512, 31, 31, 1, 4, 1, 1, 1) == "miopen"                  # its one-channel head
+    assert sel(ops.CONV_FWD, 8, 512, 31, 31, 1, 4, 1, 1, 1) == "one"                  # its one-channel head
     assert hipconv.select_wrw(False, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd"
     assert hipconv.select_wrw(False, 8, 128, 128, 128, 128, 3, 1, 1, 1) == "miopen"
     # 4x4 stride-2 pad-1: polyphase Winograd from 128 coarse / 64 fine channels up on coarse grids of 16..64
