@@ -353,6 +353,7 @@ STEP_LAYERS = [
     ("k3T_256_64_128", lambda: nn.ConvTranspose2d(256, 64, 3, 1, 1), 128),             # netG upconv_1: 64 produced channels -> the GEMM's 64-row tile
     ("k4d2_64_256",    lambda: nn.Conv2d(64, 64, 4, 2, 3, dilation=2), 256),           # netG outermost dilated down convolution (64-row tile)
     ("k4s2T_64_64_128", lambda: nn.ConvTranspose2d(64, 64, 4, 2, 1), 128),             # netG outermost up convolution: row-writing output transform
+    ("k4s1_512_1_31",  lambda: nn.Conv2d(512, 1, 4, 1, 1), 31),                        # netD's last layer ("one")
 ]
 
 
