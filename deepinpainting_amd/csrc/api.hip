@@ -132,7 +132,7 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 11; }
+int ipsr_abi_version(void) { return 12; }
 
 int ipsr_debug_set_option(int key, int value)
 {

@@ -17,3 +17,12 @@ for cfg in "2:1" "4:3"; do
 done
 python3 bench.py --steps 20 > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err
 python3 bench.py --steps 20 --dtype bf16 --batch 16 --no-cpu-baseline > gpurun_out/${R}_bench_bf16.json 2> gpurun_out/${R}_bench_bf16.err
+# HBM traffic of the layer's kernels (two PMC passes, no other tracing) -> ${R}_layer_cfg2_hbm_traffic.csv and profiles/traffic_corr_argmax.json
+for pass in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $pass -d gpurun_out/pmc_layer_$pass -o l --output-format csv -- python3 tools/profile_layer.py --cfg 2 --iters 3 > gpurun_out/pmc_layer_$pass.log 2>&1
+done
+FF=$(ls gpurun_out/pmc_layer_FETCH_SIZE/*counter_collection.csv gpurun_out/pmc_layer_FETCH_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)
+FW=$(ls gpurun_out/pmc_layer_WRITE_SIZE/*counter_collection.csv gpurun_out/pmc_layer_WRITE_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)
+python3 tools/collect_traffic.py $FF $FW > gpurun_out/${R}_layer_cfg2_hbm_traffic.csv && cp profiles/traffic_corr_argmax.json gpurun_out/${R}_traffic_corr_argmax.json
+rm -rf gpurun_out/pmc_layer_FETCH_SIZE gpurun_out/pmc_layer_WRITE_SIZE
+python3 tools/engine_map.py > gpurun_out/${R}_engine_map.txt 2> gpurun_out/${R}_engine_map.err
