@@ -132,7 +132,7 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 12; }
+int ipsr_abi_version(void) { return 13; }
 
 int ipsr_debug_set_option(int key, int value)
 {
@@ -434,7 +434,7 @@ int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, 
 
 int ipsr_cat_relu_forward(const void* y, const void* x, int B, int C1, int C2, int HW, int io_bf16, void* out, void* stream)
 {
-    if (!y || !x || !out) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_forward: null pointer");
+    if (!x || !out) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_forward: null pointer");
     if (B < 1 || C1 < 1 || C2 < 1 || HW < 1) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_forward: bad size");
     if ((HW & 3) == 0 && (!aligned_io(y, io_bf16) || !aligned_io(x, io_bf16) || !aligned_io(out, io_bf16)))
         return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_forward: tensors are not vector aligned");
@@ -443,7 +443,7 @@ int ipsr_cat_relu_forward(const void* y, const void* x, int B, int C1, int C2, i
 
 int ipsr_cat_relu_backward(const void* grad_out, const void* out, int B, int C1, int C2, int HW, int io_bf16, void* dy, void* dx, void* stream)
 {
-    if (!grad_out || !out || !dy || !dx) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_backward: null pointer");
+    if (!grad_out || !out || !dx) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_backward: null pointer");
     if (B < 1 || C1 < 1 || C2 < 1 || HW < 1) return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_backward: bad size");
     if ((HW & 3) == 0 && (!aligned_io(grad_out, io_bf16) || !aligned_io(out, io_bf16) || !aligned_io(dy, io_bf16) || !aligned_io(dx, io_bf16)))
         return fail(IPSR_ERR_INVALID, "ipsr_cat_relu_backward: tensors are not vector aligned");
@@ -456,7 +456,18 @@ int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gam
     if (!x || !y || !mean || !rstd) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: null pointer");
     if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: bad argument B=%d C=%d HW=%d act=%d", B, C, HW, act);
     if ((HW & 3) == 0 && (!aligned_io(x, io_bf16) || !aligned_io(y, io_bf16))) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: x/y are not vector aligned");
-    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, io_bf16, y, mean, rstd, static_cast<hipStream_t>(stream));
+    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, io_bf16, y, mean, rstd, 0, static_cast<hipStream_t>(stream));
+}
+
+int ipsr_instnorm_act_forward_slice(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
+                                    int B, int C, int HW, int io_bf16, void* y, size_t y_batch_stride, float* mean, float* rstd, void* stream)
+{
+    if (!x || !y || !mean || !rstd) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward_slice: null pointer");
+    if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2 || y_batch_stride < (size_t)C * HW)
+        return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward_slice: bad argument B=%d C=%d HW=%d act=%d stride=%zu", B, C, HW, act, y_batch_stride);
+    if ((HW & 3) == 0 && (!aligned_io(x, io_bf16) || !aligned_io(y, io_bf16) || (y_batch_stride & 3)))
+        return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward_slice: x/y are not vector aligned");
+    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, io_bf16, y, mean, rstd, y_batch_stride, static_cast<hipStream_t>(stream));
 }
 
 int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, const float* bias, const float* gamma,
@@ -467,8 +478,22 @@ int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, con
     if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: bad argument");
     if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(x, io_bf16) || !aligned_io(dx, io_bf16)))
         return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: tensors are not vector aligned");
-    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p, sums,
+    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p, sums, 0, 0,
                                    static_cast<hipStream_t>(stream));
+}
+
+int ipsr_instnorm_act_backward_slice(const void* dy, size_t dy_batch_stride, const void* y, size_t y_batch_stride, const void* x, const float* bias,
+                                     const float* gamma, const float* mean, const float* rstd, int act, float slope, int B, int C, int HW,
+                                     int io_bf16, void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream)
+{
+    if (!dy || !y || !x || !mean || !rstd || !dx) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward_slice: null pointer");
+    if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2 || dy_batch_stride < (size_t)C * HW || y_batch_stride < (size_t)C * HW)
+        return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward_slice: bad argument");
+    if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(x, io_bf16) || !aligned_io(dx, io_bf16) ||
+                          ((dy_batch_stride | y_batch_stride) & 3)))
+        return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward_slice: tensors are not vector aligned");
+    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p, sums,
+                                   dy_batch_stride, y_batch_stride, static_cast<hipStream_t>(stream));
 }
 
 int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx,

@@ -88,13 +88,14 @@ template <typename IO, int T, int NE, bool VEC>
 __global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const IO* __restrict__ x, const float* __restrict__ bias,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, int act, float slope, int C, int HW,
-                                                             IO* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out)
+                                                             IO* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             size_t y_bstride)
 {
     __shared__ float red[16];
     const int plane = blockIdx.x, c = plane % C, tid = threadIdx.x;
     const float bv = bias ? bias[c] : 0.0f;
     const IO* xp = x + (size_t)plane * HW;
-    IO* yp = y + (size_t)plane * HW;
+    IO* yp = y + (size_t)(plane / C) * y_bstride + (size_t)c * HW;      // y may be a channel slice of a wider tensor (skip concatenation)
     float v[NE];
     float sum = 0.0f;
     if (VEC) {
@@ -171,7 +172,8 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
                                                              const float* __restrict__ rstd_in, int act, float slope, int C, int HW,
                                                              IO* __restrict__ dx, float* __restrict__ dgamma_p,
                                                              float* __restrict__ dbeta_p, float* __restrict__ dbias_p,
-                                                             float* __restrict__ sums, unsigned* __restrict__ ticket)
+                                                             float* __restrict__ sums, unsigned* __restrict__ ticket,
+                                                             size_t dy_bstride, size_t y_bstride)
 {
     static_assert(!REX || VEC, "the re-reading variant exists for vector-aligned planes only");
     __shared__ float red[16];
@@ -180,6 +182,9 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
     const float bv = bias ? bias[c] : 0.0f;
     const float mean = mean_in[plane], rstd = rstd_in[plane];
     const size_t off = (size_t)plane * HW;
+    // dy and y may be channel slices of wider tensors (the gradient / the output of a skip concatenation); x and dx are dense
+    dy += (size_t)(plane / C) * dy_bstride + (size_t)c * HW - off;
+    y += (size_t)(plane / C) * y_bstride + (size_t)c * HW - off;
     float dz[NE], xh[REX ? 4 : NE];
     float s1 = 0.0f, s2 = 0.0f;
     if (VEC) {
@@ -329,33 +334,36 @@ constexpr int IN_MAX_HW_REG = 16384;   // largest plane a 256-thread workgroup h
     } while (0)
 
 int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
-                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, hipStream_t st)
+                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, size_t ybs, hipStream_t st)
 {
+    if (ybs == 0) ybs = (size_t)C * HW;
     if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: plane of %d elements > %d", HW, IN_MAX_HW);
     const int planes = B * C;
     if (HW > IN_MAX_HW_REG) {
         if (HW & 3) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: a plane of %d elements (> %d) must be a multiple of 4", HW, IN_MAX_HW_REG);
         if (io_bf16)
             instnorm_act_fwd_kernel<bf16_t, 512, 128, true><<<planes, 512, 0, st>>>(static_cast<const bf16_t*>(x), bias, gamma, beta, eps, act, slope,
-                                                                                   C, HW, static_cast<bf16_t*>(y), mean, rstd);
+                                                                                   C, HW, static_cast<bf16_t*>(y), mean, rstd, ybs);
         else
             instnorm_act_fwd_kernel<float, 512, 128, true><<<planes, 512, 0, st>>>(static_cast<const float*>(x), bias, gamma, beta, eps, act, slope,
-                                                                                  C, HW, static_cast<float*>(y), mean, rstd);
+                                                                                  C, HW, static_cast<float*>(y), mean, rstd, ybs);
         return check_launch("instnorm_act_fwd_kernel");
     }
     if (io_bf16)
         IN_DISPATCH(instnorm_act_fwd_kernel, bf16_t, static_cast<const bf16_t*>(x), bias, gamma, beta, eps, act, slope, C, HW,
-                    static_cast<bf16_t*>(y), mean, rstd);
+                    static_cast<bf16_t*>(y), mean, rstd, ybs);
     else
         IN_DISPATCH(instnorm_act_fwd_kernel, float, static_cast<const float*>(x), bias, gamma, beta, eps, act, slope, C, HW,
-                    static_cast<float*>(y), mean, rstd);
+                    static_cast<float*>(y), mean, rstd, ybs);
     return check_launch("instnorm_act_fwd_kernel");
 }
 
 int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const float* bias, const float* gamma, const float* mean,
                             const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dgamma_p,
-                            float* dbeta_p, float* dbias_p, float* sums, hipStream_t st)
+                            float* dbeta_p, float* dbias_p, float* sums, size_t dybs, size_t ybs, hipStream_t st)
 {
+    if (dybs == 0) dybs = (size_t)C * HW;
+    if (ybs == 0) ybs = (size_t)C * HW;
     if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: plane of %d elements > %d", HW, IN_MAX_HW);
     if (sums && C > TICKET_MAXC) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: batch sums for %d channels > %d", C, TICKET_MAXC);
     unsigned* ticket = next_ticket_row(sums);
@@ -366,19 +374,19 @@ int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const 
         if (io_bf16)
             instnorm_act_bwd_kernel<bf16_t, 512, 128, true, true><<<planes, 512, 0, st>>>(
                 static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW,
-                static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket);
+                static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs);
         else
             instnorm_act_bwd_kernel<float, 512, 128, true, true><<<planes, 512, 0, st>>>(
                 static_cast<const float*>(dy), static_cast<const float*>(y), static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW,
-                static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket);
+                static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs);
         return check_launch("instnorm_act_bwd_kernel");
     }
     if (io_bf16)
         IN_DISPATCH(instnorm_act_bwd_kernel, bf16_t, static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y),
-                    static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket);
+                    static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs);
     else
         IN_DISPATCH(instnorm_act_bwd_kernel, float, static_cast<const float*>(dy), static_cast<const float*>(y),
-                    static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket);
+                    static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs);
     return check_launch("instnorm_act_bwd_kernel");
 }
 

@@ -93,13 +93,13 @@ __global__ void __launch_bounds__(256) cat_relu_fwd_kernel(const IO* __restrict_
     IO* ob = out + (size_t)b * n;
     if ((HW & 3) == 0) {
         const size_t n4 = n >> 2, n14 = n1 >> 2;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        for (size_t i = (y ? 0 : n14) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {      // y == NULL: its half is already there
             float4 v = i < n14 ? ld4(yb, i) : ld4(xb, i - n14);
             v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
             st4(ob, i, v);
         }
     } else {
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        for (size_t i = (y ? 0 : n1) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
             st1(ob, i, relu_nan(i < n1 ? ld1(yb, i) : ld1(xb, i - n1)));
     }
 }
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) cat_relu_bwd_kernel(const IO* __restrict_
     IO* dxb = dx + (size_t)b * n2;
     if ((HW & 3) == 0) {
         const size_t n4 = n >> 2, n14 = n1 >> 2;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        for (size_t i = (dy ? 0 : n14) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {     // dy == NULL: only the skip half is wanted
             const float4 gv = ld4(gb, i), ov = ld4(ob, i);
             float4 r;
             r.x = ov.x > 0.0f ? gv.x : 0.0f; r.y = ov.y > 0.0f ? gv.y : 0.0f;
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) cat_relu_bwd_kernel(const IO* __restrict_
             if (i < n14) st4(dyb, i, r); else st4(dxb, i - n14, r);
         }
     } else {
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        for (size_t i = (dy ? 0 : n1) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
             const float r = ld1(ob, i) > 0.0f ? ld1(gb, i) : 0.0f;
             if (i < n1) st1(dyb, i, r); else st1(dxb, i - n1, r);
         }

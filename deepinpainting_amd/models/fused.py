@@ -77,6 +77,33 @@ class _CatReLU(torch.autograd.Function):
         return ops.cat_relu_backward(g, out, ctx.c1)
 
 
+class _InstNormReLUCat(torch.autograd.Function):
+    """relu(cat([InstanceNorm(y + bias) * gamma + beta, x], 1)) — a level's last norm, its skip concatenation and the parent's in-place
+    ReLU as ONE node: the norm kernel writes its half straight into the concatenated tensor (and its backward reads the gradient's
+    slice in place); only the skip half is left to the concatenation kernels."""
+
+    @staticmethod
+    def forward(ctx, y, bias, gamma, beta, eps, x):
+        B, C1, C2 = y.shape[0], y.shape[1], x.shape[1]
+        out = torch.empty((B, C1 + C2) + tuple(y.shape[2:]), dtype=y.dtype, device=y.device)
+        _, mean, rstd = ops.instnorm_act_forward(y, bias, gamma, beta, eps, "relu", 0.0, into=out)
+        ops.cat_relu_skip_half_(out, x)
+        ctx.save_for_backward(y, bias, gamma, out, mean, rstd)
+        ctx.c1 = C1
+        ctx.has_affine = gamma is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, bias, gamma, out, mean, rstd = ctx.saved_tensors
+        need_bias = bias is not None and ctx.needs_input_grad[1]
+        need_affine = ctx.has_affine and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        g = g.contiguous()
+        dyn, dg, db, dbias = ops.instnorm_act_backward(g, out, y, bias, gamma, mean, rstd, "relu", 0.0, need_affine, need_bias)
+        _, dx = ops.cat_relu_backward(g, out, ctx.c1, skip_half_only=True)
+        return dyn, dbias, dg, db, None, dx
+
+
 def cat_skip(y, x, tail_relu):
     """torch.cat([y, x], 1), with the consumer's in-place ReLU folded in when it asked for that."""
     if tail_relu and y.is_cuda and y.dtype == x.dtype and y.dtype in (torch.float32, torch.bfloat16) \
@@ -125,7 +152,15 @@ class FusedSequential(nn.Sequential):
         """True when mods[j] is the in-place ReLU a skip level's concatenated output runs into (models/networks.py:229,408)."""
         return j < len(mods) and type(mods[j]) is nn.ReLU and mods[j].inplace
 
-    def forward(self, x, head_act_done=False):
+    def forward(self, x, head_act_done=False, cat_with=None):
+        """cat_with: the level's input, when the caller (networks._cat_skip) wants relu(cat([this(x), cat_with], 1)) and this sequence
+        may produce it itself if it ends in a norm; the return value is then (tensor, concatenated?)."""
+        out = self._forward(x, head_act_done, cat_with)
+        if cat_with is None:
+            return out[0]
+        return out
+
+    def _forward(self, x, head_act_done, cat_with):
         usable = FusedSequential.enabled and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
         mods = list(self)
         n = len(mods)
@@ -136,7 +171,7 @@ class FusedSequential(nn.Sequential):
         if not usable:
             for m in mods[i:]:
                 x = m(x)
-            return x
+            return x, False
         while i < n:
             m = mods[i]
             conv = _plain_conv(m)
@@ -186,6 +221,10 @@ class FusedSequential(nn.Sequential):
                     i = j
                     continue
                 nxt = mods[j] if j < n else None
+                if nxt is None and cat_with is not None and cat_with.is_contiguous() and cat_with.dtype == y.dtype \
+                        and cat_with.shape[0] == y.shape[0] and cat_with.shape[2:] == y.shape[2:]:
+                    # the level ends here: norm + skip concatenation + the parent's ReLU in one node
+                    return _InstNormReLUCat.apply(y, bias, norm.weight, norm.bias, norm.eps, cat_with), True
                 act = _act_of(nxt) if nxt is not None else None
                 child_act = self._head_act_of_child(nxt) if (nxt is not None and act is None) else None
                 a = act or child_act or ("none", 0.0)
@@ -201,4 +240,4 @@ class FusedSequential(nn.Sequential):
                 continue
             x = m(x)
             i += 1
-        return x
+        return x, False

@@ -171,7 +171,12 @@ def _cat_skip(block, x, head_act_done=False, tail_relu=False):
     if block.outermost:
         y = block.model(x, head_act_done=head_act_done)
         return torch.relu_(y) if tail_relu else y
-    y = block.model(x, head_act_done=head_act_done)
+    if tail_relu and isinstance(block.model, FusedSequential):
+        y, done = block.model(x, head_act_done=head_act_done, cat_with=x)     # a level that ends in a norm concatenates by itself
+        if done:
+            return y
+    else:
+        y = block.model(x, head_act_done=head_act_done)
     h, w = x.size(2), x.size(3)
     if h != y.size(2) or w != y.size(3):
         y = F.interpolate(y, (h, w), mode='bilinear')

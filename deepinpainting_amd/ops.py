@@ -253,14 +253,24 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def instnorm_act_forward(x, bias, gamma, beta, eps, act, slope):
-    """y = act(InstanceNorm(x + bias[c]) * gamma[c] + beta[c]) -> (y, mean [B*C], rstd [B*C]); x contiguous fp32 [B,C,H,W]."""
+def instnorm_act_forward(x, bias, gamma, beta, eps, act, slope, into=None):
+    """y = act(InstanceNorm(x + bias[c]) * gamma[c] + beta[c]) -> (y, mean [B*C], rstd [B*C]); x contiguous fp32 / bf16 [B,C,H,W].
+    into: a contiguous [B,Ctot,H,W] tensor (Ctot > C) whose FIRST C channels receive y (the skip concatenation is written in
+    place); the returned y is then `into` itself."""
     x, bf = _req_io(x, "x")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
-    y = torch.empty_like(x)
     mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    if into is not None:
+        if into.dtype != x.dtype or not into.is_contiguous() or into.dim() != 4 or into.shape[0] != B or into.shape[1] <= C \
+                or tuple(into.shape[2:]) != tuple(x.shape[2:]) or into.device != x.device:
+            raise RuntimeError("instnorm_act_forward: `into` %s does not extend %s along the channels" % (tuple(into.shape), tuple(x.shape)))
+        _lib.check(_lib.lib().ipsr_instnorm_act_forward_slice(x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps),
+                                                              ACT_CODE[act], float(slope), B, C, hw, bf, into.data_ptr(), into.shape[1] * hw,
+                                                              mean.data_ptr(), rstd.data_ptr(), _stream()), "ipsr_instnorm_act_forward_slice")
+        return into, mean, rstd
+    y = torch.empty_like(x)
     _lib.check(_lib.lib().ipsr_instnorm_act_forward(x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps),
                                                     ACT_CODE[act], float(slope), B, C, hw, bf, y.data_ptr(), mean.data_ptr(),
                                                     rstd.data_ptr(), _stream()), "ipsr_instnorm_act_forward")
@@ -271,18 +281,31 @@ SUMS_MAX_CHANNELS = 2048       # csrc/instnorm.hip TICKET_MAXC: widest layer who
 
 
 def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_affine, need_bias):
-    """-> (dx, dgamma [C] | None, dbeta [C] | None, dbias [C] | None)."""
-    dy, bf = _req_io(dy.to(x.dtype), "grad_output")
+    """-> (dx, dgamma [C] | None, dbeta [C] | None, dbias [C] | None).  dy and y may be WIDER than x along the channels (both the
+    same [B,Ctot,H,W], contiguous): their first C channels are the operands (skip concatenation and its gradient, read in place)."""
+    x, bf = _req_io(x, "x")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
+    dy, _ = _req_io(dy.to(x.dtype), "grad_output")
+    if dy.shape[1] != y.shape[1] or dy.shape[1] < C:
+        raise RuntimeError("instnorm_act_backward: grad_output %s / output %s do not match input %s" % (tuple(dy.shape), tuple(y.shape), tuple(x.shape)))
     dx = torch.empty_like(x)
     part = torch.empty((3, B, C), dtype=torch.float32, device=x.device)
     # the batch sums of the per-plane partials are written by the same launch (the last plane of each channel to finish)
     sums = torch.empty((3, C), dtype=torch.float32, device=x.device) if C <= SUMS_MAX_CHANNELS else None
-    _lib.check(_lib.lib().ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)),
-                                                     mean.data_ptr(), rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
-                                                     dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
-                                                     _ptr(sums), _stream()), "ipsr_instnorm_act_backward")
+    L = _lib.lib()
+    if dy.shape[1] == C:
+        _lib.check(L.ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)),
+                                                mean.data_ptr(), rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
+                                                dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
+                                                _ptr(sums), _stream()), "ipsr_instnorm_act_backward")
+    else:
+        if not y.is_contiguous():
+            raise RuntimeError("instnorm_act_backward: the wide output must be contiguous")
+        _lib.check(L.ipsr_instnorm_act_backward_slice(dy.data_ptr(), dy.shape[1] * hw, y.data_ptr(), y.shape[1] * hw, x.data_ptr(), _ptr(_f32(bias)),
+                                                      _ptr(_f32(gamma)), mean.data_ptr(), rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
+                                                      dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
+                                                      _ptr(sums), _stream()), "ipsr_instnorm_act_backward_slice")
     s = sums if sums is not None else part.sum(1)
     return dx, (s[0] if need_affine else None), (s[1] if need_affine else None), (s[2] if need_bias else None)
 
@@ -313,14 +336,30 @@ def cat_relu_forward(y, x):
     return out
 
 
-def cat_relu_backward(grad_out, out, C1):
+def cat_relu_skip_half_(out, x):
+    """out[:, C1:] = relu(x) for a contiguous out [B,C1+C2,H,W] whose first C1 channels are already written (instnorm_act_forward
+    with `into`): the skip half of relu(torch.cat([y, x], 1))."""
+    x, bf = _req_io(x, "x")
+    out, bf2 = _req_io(out, "out")
+    B, C2 = x.shape[0], x.shape[1]
+    C1 = out.shape[1] - C2
+    if bf != bf2 or out.shape[0] != B or C1 < 1 or out.shape[2:] != x.shape[2:]:
+        raise RuntimeError("cat_relu_skip_half_: mismatched operands %s / %s" % (tuple(out.shape), tuple(x.shape)))
+    hw = x.numel() // (B * C2)
+    _lib.check(_lib.lib().ipsr_cat_relu_forward(None, x.data_ptr(), B, C1, C2, hw, bf, out.data_ptr(), _stream()), "ipsr_cat_relu_forward")
+    return out
+
+
+def cat_relu_backward(grad_out, out, C1, skip_half_only=False):
+    """-> (dy [B,C1,..] | None, dx [B,C2,..]): the ReLU mask from `out`, the channel slices as contiguous tensors; skip_half_only: dy is
+    not produced (its consumer reads grad_out's slice in place)."""
     g, bf = _req_io(grad_out.to(out.dtype), "grad_output")
     B, C = out.shape[0], out.shape[1]
     C2 = C - C1
     hw = out.numel() // (B * C)
-    dy = torch.empty((B, C1) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)
+    dy = None if skip_half_only else torch.empty((B, C1) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)
     dx = torch.empty((B, C2) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)
-    _lib.check(_lib.lib().ipsr_cat_relu_backward(g.data_ptr(), out.data_ptr(), B, C1, C2, hw, bf, dy.data_ptr(), dx.data_ptr(), _stream()),
+    _lib.check(_lib.lib().ipsr_cat_relu_backward(g.data_ptr(), out.data_ptr(), B, C1, C2, hw, bf, _ptr(dy), dx.data_ptr(), _stream()),
                "ipsr_cat_relu_backward")
     return dy, dx
 

@@ -168,7 +168,9 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
  * io_bf16 (here and in the norm entry points below): 0 = the activation tensors are fp32, 1 = bf16 (BASELINE config 5:
  * convolutions under bf16 autocast); bias/gamma/beta, statistics and all arithmetic are fp32 either way. */
 /* skip connection: torch.cat([y, x], 1) + the parent level's in-place ReLU (models/networks.py:270-278 with the `uprelu`
- * of :229 / :408) in one pass, and its backward (ReLU mask from `out`, the two channel slices as contiguous tensors). */
+ * of :229 / :408) in one pass, and its backward (ReLU mask from `out`, the two channel slices as contiguous tensors).
+ * y == NULL (forward) / dy == NULL (backward): only the x half is processed — the y half of `out` was written in place by
+ * ipsr_instnorm_act_forward_slice, and its gradient is read in place by ipsr_instnorm_act_backward_slice. */
 int ipsr_cat_relu_forward(const void* y, const void* x, int B, int C1, int C2, int HW, int io_bf16, void* out, void* stream);
 int ipsr_cat_relu_backward(const void* grad_out, const void* out, int B, int C1, int C2, int HW, int io_bf16,
                            void* dy, void* dx, void* stream);
@@ -193,6 +195,17 @@ int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gam
 int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, const float* bias, const float* gamma,
                                const float* mean, const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16,
                                void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream);
+/* The `_slice` forms: y (forward) / dy and y (backward) are the first C channels of wider tensors — the output of a skip
+ * concatenation torch.cat([y, x], 1) (models/networks.py:270-278) and its gradient — given by their batch strides in elements
+ * (>= C*HW); x, dx and the statistics stay dense.  With them the normalisation writes straight into the concatenated tensor and
+ * its backward reads the gradient's slice in place: the concatenation kernel only has the skip half left to copy. */
+int ipsr_instnorm_act_forward_slice(const void* x, const float* bias, const float* gamma, const float* beta, float eps,
+                                    int act, float slope, int B, int C, int HW, int io_bf16,
+                                    void* y, size_t y_batch_stride, float* mean, float* rstd, void* stream);
+int ipsr_instnorm_act_backward_slice(const void* dy, size_t dy_batch_stride, const void* y, size_t y_batch_stride, const void* x,
+                                     const float* bias, const float* gamma, const float* mean, const float* rstd, int act, float slope,
+                                     int B, int C, int HW, int io_bf16,
+                                     void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream);
 int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16,
                            void* dx, float* dbias_p, float* sums, void* stream);
 

@@ -971,6 +971,45 @@ def test_fused_backward_batch_sums_come_from_the_same_launch(shape):
         assert torch.equal(sb, ordered(pb))
 
 
+@pytest.mark.parametrize("shape,c2", [((8, 64, 128, 128), 64), ((2, 5, 7, 9), 3), ((2, 32, 256, 256), 16), ((4, 512, 4, 4), 512)])
+def test_fused_norm_relu_cat_node_vs_torch(shape, c2):
+    """relu(cat([instance_norm(y + bias) * gamma + beta, x], 1)) as one autograd node (the norm kernel writes its half of the
+    concatenated tensor in place, its backward reads the gradient's slice in place) against the plain torch graph."""
+    from deepinpainting_amd.models.fused import _InstNormReLUCat
+    g = torch.Generator(device="cuda").manual_seed(17)
+    B, C1 = shape[0], shape[1]
+    y = (torch.randn(shape, device="cuda", generator=g) * 2 + 0.5).requires_grad_(True)
+    x = torch.randn((B, c2) + shape[2:], device="cuda", generator=g).requires_grad_(True)
+    bias = torch.randn(C1, device="cuda", generator=g).requires_grad_(True)
+    gamma = (torch.rand(C1, device="cuda", generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(C1, device="cuda", generator=g).requires_grad_(True)
+    go = torch.randn((B, C1 + c2) + shape[2:], device="cuda", generator=g)
+    leaves = (y, x, bias, gamma, beta)
+    pre = torch.nn.functional.instance_norm(y + bias.view(1, -1, 1, 1), None, None, gamma, beta, True, 0.1, 1e-5)
+    ref = torch.relu(torch.cat([pre, x], 1))
+    g_ref = torch.autograd.grad(ref, leaves, go)
+    # an element whose normalised value is within rounding of 0 may sit on either side of the ReLU kink in the two evaluations: its own
+    # gradient then differs by the whole incoming value (and the plane's by 1/HW of it) — such elements are compared through the plane only
+    near = (pre.detach().abs() < 1e-5)
+    out = _InstNormReLUCat.apply(y, bias, gamma, beta, 1e-5, x)
+    g_hip = torch.autograd.grad(out, leaves, go)
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
+    assert torch.equal(out[:, C1:], torch.relu(x)) and torch.equal(g_hip[1], g_ref[1])          # the skip half is exact
+    for leaf, a, b in zip(leaves, g_hip, g_ref):
+        scale = max(1.0, float(b.abs().max()))
+        if leaf is bias:
+            scale = max(scale, float(g_ref[0].abs().sum(dim=(0, 2, 3)).max()))
+            assert float((a - b).abs().max()) <= 2e-6 * scale
+            continue
+        d = (a - b).abs()
+        tol = (5e-5 if not bool(near.any()) else 5e-4) * scale
+        if leaf is y:
+            d = d.masked_fill(near, 0.0)
+        elif leaf is gamma or leaf is beta:              # a flipped element moves its channel's sum by up to |grad| * |x_hat|
+            tol = tol + float(near.sum(dim=(0, 2, 3)).max()) * float(go.abs().max()) * 4.0
+        assert float(d.max()) <= tol, (a.shape, float(d.max()), scale, int(near.sum()))
+
+
 def test_fused_bias_act_autograd_vs_torch():
     from deepinpainting_amd.models.fused import _BiasAct
     g = torch.Generator(device="cuda").manual_seed(8)
