@@ -50,8 +50,8 @@ SIGNATURES = {
     "ipsr_instnorm_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                            c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ipsr_instnorm_act_forward_slice": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_int, c_int, c_int, c_int,
-                                                c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
-    "ipsr_instnorm_act_backward_slice": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                                c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "ipsr_instnorm_act_backward_slice": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ipsr_bias_act_backward": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),

@@ -89,13 +89,15 @@ __global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const IO* __restric
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, int act, float slope, int C, int HW,
                                                              IO* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                             size_t y_bstride)
+                                                             size_t y_bstride, IO* __restrict__ y2, size_t y2_bstride)
 {
     __shared__ float red[16];
     const int plane = blockIdx.x, c = plane % C, tid = threadIdx.x;
     const float bv = bias ? bias[c] : 0.0f;
     const IO* xp = x + (size_t)plane * HW;
     IO* yp = y + (size_t)(plane / C) * y_bstride + (size_t)c * HW;      // y may be a channel slice of a wider tensor (skip concatenation)
+    // y2 (optional): relu of the same normalised value, written into the skip half of the child level's concatenated tensor
+    IO* y2p = y2 ? y2 + (size_t)(plane / C) * y2_bstride + (size_t)c * HW : nullptr;
     float v[NE];
     float sum = 0.0f;
     if (VEC) {
@@ -144,19 +146,24 @@ __global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const IO* __restric
         for (int k = 0; k < NE / 4; ++k) {
             const int i = k * T + tid;
             if (i < n4) {
-                float4 o;
-                o.x = act_fwd((v[4 * k] - mean) * g + bt, act, slope);
-                o.y = act_fwd((v[4 * k + 1] - mean) * g + bt, act, slope);
-                o.z = act_fwd((v[4 * k + 2] - mean) * g + bt, act, slope);
-                o.w = act_fwd((v[4 * k + 3] - mean) * g + bt, act, slope);
+                float4 n, o;
+                n.x = (v[4 * k] - mean) * g + bt; n.y = (v[4 * k + 1] - mean) * g + bt;
+                n.z = (v[4 * k + 2] - mean) * g + bt; n.w = (v[4 * k + 3] - mean) * g + bt;
+                o.x = act_fwd(n.x, act, slope); o.y = act_fwd(n.y, act, slope);
+                o.z = act_fwd(n.z, act, slope); o.w = act_fwd(n.w, act, slope);
                 st4(yp, i, o);
+                if (y2p) st4(y2p, i, make_float4(act_fwd(n.x, 1, 0.f), act_fwd(n.y, 1, 0.f), act_fwd(n.z, 1, 0.f), act_fwd(n.w, 1, 0.f)));
             }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const int i = k * T + tid;
-            if (i < HW) st1(yp, i, act_fwd((v[k] - mean) * g + bt, act, slope));
+            if (i < HW) {
+                const float nv = (v[k] - mean) * g + bt;
+                st1(yp, i, act_fwd(nv, act, slope));
+                if (y2p) st1(y2p, i, act_fwd(nv, 1, 0.f));
+            }
         }
     }
     if (tid == 0) { mean_out[plane] = mean; rstd_out[plane] = rstd; }
@@ -173,7 +180,7 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
                                                              IO* __restrict__ dx, float* __restrict__ dgamma_p,
                                                              float* __restrict__ dbeta_p, float* __restrict__ dbias_p,
                                                              float* __restrict__ sums, unsigned* __restrict__ ticket,
-                                                             size_t dy_bstride, size_t y_bstride)
+                                                             size_t dy_bstride, size_t y_bstride, const IO* __restrict__ dy2, size_t dy2_bstride)
 {
     static_assert(!REX || VEC, "the re-reading variant exists for vector-aligned planes only");
     __shared__ float red[16];
@@ -185,6 +192,9 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
     // dy and y may be channel slices of wider tensors (the gradient / the output of a skip concatenation); x and dx are dense
     dy += (size_t)(plane / C) * dy_bstride + (size_t)c * HW - off;
     y += (size_t)(plane / C) * y_bstride + (size_t)c * HW - off;
+    // dy2 (optional): the gradient of the relu'd copy that went into the child level's concatenated tensor (forward's y2): the two
+    // consumers of this norm's value meet here instead of in an add kernel; relu'(y2) has the sign of y whatever `act` is
+    if (dy2) dy2 += (size_t)(plane / C) * dy2_bstride + (size_t)c * HW - off;
     float dz[NE], xh[REX ? 4 : NE];
     float s1 = 0.0f, s2 = 0.0f;
     if (VEC) {
@@ -199,6 +209,11 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
                 const float4 xv = ld4(x + off, i);
                 a.x = d.x * act_bwd(o.x, act, slope); a.y = d.y * act_bwd(o.y, act, slope);
                 a.z = d.z * act_bwd(o.z, act, slope); a.w = d.w * act_bwd(o.w, act, slope);
+                if (dy2) {
+                    const float4 e2 = ld4(dy2 + off, i);
+                    a.x += e2.x * act_bwd(o.x, 1, 0.f); a.y += e2.y * act_bwd(o.y, 1, 0.f);
+                    a.z += e2.z * act_bwd(o.z, 1, 0.f); a.w += e2.w * act_bwd(o.w, 1, 0.f);
+                }
                 h.x = ((xv.x + bv) - mean) * rstd; h.y = ((xv.y + bv) - mean) * rstd;
                 h.z = ((xv.z + bv) - mean) * rstd; h.w = ((xv.w + bv) - mean) * rstd;
                 s1 += (a.x + a.y) + (a.z + a.w);
@@ -215,6 +230,7 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
             dz[k] = 0.0f; xh[k] = 0.0f;
             if (i < HW) {
                 dz[k] = ld1(dy, off + i) * act_bwd(ld1(y, off + i), act, slope);
+                if (dy2) dz[k] += ld1(dy2, off + i) * act_bwd(ld1(y, off + i), 1, 0.f);
                 xh[k] = ((ld1(x, off + i) + bv) - mean) * rstd;
                 s1 += dz[k];
                 s2 = __builtin_fmaf(dz[k], xh[k], s2);
@@ -334,7 +350,7 @@ constexpr int IN_MAX_HW_REG = 16384;   // largest plane a 256-thread workgroup h
     } while (0)
 
 int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
-                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, size_t ybs, hipStream_t st)
+                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, size_t ybs, void* y2, size_t y2bs, hipStream_t st)
 {
     if (ybs == 0) ybs = (size_t)C * HW;
     if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: plane of %d elements > %d", HW, IN_MAX_HW);
@@ -343,24 +359,24 @@ int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma
         if (HW & 3) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: a plane of %d elements (> %d) must be a multiple of 4", HW, IN_MAX_HW_REG);
         if (io_bf16)
             instnorm_act_fwd_kernel<bf16_t, 512, 128, true><<<planes, 512, 0, st>>>(static_cast<const bf16_t*>(x), bias, gamma, beta, eps, act, slope,
-                                                                                   C, HW, static_cast<bf16_t*>(y), mean, rstd, ybs);
+                                                                                   C, HW, static_cast<bf16_t*>(y), mean, rstd, ybs, static_cast<bf16_t*>(y2), y2bs);
         else
             instnorm_act_fwd_kernel<float, 512, 128, true><<<planes, 512, 0, st>>>(static_cast<const float*>(x), bias, gamma, beta, eps, act, slope,
-                                                                                  C, HW, static_cast<float*>(y), mean, rstd, ybs);
+                                                                                  C, HW, static_cast<float*>(y), mean, rstd, ybs, static_cast<float*>(y2), y2bs);
         return check_launch("instnorm_act_fwd_kernel");
     }
     if (io_bf16)
         IN_DISPATCH(instnorm_act_fwd_kernel, bf16_t, static_cast<const bf16_t*>(x), bias, gamma, beta, eps, act, slope, C, HW,
-                    static_cast<bf16_t*>(y), mean, rstd, ybs);
+                    static_cast<bf16_t*>(y), mean, rstd, ybs, static_cast<bf16_t*>(y2), y2bs);
     else
         IN_DISPATCH(instnorm_act_fwd_kernel, float, static_cast<const float*>(x), bias, gamma, beta, eps, act, slope, C, HW,
-                    static_cast<float*>(y), mean, rstd, ybs);
+                    static_cast<float*>(y), mean, rstd, ybs, static_cast<float*>(y2), y2bs);
     return check_launch("instnorm_act_fwd_kernel");
 }
 
 int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const float* bias, const float* gamma, const float* mean,
                             const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dgamma_p,
-                            float* dbeta_p, float* dbias_p, float* sums, size_t dybs, size_t ybs, hipStream_t st)
+                            float* dbeta_p, float* dbias_p, float* sums, size_t dybs, size_t ybs, const void* dy2, size_t dy2bs, hipStream_t st)
 {
     if (dybs == 0) dybs = (size_t)C * HW;
     if (ybs == 0) ybs = (size_t)C * HW;
@@ -374,19 +390,19 @@ int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const 
         if (io_bf16)
             instnorm_act_bwd_kernel<bf16_t, 512, 128, true, true><<<planes, 512, 0, st>>>(
                 static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW,
-                static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs);
+                static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs, static_cast<const bf16_t*>(dy2), dy2bs);
         else
             instnorm_act_bwd_kernel<float, 512, 128, true, true><<<planes, 512, 0, st>>>(
                 static_cast<const float*>(dy), static_cast<const float*>(y), static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW,
-                static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs);
+                static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs, static_cast<const float*>(dy2), dy2bs);
         return check_launch("instnorm_act_bwd_kernel");
     }
     if (io_bf16)
         IN_DISPATCH(instnorm_act_bwd_kernel, bf16_t, static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y),
-                    static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs);
+                    static_cast<const bf16_t*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<bf16_t*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs, static_cast<const bf16_t*>(dy2), dy2bs);
     else
         IN_DISPATCH(instnorm_act_bwd_kernel, float, static_cast<const float*>(dy), static_cast<const float*>(y),
-                    static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs);
+                    static_cast<const float*>(x), bias, gamma, mean, rstd, act, slope, C, HW, static_cast<float*>(dx), dgamma_p, dbeta_p, dbias_p, sums, ticket, dybs, ybs, static_cast<const float*>(dy2), dy2bs);
     return check_launch("instnorm_act_bwd_kernel");
 }
 

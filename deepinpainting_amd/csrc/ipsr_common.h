@@ -208,10 +208,12 @@ int launch_cat_relu_bwd(const void* g, const void* out, int B, int C1, int C2, i
 
 // instnorm.hip — conv-bias + InstanceNorm2d + activation, fused forward / backward (one (sample, channel) plane per workgroup)
 int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
-                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, size_t y_bstride, hipStream_t st);
+                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, size_t y_bstride, void* y2, size_t y2_bstride,
+                            hipStream_t st);
 int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const float* bias, const float* gamma, const float* mean,
                             const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dgamma_p,
-                            float* dbeta_p, float* dbias_p, float* sums, size_t dy_bstride, size_t y_bstride, hipStream_t st);
+                            float* dbeta_p, float* dbias_p, float* sums, size_t dy_bstride, size_t y_bstride, const void* dy2, size_t dy2_bstride,
+                            hipStream_t st);
 int launch_bias_act_bwd(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dbias_p,
                         float* sums, hipStream_t st);
 

@@ -104,6 +104,64 @@ class _InstNormReLUCat(torch.autograd.Function):
         return dyn, dbias, dg, db, None, dx
 
 
+class _InstNormActSkip(torch.autograd.Function):
+    """The norm that produces a level's input, with TWO outputs: act(norm) for the level's down path and relu(norm) written straight
+    into the skip half of the level's concatenated tensor (allocated here, completed by _InstNormReLUCatInto at the level's end).
+    Backward: the two consumers' gradients meet inside the norm's backward kernel (no add kernel, no slice copy)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, gamma, beta, eps, act, slope, c1):
+        B, C2 = y.shape[0], y.shape[1]
+        buf = torch.empty((B, c1 + C2) + tuple(y.shape[2:]), dtype=y.dtype, device=y.device)
+        x_act, mean, rstd = ops.instnorm_act_forward(y, bias, gamma, beta, eps, act, slope, relu_into=buf, relu_at=c1)
+        ctx.save_for_backward(y, bias, gamma, x_act, mean, rstd)
+        ctx.act, ctx.slope, ctx.c1 = act, slope, c1
+        ctx.has_affine = gamma is not None
+        return x_act, buf
+
+    @staticmethod
+    def backward(ctx, g_x, g_buf):
+        y, bias, gamma, x_act, mean, rstd = ctx.saved_tensors
+        need_bias = bias is not None and ctx.needs_input_grad[1]
+        need_affine = ctx.has_affine and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        if g_x is None:
+            g_x = torch.zeros_like(x_act)
+        dx, dg, db, dbias = ops.instnorm_act_backward(g_x.contiguous(), x_act, y, bias, gamma, mean, rstd, ctx.act, ctx.slope, need_affine, need_bias,
+                                                      dy2=None if g_buf is None else g_buf.contiguous(), dy2_at=ctx.c1)
+        return dx, dbias, dg, db, None, None, None, None
+
+
+class _InstNormReLUCatInto(torch.autograd.Function):
+    """_InstNormReLUCat into a concatenated tensor whose skip half is already there (written by _InstNormActSkip): the first C1
+    channels of `buf` receive relu(norm(y)); the gradient of `buf` is handed back whole (its producer reads the skip half in place)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, gamma, beta, eps, buf):
+        _, mean, rstd = ops.instnorm_act_forward(y, bias, gamma, beta, eps, "relu", 0.0, into=buf, into_at=0)
+        ctx.mark_dirty(buf)
+        ctx.save_for_backward(y, bias, gamma, buf, mean, rstd)
+        ctx.has_affine = gamma is not None
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        y, bias, gamma, out, mean, rstd = ctx.saved_tensors
+        need_bias = bias is not None and ctx.needs_input_grad[1]
+        need_affine = ctx.has_affine and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        g = g.contiguous()
+        dyn, dg, db, dbias = ops.instnorm_act_backward(g, out, y, bias, gamma, mean, rstd, "relu", 0.0, need_affine, need_bias)
+        return dyn, dbias, dg, db, None, g
+
+
+def _tail_norm_channels(block):
+    """Output channels of a skip level whose sequence ends in a plain InstanceNorm (then the level can complete a concatenated tensor
+    its producer allocated), else None."""
+    inner = getattr(block, "model", None)
+    if getattr(block, "outermost", True) or not isinstance(inner, FusedSequential) or len(inner) == 0 or not _plain_inorm(inner[-1]):
+        return None
+    return int(inner[-1].num_features)
+
+
 def cat_skip(y, x, tail_relu):
     """torch.cat([y, x], 1), with the consumer's in-place ReLU folded in when it asked for that."""
     if tail_relu and y.is_cuda and y.dtype == x.dtype and y.dtype in (torch.float32, torch.bfloat16) \
@@ -152,15 +210,15 @@ class FusedSequential(nn.Sequential):
         """True when mods[j] is the in-place ReLU a skip level's concatenated output runs into (models/networks.py:229,408)."""
         return j < len(mods) and type(mods[j]) is nn.ReLU and mods[j].inplace
 
-    def forward(self, x, head_act_done=False, cat_with=None):
+    def forward(self, x, head_act_done=False, cat_with=None, cat_buf=None):
         """cat_with: the level's input, when the caller (networks._cat_skip) wants relu(cat([this(x), cat_with], 1)) and this sequence
         may produce it itself if it ends in a norm; the return value is then (tensor, concatenated?)."""
-        out = self._forward(x, head_act_done, cat_with)
+        out = self._forward(x, head_act_done, cat_with, cat_buf)
         if cat_with is None:
             return out[0]
         return out
 
-    def _forward(self, x, head_act_done, cat_with):
+    def _forward(self, x, head_act_done, cat_with, cat_buf):
         usable = FusedSequential.enabled and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
         mods = list(self)
         n = len(mods)
@@ -224,10 +282,24 @@ class FusedSequential(nn.Sequential):
                 if nxt is None and cat_with is not None and cat_with.is_contiguous() and cat_with.dtype == y.dtype \
                         and cat_with.shape[0] == y.shape[0] and cat_with.shape[2:] == y.shape[2:]:
                     # the level ends here: norm + skip concatenation + the parent's ReLU in one node
+                    if cat_buf is not None and cat_buf.dtype == y.dtype and cat_buf.shape[0] == y.shape[0] and cat_buf.shape[2:] == y.shape[2:] \
+                            and cat_buf.shape[1] == y.shape[1] + cat_with.shape[1]:
+                        return _InstNormReLUCatInto.apply(y, bias, norm.weight, norm.bias, norm.eps, cat_buf), True
                     return _InstNormReLUCat.apply(y, bias, norm.weight, norm.bias, norm.eps, cat_with), True
                 act = _act_of(nxt) if nxt is not None else None
                 child_act = self._head_act_of_child(nxt) if (nxt is not None and act is None) else None
                 a = act or child_act or ("none", 0.0)
+                if act is None and child_act is not None:
+                    tail = self._tail_relu_after(mods, j + 1)
+                    c1 = _tail_norm_channels(nxt) if tail else None
+                    if c1:      # this norm also writes the skip half of the child's concatenated tensor
+                        x, buf = _InstNormActSkip.apply(y, bias, norm.weight, norm.bias, norm.eps, a[0], a[1], c1)
+                        x = nxt(x, head_act_done=True, tail_relu=tail, cat_buf=buf)
+                    else:
+                        x = _InstNormAct.apply(y, bias, norm.weight, norm.bias, norm.eps, a[0], a[1])
+                        x = nxt(x, head_act_done=True, tail_relu=tail)
+                    i = j + 2 if tail else j + 1
+                    continue
                 x = _InstNormAct.apply(y, bias, norm.weight, norm.bias, norm.eps, a[0], a[1])
                 if act is not None:
                     i = j + 1

@@ -164,15 +164,16 @@ class GANLoss(nn.Module):
 # ----------------------------------------------------------------------------------------------------
 # U-Net building blocks
 # ----------------------------------------------------------------------------------------------------
-def _cat_skip(block, x, head_act_done=False, tail_relu=False):
+def _cat_skip(block, x, head_act_done=False, tail_relu=False, cat_buf=None):
     """Shared forward of every skip block (:270-278, :358-366, :443-452).  `head_act_done`: the producer of x has already
     applied this level's leading in-place activation; `tail_relu`: the consumer's in-place ReLU is to be applied to the
-    concatenated result here (both fused into kernels, see models/fused.py)."""
+    concatenated result here (both fused into kernels, see models/fused.py); `cat_buf`: the concatenated tensor, allocated by the
+    producer of x with its skip half relu(x) already in place (fused._InstNormActSkip) — the level's last norm completes it."""
     if block.outermost:
         y = block.model(x, head_act_done=head_act_done)
         return torch.relu_(y) if tail_relu else y
     if tail_relu and isinstance(block.model, FusedSequential):
-        y, done = block.model(x, head_act_done=head_act_done, cat_with=x)     # a level that ends in a norm concatenates by itself
+        y, done = block.model(x, head_act_done=head_act_done, cat_with=x, cat_buf=cat_buf)     # a level that ends in a norm concatenates by itself
         if done:
             return y
     else:
@@ -233,8 +234,8 @@ class UnetSkipConnectionBlock_3(nn.Module):
         L = _block3_layers(outer_nc, inner_nc, input_nc, norm_layer)
         self.model = FusedSequential(*_assemble3(L, outer_nc, inner_nc, submodule, outermost, innermost, use_dropout))
 
-    def forward(self, x, head_act_done=False, tail_relu=False):
-        return _cat_skip(self, x, head_act_done, tail_relu)
+    def forward(self, x, head_act_done=False, tail_relu=False, cat_buf=None):
+        return _cat_skip(self, x, head_act_done, tail_relu, cat_buf)
 
 
 class IPSR(nn.Module):
@@ -263,8 +264,8 @@ class IPSR(nn.Module):
         self.model = FusedSequential(*_assemble3(L, outer_nc, inner_nc, submodule, outermost, innermost, use_dropout,
                                                mid_down=(ipsr, innerCos), head_up=(innerCos2,)))
 
-    def forward(self, x, head_act_done=False, tail_relu=False):
-        return _cat_skip(self, x, head_act_done, tail_relu)
+    def forward(self, x, head_act_done=False, tail_relu=False, cat_buf=None):
+        return _cat_skip(self, x, head_act_done, tail_relu, cat_buf)
 
 
 class UnetGeneratorIPSR(nn.Module):
@@ -316,8 +317,8 @@ class UnetSkipConnectionBlock(nn.Module):
                 model.append(nn.Dropout(0.5))
         self.model = FusedSequential(*model)
 
-    def forward(self, x, head_act_done=False, tail_relu=False):
-        return _cat_skip(self, x, head_act_done, tail_relu)
+    def forward(self, x, head_act_done=False, tail_relu=False, cat_buf=None):
+        return _cat_skip(self, x, head_act_done, tail_relu, cat_buf)
 
 
 class UnetGenerator(nn.Module):

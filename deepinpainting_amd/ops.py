@@ -253,56 +253,89 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def instnorm_act_forward(x, bias, gamma, beta, eps, act, slope, into=None):
+def _slot(t, c0, hw):
+    """(pointer to channel c0 of a contiguous [B,Ctot,H,W] tensor, its batch stride in elements)."""
+    return t.data_ptr() + c0 * hw * t.element_size(), t.shape[1] * hw
+
+
+def _check_wide(wide, x, what):
+    if wide.dtype != x.dtype or not wide.is_contiguous() or wide.dim() != 4 or wide.shape[0] != x.shape[0] \
+            or tuple(wide.shape[2:]) != tuple(x.shape[2:]) or wide.device != x.device:
+        raise RuntimeError("%s %s does not extend %s along the channels" % (what, tuple(wide.shape), tuple(x.shape)))
+
+
+def instnorm_act_forward(x, bias, gamma, beta, eps, act, slope, into=None, into_at=0, relu_into=None, relu_at=0):
     """y = act(InstanceNorm(x + bias[c]) * gamma[c] + beta[c]) -> (y, mean [B*C], rstd [B*C]); x contiguous fp32 / bf16 [B,C,H,W].
-    into: a contiguous [B,Ctot,H,W] tensor (Ctot > C) whose FIRST C channels receive y (the skip concatenation is written in
-    place); the returned y is then `into` itself."""
+    into / into_at: a contiguous [B,Ctot,H,W] tensor whose channels [into_at, into_at + C) receive y (a skip concatenation written
+    in place); the returned y is then `into` itself.  relu_into / relu_at: a second destination of the same kind that receives
+    relu(normalised value) — the skip half of the CHILD level's concatenated tensor."""
     x, bf = _req_io(x, "x")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
     mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    if into is None and relu_into is None:
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().ipsr_instnorm_act_forward(x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps),
+                                                        ACT_CODE[act], float(slope), B, C, hw, bf, y.data_ptr(), mean.data_ptr(),
+                                                        rstd.data_ptr(), _stream()), "ipsr_instnorm_act_forward")
+        return y, mean, rstd
     if into is not None:
-        if into.dtype != x.dtype or not into.is_contiguous() or into.dim() != 4 or into.shape[0] != B or into.shape[1] <= C \
-                or tuple(into.shape[2:]) != tuple(x.shape[2:]) or into.device != x.device:
-            raise RuntimeError("instnorm_act_forward: `into` %s does not extend %s along the channels" % (tuple(into.shape), tuple(x.shape)))
-        _lib.check(_lib.lib().ipsr_instnorm_act_forward_slice(x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps),
-                                                              ACT_CODE[act], float(slope), B, C, hw, bf, into.data_ptr(), into.shape[1] * hw,
-                                                              mean.data_ptr(), rstd.data_ptr(), _stream()), "ipsr_instnorm_act_forward_slice")
-        return into, mean, rstd
-    y = torch.empty_like(x)
-    _lib.check(_lib.lib().ipsr_instnorm_act_forward(x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps),
-                                                    ACT_CODE[act], float(slope), B, C, hw, bf, y.data_ptr(), mean.data_ptr(),
-                                                    rstd.data_ptr(), _stream()), "ipsr_instnorm_act_forward")
+        _check_wide(into, x, "instnorm_act_forward: `into`")
+        if into_at < 0 or into_at + C > into.shape[1]:
+            raise RuntimeError("instnorm_act_forward: channels [%d, %d) outside `into` %s" % (into_at, into_at + C, tuple(into.shape)))
+        y, (yp, ybs) = into, _slot(into, into_at, hw)
+    else:
+        y = torch.empty_like(x)
+        yp, ybs = y.data_ptr(), C * hw
+    y2p, y2bs = None, 0
+    if relu_into is not None:
+        _check_wide(relu_into, x, "instnorm_act_forward: `relu_into`")
+        if relu_at < 0 or relu_at + C > relu_into.shape[1]:
+            raise RuntimeError("instnorm_act_forward: channels [%d, %d) outside `relu_into` %s" % (relu_at, relu_at + C, tuple(relu_into.shape)))
+        y2p, y2bs = _slot(relu_into, relu_at, hw)
+    _lib.check(_lib.lib().ipsr_instnorm_act_forward_slice(x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps),
+                                                          ACT_CODE[act], float(slope), B, C, hw, bf, yp, ybs, y2p, y2bs,
+                                                          mean.data_ptr(), rstd.data_ptr(), _stream()), "ipsr_instnorm_act_forward_slice")
     return y, mean, rstd
 
 
 SUMS_MAX_CHANNELS = 2048       # csrc/instnorm.hip TICKET_MAXC: widest layer whose batch sums come out of the backward launch itself
 
 
-def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_affine, need_bias):
-    """-> (dx, dgamma [C] | None, dbeta [C] | None, dbias [C] | None).  dy and y may be WIDER than x along the channels (both the
-    same [B,Ctot,H,W], contiguous): their first C channels are the operands (skip concatenation and its gradient, read in place)."""
+def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_affine, need_bias, at=0, dy2=None, dy2_at=0):
+    """-> (dx, dgamma [C] | None, dbeta [C] | None, dbias [C] | None).  dy and y may be WIDER than x along the channels (contiguous
+    [B,Ctot,H,W]): their channels [at, at + C) are the operands (a skip concatenation and its gradient, read in place).  dy2 / dy2_at:
+    the gradient of the relu'd second output of the forward (channels [dy2_at, dy2_at + C) of a wide tensor), added inside the kernel."""
     x, bf = _req_io(x, "x")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
     dy, _ = _req_io(dy.to(x.dtype), "grad_output")
-    if dy.shape[1] != y.shape[1] or dy.shape[1] < C:
-        raise RuntimeError("instnorm_act_backward: grad_output %s / output %s do not match input %s" % (tuple(dy.shape), tuple(y.shape), tuple(x.shape)))
     dx = torch.empty_like(x)
     part = torch.empty((3, B, C), dtype=torch.float32, device=x.device)
     # the batch sums of the per-plane partials are written by the same launch (the last plane of each channel to finish)
     sums = torch.empty((3, C), dtype=torch.float32, device=x.device) if C <= SUMS_MAX_CHANNELS else None
     L = _lib.lib()
-    if dy.shape[1] == C:
+    if dy.shape[1] == C and y.shape[1] == C and dy2 is None:
         _lib.check(L.ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)),
                                                 mean.data_ptr(), rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
                                                 dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
                                                 _ptr(sums), _stream()), "ipsr_instnorm_act_backward")
     else:
-        if not y.is_contiguous():
-            raise RuntimeError("instnorm_act_backward: the wide output must be contiguous")
-        _lib.check(L.ipsr_instnorm_act_backward_slice(dy.data_ptr(), dy.shape[1] * hw, y.data_ptr(), y.shape[1] * hw, x.data_ptr(), _ptr(_f32(bias)),
+        _check_wide(dy, x, "instnorm_act_backward: grad_output")
+        _check_wide(y, x, "instnorm_act_backward: output")
+        if at < 0 or at + C > dy.shape[1] or (y.shape[1] != C and y.shape[1] != dy.shape[1]):
+            raise RuntimeError("instnorm_act_backward: channels [%d, %d) outside %s / %s" % (at, at + C, tuple(dy.shape), tuple(y.shape)))
+        dyp, dybs = _slot(dy, at if dy.shape[1] != C else 0, hw)
+        yp, ybs = _slot(y, at if y.shape[1] != C else 0, hw)
+        d2p, d2bs = None, 0
+        if dy2 is not None:
+            dy2, _ = _req_io(dy2.to(x.dtype), "second grad_output")
+            _check_wide(dy2, x, "instnorm_act_backward: second grad_output")
+            if dy2_at < 0 or dy2_at + C > dy2.shape[1]:
+                raise RuntimeError("instnorm_act_backward: channels [%d, %d) outside the second gradient %s" % (dy2_at, dy2_at + C, tuple(dy2.shape)))
+            d2p, d2bs = _slot(dy2, dy2_at, hw)
+        _lib.check(L.ipsr_instnorm_act_backward_slice(dyp, dybs, d2p, d2bs, yp, ybs, x.data_ptr(), _ptr(_f32(bias)),
                                                       _ptr(_f32(gamma)), mean.data_ptr(), rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
                                                       dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
                                                       _ptr(sums), _stream()), "ipsr_instnorm_act_backward_slice")

@@ -195,14 +195,18 @@ int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gam
 int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, const float* bias, const float* gamma,
                                const float* mean, const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16,
                                void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream);
-/* The `_slice` forms: y (forward) / dy and y (backward) are the first C channels of wider tensors — the output of a skip
- * concatenation torch.cat([y, x], 1) (models/networks.py:270-278) and its gradient — given by their batch strides in elements
- * (>= C*HW); x, dx and the statistics stay dense.  With them the normalisation writes straight into the concatenated tensor and
- * its backward reads the gradient's slice in place: the concatenation kernel only has the skip half left to copy. */
+/* The `_slice` forms: y (forward) / dy and y (backward) are C channels of wider tensors — the output of a skip concatenation
+ * torch.cat([y, x], 1) (models/networks.py:270-278) and its gradient — given by a pointer to their first element and their batch
+ * strides in elements (>= C*HW); x, dx and the statistics stay dense.  With them a level's last normalisation writes straight into
+ * the concatenated tensor and its backward reads the gradient's slice in place.
+ * y2 / dy2 (optional, NULL = absent): a second output relu(normalised value) — the SKIP half of the child level's concatenated tensor,
+ * written by the norm that produces the level's input — and its gradient: the two consumers of a level's input (its down path and
+ * its skip connection) then meet inside this backward, dz = dy * act'(y) + dy2 * relu'(y), instead of in an add kernel. */
 int ipsr_instnorm_act_forward_slice(const void* x, const float* bias, const float* gamma, const float* beta, float eps,
                                     int act, float slope, int B, int C, int HW, int io_bf16,
-                                    void* y, size_t y_batch_stride, float* mean, float* rstd, void* stream);
-int ipsr_instnorm_act_backward_slice(const void* dy, size_t dy_batch_stride, const void* y, size_t y_batch_stride, const void* x,
+                                    void* y, size_t y_batch_stride, void* y2, size_t y2_batch_stride, float* mean, float* rstd, void* stream);
+int ipsr_instnorm_act_backward_slice(const void* dy, size_t dy_batch_stride, const void* dy2, size_t dy2_batch_stride,
+                                     const void* y, size_t y_batch_stride, const void* x,
                                      const float* bias, const float* gamma, const float* mean, const float* rstd, int act, float slope,
                                      int B, int C, int HW, int io_bf16,
                                      void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream);

@@ -1010,6 +1010,44 @@ def test_fused_norm_relu_cat_node_vs_torch(shape, c2):
         assert float(d.max()) <= tol, (a.shape, float(d.max()), scale, int(near.sum()))
 
 
+@pytest.mark.parametrize("shape,c1", [((8, 64, 64, 64), 64), ((2, 6, 7, 9), 5), ((2, 16, 256, 256), 8)])
+def test_fused_skip_source_and_sink_nodes_vs_torch(shape, c1):
+    """The pair that carries a level's skip connection without a concatenation pass: _InstNormActSkip (the norm producing the level's
+    input also writes relu(value) into the skip half of the level's concatenated tensor) and _InstNormReLUCatInto (the level's last
+    norm completes that tensor) — against  x = leaky(norm(v)); out = relu(cat([norm2(f(x)), x], 1))  in plain torch, f = a 1x1 mix."""
+    from deepinpainting_amd.models.fused import _InstNormActSkip, _InstNormReLUCatInto
+    g = torch.Generator(device="cuda").manual_seed(23)
+    B, C2 = shape[0], shape[1]
+    v = (torch.randn(shape, device="cuda", generator=g) * 1.5 + 0.2).requires_grad_(True)
+    gam1 = (torch.rand(C2, device="cuda", generator=g) + 0.5).requires_grad_(True)
+    bet1 = torch.randn(C2, device="cuda", generator=g).requires_grad_(True)
+    mix = (torch.randn(c1, C2, 1, 1, device="cuda", generator=g) / C2 ** 0.5).requires_grad_(True)
+    gam2 = (torch.rand(c1, device="cuda", generator=g) + 0.5).requires_grad_(True)
+    bet2 = torch.randn(c1, device="cuda", generator=g).requires_grad_(True)
+    go = torch.randn((B, c1 + C2) + shape[2:], device="cuda", generator=g)
+    leaves = (v, gam1, bet1, mix, gam2, bet2)
+    inorm = torch.nn.functional.instance_norm
+
+    n1 = inorm(v, None, None, gam1, bet1, True, 0.1, 1e-5)
+    x = torch.nn.functional.leaky_relu(n1, 0.2)
+    n2 = inorm(torch.nn.functional.conv2d(x, mix), None, None, gam2, bet2, True, 0.1, 1e-5)
+    ref = torch.relu(torch.cat([n2, x], 1))
+    g_ref = torch.autograd.grad(ref, leaves, go)
+
+    xa, buf = _InstNormActSkip.apply(v, None, gam1, bet1, 1e-5, "leaky", 0.2, c1)
+    out = _InstNormReLUCatInto.apply(torch.nn.functional.conv2d(xa, mix), None, gam2, bet2, 1e-5, buf)
+    g_hip = torch.autograd.grad(out, leaves, go)
+    torch.testing.assert_close(out, ref, rtol=3e-5, atol=3e-5)
+    near = int((n1.detach().abs() < 1e-5).sum()) + int((n2.detach().abs() < 1e-5).sum())       # elements on a ReLU / LeakyReLU kink
+    for a, b in zip(g_hip, g_ref):
+        scale = max(1.0, float(b.abs().max()))
+        d = (a - b).abs()
+        if near == 0:
+            assert float(d.max()) <= 1e-4 * scale, (a.shape, float(d.max()), scale)
+        else:           # a flipped mask moves single elements by a whole gradient value: compare in the mean
+            assert float(d.mean()) <= 1e-5 * scale and float((d > 1e-3 * scale).float().mean()) <= 1e-4, (a.shape, float(d.mean()), scale, near)
+
+
 def test_fused_bias_act_autograd_vs_torch():
     from deepinpainting_amd.models.fused import _BiasAct
     g = torch.Generator(device="cuda").manual_seed(8)
