@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libipsr_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 
@@ -49,6 +49,9 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "ipsr_instnorm_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                            c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ipsr_bias_act_skip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]),
+    "ipsr_bias_act_backward_skip": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_void_p]),
     "ipsr_instnorm_act_forward_slice": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_int, c_int, c_int, c_int,
                                                 c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "ipsr_instnorm_act_backward_slice": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,

@@ -132,7 +132,7 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_abi_version(void) { return 13; }
+int ipsr_abi_version(void) { return 14; }
 
 int ipsr_debug_set_option(int key, int value)
 {
@@ -421,7 +421,17 @@ int ipsr_bias_act(void* x, const float* bias, int B, int C, int HW, int act, flo
     if (!x) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: null pointer");
     if (B < 1 || C < 1 || HW < 1) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: bad size B=%d C=%d HW=%d", B, C, HW);
     if ((HW & 3) == 0 && !aligned_io(x, io_bf16)) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: x is not vector aligned");
-    return launch_bias_act(x, bias, B, C, HW, act, slope, io_bf16, static_cast<hipStream_t>(stream));
+    return launch_bias_act(x, bias, B, C, HW, act, slope, io_bf16, nullptr, 0, static_cast<hipStream_t>(stream));
+}
+
+int ipsr_bias_act_skip(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* y2, size_t y2_batch_stride,
+                       void* stream)
+{
+    if (!x || !y2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_skip: null pointer");
+    if (B < 1 || C < 1 || HW < 1 || y2_batch_stride < (size_t)C * HW) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_skip: bad size B=%d C=%d HW=%d", B, C, HW);
+    if ((HW & 3) == 0 && (!aligned_io(x, io_bf16) || !aligned_io(y2, io_bf16) || (y2_batch_stride & 3)))
+        return fail(IPSR_ERR_INVALID, "ipsr_bias_act_skip: tensors are not vector aligned");
+    return launch_bias_act(x, bias, B, C, HW, act, slope, io_bf16, y2, y2_batch_stride, static_cast<hipStream_t>(stream));
 }
 
 int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, void* stream)
@@ -507,7 +517,17 @@ int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, 
     if (B < 1 || C < 1 || HW < 1 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: bad argument");
     if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(dx, io_bf16)))
         return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: tensors are not vector aligned");
-    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, sums, static_cast<hipStream_t>(stream));
+    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, sums, nullptr, 0, static_cast<hipStream_t>(stream));
+}
+
+int ipsr_bias_act_backward_skip(const void* dy, const void* dy2, size_t dy2_batch_stride, const void* y, int act, float slope, int B, int C, int HW,
+                                int io_bf16, void* dx, float* dbias_p, float* sums, void* stream)
+{
+    if (!dy || !dy2 || !y || !dx) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward_skip: null pointer");
+    if (B < 1 || C < 1 || HW < 1 || act < 0 || act > 2 || dy2_batch_stride < (size_t)C * HW) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward_skip: bad argument");
+    if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(dy2, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(dx, io_bf16) || (dy2_batch_stride & 3)))
+        return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward_skip: tensors are not vector aligned");
+    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, sums, dy2, dy2_batch_stride, static_cast<hipStream_t>(stream));
 }
 
 size_t innercos_workspace_bytes(int B, int Cuse, int N) { return innercos_ws_bytes(B, Cuse, N); }

@@ -293,12 +293,15 @@ __global__ void __launch_bounds__(T) instnorm_act_bwd_kernel(const IO* __restric
 template <typename IO>
 __global__ void __launch_bounds__(256) bias_act_bwd_kernel(const IO* __restrict__ dy, const IO* __restrict__ y, int act, float slope,
                                                            int HW, IO* __restrict__ dx, float* __restrict__ dbias_p, int C,
-                                                           float* __restrict__ sums, unsigned* __restrict__ ticket)
+                                                           float* __restrict__ sums, unsigned* __restrict__ ticket,
+                                                           const IO* __restrict__ dy2, size_t dy2_bstride)
 {
     __shared__ float red[4];
     __shared__ int last_s;
     const int plane = blockIdx.x, tid = threadIdx.x;
     const size_t off = (size_t)plane * HW;
+    // dy2 (optional): gradient of the relu'd second output (forward's y2), a channel slice of the concatenated tensor's gradient
+    if (dy2) dy2 += (size_t)(plane / C) * dy2_bstride + (size_t)(plane % C) * HW - off;
     float s = 0.0f;
     if ((HW & 3) == 0) {
         const int n4 = HW >> 2;
@@ -308,12 +311,18 @@ __global__ void __launch_bounds__(256) bias_act_bwd_kernel(const IO* __restrict_
             float4 r;
             r.x = d.x * act_bwd(o.x, act, slope); r.y = d.y * act_bwd(o.y, act, slope);
             r.z = d.z * act_bwd(o.z, act, slope); r.w = d.w * act_bwd(o.w, act, slope);
+            if (dy2) {
+                const float4 e2 = ld4(dy2 + off, i);
+                r.x += e2.x * act_bwd(o.x, 1, 0.f); r.y += e2.y * act_bwd(o.y, 1, 0.f);
+                r.z += e2.z * act_bwd(o.z, 1, 0.f); r.w += e2.w * act_bwd(o.w, 1, 0.f);
+            }
             s += (r.x + r.y) + (r.z + r.w);
             st4(dx + off, i, r);
         }
     } else {
         for (int i = tid; i < HW; i += 256) {
-            const float r = ld1(dy, off + i) * act_bwd(ld1(y, off + i), act, slope);
+            float r = ld1(dy, off + i) * act_bwd(ld1(y, off + i), act, slope);
+            if (dy2) r += ld1(dy2, off + i) * act_bwd(ld1(y, off + i), 1, 0.f);
             s += r;
             st1(dx, off + i, r);
         }
@@ -407,17 +416,17 @@ int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const 
 }
 
 int launch_bias_act_bwd(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dbias_p,
-                        float* sums, hipStream_t st)
+                        float* sums, const void* dy2, size_t dy2bs, hipStream_t st)
 {
     if (sums && (C > TICKET_MAXC || !dbias_p)) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_bias_act_backward: batch sums need the partials and <= %d channels", TICKET_MAXC);
     unsigned* ticket = next_ticket_row(sums);
     if (sums && !ticket) return fail(IPSR_ERR_LAUNCH, "ipsr_bias_act_backward: ticket pool address");
     if (io_bf16)
         bias_act_bwd_kernel<bf16_t><<<B * C, 256, 0, st>>>(static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y), act, slope, HW,
-                                                           static_cast<bf16_t*>(dx), dbias_p, C, sums, ticket);
+                                                           static_cast<bf16_t*>(dx), dbias_p, C, sums, ticket, static_cast<const bf16_t*>(dy2), dy2bs);
     else
         bias_act_bwd_kernel<float><<<B * C, 256, 0, st>>>(static_cast<const float*>(dy), static_cast<const float*>(y), act, slope, HW,
-                                                          static_cast<float*>(dx), dbias_p, C, sums, ticket);
+                                                          static_cast<float*>(dx), dbias_p, C, sums, ticket, static_cast<const float*>(dy2), dy2bs);
     return check_launch("bias_act_bwd_kernel");
 }
 

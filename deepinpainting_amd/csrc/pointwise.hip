@@ -24,22 +24,32 @@ __device__ __forceinline__ float act_apply(float v, float slope)
     return v;
 }
 
+// y2 (optional): relu(x + bias) as a second output — the skip half of the child level's concatenated tensor (see instnorm.hip's y2),
+// channel slice given by its batch stride.
 template <typename IO, int ACT>
-__global__ void __launch_bounds__(256) bias_act_kernel(IO* __restrict__ x, const float* __restrict__ bias, int C, int HW, float slope)
+__global__ void __launch_bounds__(256) bias_act_kernel(IO* __restrict__ x, const float* __restrict__ bias, int C, int HW, float slope,
+                                                       IO* __restrict__ y2, size_t y2_bstride)
 {
     const int plane = blockIdx.y;                       // b*C + c
     const float bv = bias ? bias[plane % C] : 0.0f;
     IO* p = x + (size_t)plane * HW;
+    IO* q = y2 ? y2 + (size_t)(plane / C) * y2_bstride + (size_t)(plane % C) * HW : nullptr;
     if ((HW & 3) == 0) {
         const int n4 = HW >> 2;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
             float4 v = ld4(p, i);
-            v.x = act_apply<ACT>(v.x + bv, slope); v.y = act_apply<ACT>(v.y + bv, slope);
-            v.z = act_apply<ACT>(v.z + bv, slope); v.w = act_apply<ACT>(v.w + bv, slope);
+            v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+            if (q) st4(q, i, make_float4(relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)));
+            v.x = act_apply<ACT>(v.x, slope); v.y = act_apply<ACT>(v.y, slope);
+            v.z = act_apply<ACT>(v.z, slope); v.w = act_apply<ACT>(v.w, slope);
             st4(p, i, v);
         }
     } else {
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) st1(p, i, act_apply<ACT>(ld1(p, i) + bv, slope));
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+            const float v = ld1(p, i) + bv;
+            if (q) st1(q, i, relu_nan(v));
+            st1(p, i, act_apply<ACT>(v, slope));
+        }
     }
 }
 
@@ -153,7 +163,7 @@ int launch_cat_relu_bwd(const void* g, const void* out, int B, int C1, int C2, i
     return check_launch("cat_relu_bwd_kernel");
 }
 
-int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, hipStream_t st)
+int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* y2, size_t y2bs, hipStream_t st)
 {
     const int planes = B * C;
     if (planes > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_bias_act: B*C=%d > 65535 planes", planes);
@@ -164,9 +174,9 @@ int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, f
     if (act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: unknown activation %d", act);
 #define BA_LAUNCH(IO)                                                                                         \
     switch (act) {                                                                                            \
-        case 0: bias_act_kernel<IO, 0><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope); break; \
-        case 1: bias_act_kernel<IO, 1><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope); break; \
-        default: bias_act_kernel<IO, 2><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope); break; \
+        case 0: bias_act_kernel<IO, 0><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope, static_cast<IO*>(y2), y2bs); break; \
+        case 1: bias_act_kernel<IO, 1><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope, static_cast<IO*>(y2), y2bs); break; \
+        default: bias_act_kernel<IO, 2><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope, static_cast<IO*>(y2), y2bs); break; \
     }
     if (io_bf16) { BA_LAUNCH(bf16_t) } else { BA_LAUNCH(float) }
 #undef BA_LAUNCH

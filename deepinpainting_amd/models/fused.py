@@ -61,6 +61,31 @@ class _BiasAct(torch.autograd.Function):
         return dx, dbias, None, None
 
 
+class _BiasActSkip(torch.autograd.Function):
+    """_BiasAct with a second output: relu(x + bias) written into the skip half of the child level's concatenated tensor (allocated
+    here); backward dx = dy * act'(y) + dbuf[:, c1:] * relu'(y).  The level-1 blocks, whose input comes from a convolution alone."""
+
+    @staticmethod
+    def forward(ctx, x, bias, act, slope, c1):
+        B, C2 = x.shape[0], x.shape[1]
+        buf = torch.empty((B, c1 + C2) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+        ops.bias_act_(x, bias, act, slope, relu_into=buf, relu_at=c1)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        ctx.act, ctx.slope, ctx.c1 = act, slope, c1
+        ctx.has_bias = bias is not None
+        return x, buf
+
+    @staticmethod
+    def backward(ctx, dy, dbuf):
+        (y,) = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(y)
+        dx, dbias = ops.bias_act_backward(dy.contiguous(), y, ctx.act, ctx.slope, ctx.has_bias and ctx.needs_input_grad[1],
+                                          dy2=None if dbuf is None else dbuf.contiguous(), dy2_at=ctx.c1)
+        return dx, dbias, None, None, None
+
+
 class _CatReLU(torch.autograd.Function):
     """relu(cat([y, x], 1)): the skip concatenation of a level followed by the parent's in-place ReLU."""
 
@@ -262,7 +287,12 @@ class FusedSequential(nn.Sequential):
                     i += 2
                 else:
                     tail = self._tail_relu_after(mods, i + 2)
-                    x = nxt(_BiasAct.apply(y, m.bias, child_act[0], child_act[1]), head_act_done=True, tail_relu=tail)
+                    c1 = _tail_norm_channels(nxt) if tail else None
+                    if c1:      # this bias pass also writes the skip half of the child's concatenated tensor
+                        xa, buf = _BiasActSkip.apply(y, m.bias, child_act[0], child_act[1], c1)
+                        x = nxt(xa, head_act_done=True, tail_relu=tail, cat_buf=buf)
+                    else:
+                        x = nxt(_BiasAct.apply(y, m.bias, child_act[0], child_act[1]), head_act_done=True, tail_relu=tail)
                     i += 3 if tail else 2
                 continue
             if norm is not None:

@@ -233,15 +233,25 @@ def _f32(t):
     return None if t is None else _req(t, torch.float32, "parameter")
 
 
-def bias_act_(x, bias, act="relu", slope=0.2):
-    """In place x[b,c,...] = act(x + bias[c]) on a contiguous fp32/bf16 [B,C,*] tensor.  act: none | relu | leaky."""
+def bias_act_(x, bias, act="relu", slope=0.2, relu_into=None, relu_at=0):
+    """In place x[b,c,...] = act(x + bias[c]) on a contiguous fp32/bf16 [B,C,*] tensor.  act: none | relu | leaky.
+    relu_into / relu_at: a contiguous [B,Ctot,H,W] tensor whose channels [relu_at, relu_at + C) also receive relu(x + bias) — the skip
+    half of the child level's concatenated tensor."""
     if not x.is_contiguous():
         raise RuntimeError("bias_act_ works in place and needs a contiguous tensor")
     x, bf = _req_io(x, "x")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
-    _lib.check(_lib.lib().ipsr_bias_act(x.data_ptr(), _ptr(_f32(bias)), B, C, hw, ACT_CODE[act], float(slope), bf, _stream()),
-               "ipsr_bias_act")
+    if relu_into is None:
+        _lib.check(_lib.lib().ipsr_bias_act(x.data_ptr(), _ptr(_f32(bias)), B, C, hw, ACT_CODE[act], float(slope), bf, _stream()),
+                   "ipsr_bias_act")
+        return x
+    _check_wide(relu_into, x, "bias_act_: `relu_into`")
+    if relu_at < 0 or relu_at + C > relu_into.shape[1]:
+        raise RuntimeError("bias_act_: channels [%d, %d) outside `relu_into` %s" % (relu_at, relu_at + C, tuple(relu_into.shape)))
+    y2p, y2bs = _slot(relu_into, relu_at, hw)
+    _lib.check(_lib.lib().ipsr_bias_act_skip(x.data_ptr(), _ptr(_f32(bias)), B, C, hw, ACT_CODE[act], float(slope), bf, y2p, y2bs, _stream()),
+               "ipsr_bias_act_skip")
     return x
 
 
@@ -343,15 +353,25 @@ def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_af
     return dx, (s[0] if need_affine else None), (s[1] if need_affine else None), (s[2] if need_bias else None)
 
 
-def bias_act_backward(dy, y, act, slope, need_bias):
+def bias_act_backward(dy, y, act, slope, need_bias, dy2=None, dy2_at=0):
+    """dx = dy * act'(y) (+ dy2[:, dy2_at : dy2_at + C] * relu'(y): the gradient of bias_act_'s second output), dbias [C] | None."""
     dy, bf = _req_io(dy.to(y.dtype), "grad_output")
     B, C = y.shape[0], y.shape[1]
     hw = y.numel() // (B * C)
     dx = torch.empty_like(y)
     part = torch.empty((B, C), dtype=torch.float32, device=y.device) if need_bias else None
     sums = torch.empty(C, dtype=torch.float32, device=y.device) if need_bias and C <= SUMS_MAX_CHANNELS else None
-    _lib.check(_lib.lib().ipsr_bias_act_backward(dy.data_ptr(), y.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf, dx.data_ptr(),
-                                                 _ptr(part), _ptr(sums), _stream()), "ipsr_bias_act_backward")
+    if dy2 is None:
+        _lib.check(_lib.lib().ipsr_bias_act_backward(dy.data_ptr(), y.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf, dx.data_ptr(),
+                                                     _ptr(part), _ptr(sums), _stream()), "ipsr_bias_act_backward")
+    else:
+        dy2, _ = _req_io(dy2.to(y.dtype), "second grad_output")
+        _check_wide(dy2, y, "bias_act_backward: second grad_output")
+        if dy2_at < 0 or dy2_at + C > dy2.shape[1]:
+            raise RuntimeError("bias_act_backward: channels [%d, %d) outside the second gradient %s" % (dy2_at, dy2_at + C, tuple(dy2.shape)))
+        d2p, d2bs = _slot(dy2, dy2_at, hw)
+        _lib.check(_lib.lib().ipsr_bias_act_backward_skip(dy.data_ptr(), d2p, d2bs, y.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
+                                                          dx.data_ptr(), _ptr(part), _ptr(sums), _stream()), "ipsr_bias_act_backward_skip")
     return dx, ((sums if sums is not None else part.sum(0)) if need_bias else None)
 
 

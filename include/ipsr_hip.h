@@ -176,6 +176,13 @@ int ipsr_cat_relu_backward(const void* grad_out, const void* out, int B, int C1,
                            void* dy, void* dx, void* stream);
 int ipsr_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* stream);
 int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, void* stream);
+/* ipsr_bias_act with a second output y2 = relu(x + bias), a C-channel slice (pointer to its first element + batch stride in
+ * elements) of the child level's concatenated tensor, and the matching backward dx = dy * act'(y) + dy2 * relu'(y): the level-1
+ * blocks of the U-Nets, whose input comes from a convolution without a norm (see the y2 / dy2 forms of the norm entry points). */
+int ipsr_bias_act_skip(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* y2, size_t y2_batch_stride,
+                       void* stream);
+int ipsr_bias_act_backward_skip(const void* dy, const void* dy2, size_t dy2_batch_stride, const void* y, int act, float slope, int B, int C, int HW,
+                                int io_bf16, void* dx, float* dbias_p, float* sums, void* stream);
 
 /* ---- conv-bias + InstanceNorm2d + activation ------------------------------------------------------
  * replaces the chain  Conv2d/ConvTranspose2d bias add -> nn.InstanceNorm2d(affine) -> LeakyReLU(0.2)/ReLU  that follows
