@@ -22,8 +22,9 @@ constexpr int THIN_ROWS = 64;        // rows per workgroup (weight gradient)
 
 __device__ __forceinline__ float thin_relu(float v) { return v < 0.0f ? 0.0f : v; }      // NaN stays NaN (torch.relu)
 
-// few -> many.  One thread = one pixel x 16 output channels; the I*9 window values live in registers, the 16*I*9 weights in LDS
-// (uniform reads: broadcast).  grid (ceil(W/256), H, B * O/16).
+// few -> many.  One thread = TWO adjacent pixels x 16 output channels: the I x 3 x 4 window values live in registers, the 16*I*9 weights in
+// LDS (uniform reads: broadcast) — every weight read feeds two multiply-adds (with one pixel per thread the kernel was bound by its 432
+// ds_reads per thread, 2 TB/s of output).  grid (ceil(W/512), H, B * O/16); W even.
 template <int I>
 __global__ void __launch_bounds__(256) thin_f2m_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, int relu,
                                                        float* __restrict__ out, int B, int O, int H, int W, long so, long si, int flip)
@@ -36,9 +37,9 @@ __global__ void __launch_bounds__(256) thin_f2m_kernel(const float* __restrict__
         wl[o][rem] = w[(long)(o0 + o) * so + (long)i * si + (flip ? 8 - t : t)];
     }
     __syncthreads();
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
     if (x >= W) return;
-    float win[I][9];
+    float win[I][3][4];                                   // columns x-1 .. x+2
 #pragma unroll
     for (int i = 0; i < I; ++i) {
         const float* ip = in + ((size_t)b * I + i) * H * W;
@@ -47,21 +48,28 @@ __global__ void __launch_bounds__(256) thin_f2m_kernel(const float* __restrict__
             const int yy = y + r - 1;
             const bool yok = (unsigned)yy < (unsigned)H;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int xx = x + s - 1;
-                win[i][r * 3 + s] = (yok && (unsigned)xx < (unsigned)W) ? ip[(size_t)yy * W + xx] : 0.0f;
+            for (int c = 0; c < 4; ++c) {
+                const int xx = x + c - 1;
+                win[i][r][c] = (yok && (unsigned)xx < (unsigned)W) ? ip[(size_t)yy * W + xx] : 0.0f;
             }
         }
     }
     float* op = out + (((size_t)b * O + o0) * H + y) * W + x;
 #pragma unroll 4
     for (int o = 0; o < THIN_OC; ++o) {
-        float acc = bias ? bias[o0 + o] : 0.0f;
+        float a0 = bias ? bias[o0 + o] : 0.0f, a1 = a0;
 #pragma unroll
         for (int i = 0; i < I; ++i)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(wl[o][i * 9 + t], win[i][t], acc);
-        op[(size_t)o * H * W] = relu ? thin_relu(acc) : acc;
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float wv = wl[o][i * 9 + r * 3 + q];
+                    a0 = __builtin_fmaf(wv, win[i][r][q], a0);
+                    a1 = __builtin_fmaf(wv, win[i][r][q + 1], a1);
+                }
+        if (relu) { a0 = thin_relu(a0); a1 = thin_relu(a1); }
+        *reinterpret_cast<float2*>(op + (size_t)o * H * W) = make_float2(a0, a1);
     }
 }
 
@@ -359,7 +367,8 @@ int ipsr_conv3x3_thin(int op, const float* in, const float* w, const float* bias
     if (op == 0) {          // few -> many
         if (O % THIN_OC != 0 || (I != 3 && I != 6)) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: few->many needs 3 or 6 inputs and outputs %% 16 == 0 (got %d -> %d)", I, O);
         if ((size_t)B * (O / THIN_OC) > 65535 || H > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: grid too large");
-        const dim3 grid(cdiv(W, 256), H, B * (O / THIN_OC));
+        if ((W & 1) || (reinterpret_cast<uintptr_t>(out) & 7u)) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: few->many needs an even width and an 8-byte aligned output (W=%d)", W);
+        const dim3 grid(cdiv(W, 512), H, B * (O / THIN_OC));
         if (I == 3) thin_f2m_kernel<3><<<grid, 256, 0, st>>>(in, w, bias, relu, out, B, O, H, W, so, si, flip);
         else thin_f2m_kernel<6><<<grid, 256, 0, st>>>(in, w, bias, relu, out, B, O, H, W, so, si, flip);
         return check_launch("thin_f2m_kernel");

@@ -628,7 +628,7 @@ def thin_supported(op, Cin, H, W, Cout):
     fwd = op in (CONV_FWD, CONVT_FWD)
     i, o = (Cin, Cout) if fwd else (Cout, Cin)
     if i in (3, 6) and o % 16 == 0 and o >= 16:
-        return True
+        return W % 2 == 0
     return o in (3, 6) and W % 4 == 0 and i * o * 36 <= 48 * 1024 and i >= 16
 
 
