@@ -120,7 +120,7 @@ def _select(mode, _nosm, op, B, Cin, H, W, Cout, k, stride, pad, dil):
         return "smallmap"        # innermost levels (<= 32 positions per batch): the weight tensor streamed once into MFMA operands
     if mode == "auto":
         g = _s2_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
-        if g is not None and _s2_wins(g, _s2_mode(op)) and ops.s2_winograd_supported(_s2_mode(op), B, *g):
+        if g is not None and _s2_wins(g, _s2_mode(op), B) and ops.s2_winograd_supported(_s2_mode(op), B, *g):
             return "wino_s2"     # 4x4 stride-2 layers: polyphase Winograd F(5x5,2x2)
     # auto: measured rules (MI355X, batch 8; profiles/r03_hipconv_k3.txt).  64 produced channels run on the GEMM's 64-row tile:
     # 64 -> 64 @256x256 (VGG conv1_2, forward and input gradient) 0.311 vs MIOpen's 0.378 ms
@@ -146,13 +146,15 @@ def _s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
     return Cout, Cin, H // 2, W // 2
 
 
-def _s2_wins(geom, mode=None):
+def _s2_wins(geom, mode=None, B=8):
     """Measured (profiles/r03_hipconv_k4s2.txt, batch 8): F(5x5,2x2) beats MIOpen by 5-35 % from 128 coarse / 64 fine channels up
     on coarse grids of 16..64; it loses on 8x8 and below (too few tiles).  The 64-channel 128x128 layer is transform bound: only
     its coarse-to-fine pass (ConvTranspose2d forward), whose output transform writes whole rows, is ahead (0.210 vs 0.226 ms)."""
     Kc, Cf, nh, nw = geom
     if mode == ops.S2_COARSE_TO_FINE and Kc >= 64 and Cf >= 64 and 16 <= min(nh, nw) and max(nh, nw) <= 128:
         return True
+    if mode == ops.S2_COARSE_TO_FINE and B >= 16 and Kc >= 512 and Cf >= 512 and min(nh, nw) == 8 and max(nh, nw) == 8:
+        return True          # netF's 512 -> 512 @16 -> 8 input gradient at batch 16 (the batched discriminator pass): 0.141 vs 0.188 ms
     return Kc >= 128 and Cf >= 64 and 16 <= min(nh, nw) and max(nh, nw) <= 64
 
 

@@ -621,6 +621,7 @@ def test_dispatcher_rules_and_refusals():
     assert sel(ops.CONVT_BWD_DATA, 8, 64, 128, 128, 64, 4, 2, 1, 1) == "miopen"          # the other two are transform bound
     assert hipconv.select_wrw(True, 8, 64, 128, 128, 64, 4, 2, 1, 1) == "miopen"
     assert sel(ops.CONV_FWD, 8, 512, 16, 16, 512, 4, 2, 1, 1) == "miopen"                # 8x8 coarse grid: too few tiles
+    assert sel(ops.CONV_BWD_DATA, 16, 512, 16, 16, 512, 4, 2, 1, 1) == "wino_s2" and sel(ops.CONV_BWD_DATA, 8, 512, 16, 16, 512, 4, 2, 1, 1) == "miopen"
     assert sel(ops.CONV_FWD, 8, 3, 256, 256, 64, 4, 2, 1, 1) == "miopen"                 # 3 input channels
     # innermost levels: the weight gradient of the 4x4 stride-2 layers as one GEMM that writes dW in place
     assert hipconv.select_wrw(False, 8, 512, 8, 8, 512, 4, 2, 1, 1) == "smallmap"        # netP down 512 -> 512 @8 -> 4
