@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks ITSELF: the parent — before any GPU call, and
+never touching the GPU afterwards — runs the second command above as a CHILD process (no exec), lets rank 0's JSON line through and
+exits with the child's status.  `--backend gloo` is a dry mode for machines without GPUs (launcher, argument plumbing, the bucketed
+gradient exchange and the N>1 reporting on small stand-in nets; no kernels, labelled `dry_run`).
+
 One "step" = the reference's training iteration (train.ipynb cell 2:24-27) on device-resident synthetic
 tensors of BASELINE.json config 2:  set_input + set_ref_latent + set_gt_latent + optimize_parameters,
 256x256, 128x128 centre hole (M = 256 masked feature positions), batch 8 per GPU, fp32, dropout on
@@ -262,6 +267,154 @@ def conv_roofline(args, ng, gsteps, gemm_ms, gemm_flops, gemm_useful):
             "flop_saving_vs_direct": "F(4x4,3x3) and F(3x3,4x4): 4.0x; polyphase F(5x5,2x2): 2.78x (per family, not applied here)"}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as a CHILD process and return its exit status.
+    Runs before this process has made any GPU call (importing torch makes none) and makes none afterwards: on this pool a process
+    that initialised the GPU must never exec, and N ranks + an idle parent holding the card would only cost memory."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # this pool's driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    print("[bench] --gpus %d without a torchrun environment: starting %s" % (n, " ".join(cmd[1:])), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env)                    # stdout / stderr inherited: rank 0's JSON line goes straight through
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait()
+
+
+def rccl_env():
+    return {k: v for k, v in sorted(os.environ.items())
+            if k.startswith(("NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "HSA_FORCE_FINE_GRAIN_PCIE", "OMP_NUM_THREADS")}
+
+
+def ddp_report(args, world, rank, device, elapsed, step_ms, reducers, backend):
+    """N > 1 only (collective: every rank calls it).  What the exchange looked like from every rank: the ranks the backend saw, each
+    rank's own time per step, and the EXPOSED part of the two gradient all-reduces — the time the compute stream waits in
+    GradBucketReducer.finish() after the backward's last kernel (HIP events on that stream; the rest ran under the backward)."""
+    import torch.distributed as dist
+    mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(),
+            "device": (torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu"),
+            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+            "ms_per_step_median": round(statistics.median(step_ms), 3) if step_ms else None}
+    for key, red in reducers.items():
+        ms = red.exposed_ms() if red is not None else []
+        ms = ms[-args.steps:] if args.steps else ms
+        mine["exposed_allreduce_ms_" + key] = round(statistics.mean(ms), 4) if ms else None
+    if device.type == "cuda":
+        mine["hbm_peak_allocated_gb"] = round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank != 0:
+        return None
+    exp = {k: [g.get("exposed_allreduce_ms_" + k) for g in gathered] for k in reducers}
+    return {"backend": backend + (" (RCCL)" if backend == "nccl" else " (CPU dry mode)"), "world_size_seen": dist.get_world_size(),
+            "ranks": gathered,
+            "exposed_allreduce_ms_per_step": {k: {"max_over_ranks": max(v) if all(x is not None for x in v) else None,
+                                                  "mean_over_ranks": round(statistics.mean(v), 4) if all(x is not None for x in v) else None}
+                                              for k, v in exp.items()},
+            "allreduce_bytes_per_step": {k: (red.bytes_per_exchange() if red is not None else None) for k, red in reducers.items()},
+            "buckets": {k: (len(red.buckets) if red is not None else None) for k, red in reducers.items()},
+            "bucket_mb": args.ddp_bucket_mb, "env": rccl_env()}
+
+
+def dry_run(args):
+    """`--backend gloo`: everything of the N>1 path that is not a kernel — rendezvous from the torchrun environment, rank-0 broadcast,
+    two bucketed gradient exchanges per step ((D,F) then (G,P), as models/IPSR.py orders them) on small stand-in nets, the barrier /
+    max-over-ranks timing and the N>1 report — on the CPU.  The line says `dry_run`; its `value` is not a measurement of anything."""
+    import torch.nn as nn
+    from deepinpainting_amd import dist as idist
+    rank, world, _ = idist.init_distributed(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    device = torch.device("cpu")
+    torch.manual_seed(1234 + rank)                   # different init per rank: the broadcast has to make them equal
+
+    def net(cin, cout):
+        return nn.Sequential(nn.Conv2d(cin, 16, 3, padding=1), nn.InstanceNorm2d(16, affine=True), nn.ReLU(), nn.Conv2d(16, cout, 3, padding=1))
+    nets = {"G": net(6, 3), "P": net(3, 3), "D": net(3, 1), "F": net(3, 1)}
+    for m in nets.values():
+        idist.broadcast_module(m, src=0)
+    reducers = {"D": idist.GradBucketReducer([nets["D"], nets["F"]], bucket_bytes=2048),
+                "G": idist.GradBucketReducer([nets["G"], nets["P"]], bucket_bytes=2048)}
+    for r in reducers.values():
+        r.timing = True
+    opts = {k: torch.optim.SGD(m.parameters(), lr=1e-2) for k, m in nets.items()}
+    g = torch.Generator().manual_seed(99 + rank)
+    img = torch.rand(args.batch, 3, 16, 16, generator=g)
+
+    def step():
+        fake_p = nets["P"](img)
+        fake = nets["G"](torch.cat((fake_p, img), 1))
+        for k in ("D", "F"):
+            opts[k].zero_grad()
+        reducers["D"].arm()
+        (nets["D"](fake.detach()).pow(2).mean() + nets["F"](img).pow(2).mean()).backward()
+        reducers["D"].finish()
+        for k in ("D", "F"):
+            opts[k].step()
+        for k in ("G", "P"):
+            opts[k].zero_grad()
+        frozen = [p for k in ("D", "F") for p in nets[k].parameters()]
+        for p in frozen:
+            p.requires_grad_(False)
+        reducers["G"].arm()
+        ((fake - img).abs().mean() + nets["D"](fake).pow(2).mean()).backward()
+        reducers["G"].finish()
+        for p in frozen:
+            p.requires_grad_(True)
+        for k in ("G", "P"):
+            opts[k].step()
+    for _ in range(args.warmup):
+        step()
+    for r in reducers.values():
+        r.exposed_ms()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    step_ms = []
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        step()
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    flat = torch.cat([p.detach().reshape(-1) for m in nets.values() for p in m.parameters()])
+    ddp = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ddp = ddp_report(args, world, rank, device, elapsed, step_ms, reducers, "gloo")
+        elapsed = float(t.item())
+        lo, hi = flat.clone(), flat.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
+    else:
+        in_sync = True
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": round(args.batch * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "dry_run": True,
+                          "config": {"workload": "DRY RUN (--backend gloo): stand-in nets on the CPU, no HIP kernels — launcher, rendezvous, gradient "
+                                                 "exchange and reporting of the N>1 path only; not a measurement",
+                                     "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+                          "weights_identical_on_all_ranks_after_the_steps": in_sync, "ddp": ddp}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0 if in_sync else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,7 +432,15 @@ def main():
                     help="arithmetic of the Winograd convolution GEMMs for fp32 activations (default fp32 = the reference's; the split-bf16 "
                          "forms are reported as what they are, never as the headline)")
     ap.add_argument("--debug-opt", action="append", default=[], help="key=value for ipsr_debug_set_option (kernel-variant A/B; never set by default)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL over xGMI (the measurement); gloo = DRY MODE on the CPU: launcher + argument plumbing + the "
+                         "gradient exchange on stand-in nets, no kernels (tests/test_bench_launcher.py)")
+    ap.add_argument("--ddp-bucket-mb", type=int, default=64, help="gradient bucket size of the all-reduce (dist.GradBucketReducer)")
     args = ap.parse_args()
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.backend == "gloo":
+        return dry_run(args)
     if args.debug_opt:
         from deepinpainting_amd import _lib as _dbg_lib
         for kv in args.debug_opt:
@@ -292,6 +453,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the IPSR layer has no CPU path (the CPU twin is only the reported baseline)")
+    # the device is chosen from the launcher's LOCAL_RANK before the communicator exists; init_distributed sets it again for nccl
     rank, world, local_rank = idist.init_distributed(backend="nccl", rccl_algo=args.rccl_algo, rccl_proto=args.rccl_proto,
                                                         rccl_channels=args.rccl_min_channels)
     if world != args.gpus:
@@ -305,9 +467,13 @@ def main():
 
     opt = Option(gpu_ids=[local_rank], batchSize=args.batch, use_dropout=True, quiet=True, allow_random_vgg=True,
                  batch_vgg=os.environ.get("IPSR_BENCH_BATCH_VGG", "0") == "1", batch_disc=os.environ.get("IPSR_BENCH_BATCH_DISC", "1") == "1", amp_bf16=(args.dtype == "bf16"), conv_math=args.conv_math,
-                 checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
+                 ddp_bucket_mb=args.ddp_bucket_mb, checkpoints_dir=os.path.join("/tmp", "ipsr_bench_ckpt_%d" % rank))
     torch.manual_seed(1234)                       # identical init on every rank (rank 0 is broadcast anyway)
     model = quiet(create_model, opt)
+    reducers = {"D": model._reducer_D, "G": model._reducer_G}
+    for red in reducers.values():
+        if red is not None:
+            red.timing = world > 1
     cl = os.environ.get("IPSR_BENCH_CHANNELS_LAST", "0")             # experiment knob, not the default: "1" = all nets,
     if cl != "0":                                                    # or a comma list of netG,netP,netD,netF,vgg
         names = ("netG", "netP", "netD", "netF", "vgg") if cl == "1" else tuple(cl.split(","))
@@ -327,6 +493,9 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    for red in reducers.values():
+        if red is not None:
+            red.exposed_ms()                      # drop the warm-up steps' records
     lib.ipsr_profile_enable(max(args.steps, 1))
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
@@ -344,6 +513,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+    ddp = ddp_report(args, world, rank, device, elapsed, step_ms, reducers, "nccl") if world > 1 else None
+    for red in reducers.values():
+        if red is not None:
+            red.timing = False
 
     def read_region(region):
         buf = (ctypes.c_float * max(args.steps, 1))()
@@ -500,6 +673,7 @@ def main():
         if args.dtype == "f32" else None,
         "alt_arithmetic": alt,
         "strict_reference": strict,
+        "ddp": ddp,
         "losses_last_step": {k: round(v, 4) for k, v in errs.items()},
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -511,4 +685,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

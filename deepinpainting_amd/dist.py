@@ -128,6 +128,11 @@ class GradBucketReducer(object):
         self._pending = None
         self._work = []
         self._hooks = []
+        # measurement (bench.py --gpus N): with `timing` on, finish() brackets its waits — HIP events on the current stream for
+        # device buckets (work.wait() makes THAT stream wait for the collective, so the bracket is the time the compute stream
+        # stalls after the backward's last kernel: the EXPOSED part of the all-reduce), the host clock for CPU buckets (gloo)
+        self.timing = False
+        self._exposed = []
         if self.world > 1:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -210,9 +215,10 @@ class GradBucketReducer(object):
         if not self.armed:
             return
         launched = {bi for bi, _, _ in self._work}
-        for bi in range(len(self.buckets)):
-            if bi not in launched:
-                self._launch(bi)
+        late = [bi for bi in range(len(self.buckets)) if bi not in launched]
+        mark = self._timing_mark() if self.timing else None
+        for bi in late:
+            self._launch(bi)
         for bi, work, views in self._work:
             work.wait()
             # the rank-averaged gradients stay where the collective left them: .grad becomes a view of the bucket (no copy
@@ -222,11 +228,39 @@ class GradBucketReducer(object):
             # ever without a gradient in optimize_parameters(), so the trainer is unaffected.
             for p, v in zip(self.buckets[bi]["params"], views):
                 p.grad = v
+        if mark is not None:
+            self._exposed.append((mark, self._timing_mark(), len(late)))
         self._work = []
         self.armed = False
         for b in self.buckets:
             for p in b["params"]:
                 _GRAD_SINKS.pop(p.data_ptr(), None)
+
+    def _timing_mark(self):
+        dev = self.buckets[0]["params"][0].device if self.buckets else torch.device("cpu")
+        if dev.type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(dev))
+            return ev
+        import time
+        return time.perf_counter()
+
+    def exposed_ms(self, reset=True):
+        """Per finish() call since the last reset: milliseconds the consumer waited for the collectives after the backward
+        (see `timing`).  Synchronises the device."""
+        out = []
+        for a, b, _ in self._exposed:
+            if isinstance(a, float):
+                out.append((b - a) * 1e3)
+            else:
+                b.synchronize()
+                out.append(a.elapsed_time(b))
+        if reset:
+            self._exposed = []
+        return out
+
+    def bytes_per_exchange(self):
+        return sum(4 * b["numel"] for b in self.buckets)
 
     def close(self):
         for h in self._hooks:
