@@ -43,21 +43,21 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     "ipsr_cat_relu_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ipsr_cat_relu_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "ipsr_bias_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "ipsr_bias_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "ipsr_bias_relu_pool2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ipsr_instnorm_act_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_int, c_int, c_int, c_int,
-                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ipsr_instnorm_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
-                                           c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ipsr_bias_act_skip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]),
+                                           c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ipsr_bias_act_skip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "ipsr_bias_act_backward_skip": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                            c_void_p]),
+                                            c_void_p, c_void_p]),
     "ipsr_instnorm_act_forward_slice": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_float, c_int, c_int, c_int, c_int,
-                                                c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+                                                c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ipsr_instnorm_act_backward_slice": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
-                                                 c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                                 c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ipsr_bias_act_backward": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                       c_void_p]),
+                                       c_void_p, c_void_p]),
     "ipsr_conv2d_workspace_bytes": (c_size_t, [c_int] * 10),
     "ipsr_conv2d": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_void_p, c_size_t, c_void_p]),

@@ -416,22 +416,22 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
 
 static inline bool aligned_io(const void* p, int io_bf16) { return (reinterpret_cast<uintptr_t>(p) & (io_bf16 ? 7u : 15u)) == 0; }
 
-int ipsr_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* stream)
+int ipsr_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, unsigned* tickets, void* stream)
 {
     if (!x) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: null pointer");
     if (B < 1 || C < 1 || HW < 1) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: bad size B=%d C=%d HW=%d", B, C, HW);
     if ((HW & 3) == 0 && !aligned_io(x, io_bf16)) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: x is not vector aligned");
-    return launch_bias_act(x, bias, B, C, HW, act, slope, io_bf16, nullptr, 0, static_cast<hipStream_t>(stream));
+    return launch_bias_act(x, bias, B, C, HW, act, slope, io_bf16, nullptr, 0, tickets, static_cast<hipStream_t>(stream));
 }
 
 int ipsr_bias_act_skip(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* y2, size_t y2_batch_stride,
-                       void* stream)
+                       unsigned* tickets, void* stream)
 {
     if (!x || !y2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_skip: null pointer");
     if (B < 1 || C < 1 || HW < 1 || y2_batch_stride < (size_t)C * HW) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_skip: bad size B=%d C=%d HW=%d", B, C, HW);
     if ((HW & 3) == 0 && (!aligned_io(x, io_bf16) || !aligned_io(y2, io_bf16) || (y2_batch_stride & 3)))
         return fail(IPSR_ERR_INVALID, "ipsr_bias_act_skip: tensors are not vector aligned");
-    return launch_bias_act(x, bias, B, C, HW, act, slope, io_bf16, y2, y2_batch_stride, static_cast<hipStream_t>(stream));
+    return launch_bias_act(x, bias, B, C, HW, act, slope, io_bf16, y2, y2_batch_stride, tickets, static_cast<hipStream_t>(stream));
 }
 
 int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, void* stream)
@@ -461,43 +461,43 @@ int ipsr_cat_relu_backward(const void* grad_out, const void* out, int B, int C1,
 }
 
 int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
-                              int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, void* stream)
+                              int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, unsigned* tickets, void* stream)
 {
     if (!x || !y || !mean || !rstd) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: null pointer");
     if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: bad argument B=%d C=%d HW=%d act=%d", B, C, HW, act);
     if ((HW & 3) == 0 && (!aligned_io(x, io_bf16) || !aligned_io(y, io_bf16))) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward: x/y are not vector aligned");
-    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, io_bf16, y, mean, rstd, 0, nullptr, 0, static_cast<hipStream_t>(stream));
+    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, io_bf16, y, mean, rstd, 0, nullptr, 0, tickets, static_cast<hipStream_t>(stream));
 }
 
 int ipsr_instnorm_act_forward_slice(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
                                     int B, int C, int HW, int io_bf16, void* y, size_t y_batch_stride, void* y2, size_t y2_batch_stride,
-                                    float* mean, float* rstd, void* stream)
+                                    float* mean, float* rstd, unsigned* tickets, void* stream)
 {
     if (!x || !y || !mean || !rstd) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward_slice: null pointer");
     if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2 || y_batch_stride < (size_t)C * HW || (y2 && y2_batch_stride < (size_t)C * HW))
         return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward_slice: bad argument B=%d C=%d HW=%d act=%d stride=%zu", B, C, HW, act, y_batch_stride);
     if ((HW & 3) == 0 && (!aligned_io(x, io_bf16) || !aligned_io(y, io_bf16) || (y_batch_stride & 3) || !aligned_io(y2, io_bf16) || (y2_batch_stride & 3)))
         return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_forward_slice: x/y are not vector aligned");
-    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, io_bf16, y, mean, rstd, y_batch_stride, y2, y2_batch_stride,
+    return launch_instnorm_act_fwd(x, bias, gamma, beta, eps, act, slope, B, C, HW, io_bf16, y, mean, rstd, y_batch_stride, y2, y2_batch_stride, tickets,
                                    static_cast<hipStream_t>(stream));
 }
 
 int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, const float* bias, const float* gamma,
                                const float* mean, const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16,
-                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream)
+                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, unsigned* tickets, void* stream)
 {
     if (!dy || !y || !x || !mean || !rstd || !dx) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: null pointer");
     if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: bad argument");
     if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(x, io_bf16) || !aligned_io(dx, io_bf16)))
         return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: tensors are not vector aligned");
-    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p, sums, 0, 0, nullptr, 0,
+    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p, sums, tickets, 0, 0, nullptr, 0,
                                    static_cast<hipStream_t>(stream));
 }
 
 int ipsr_instnorm_act_backward_slice(const void* dy, size_t dy_batch_stride, const void* dy2, size_t dy2_batch_stride, const void* y,
                                      size_t y_batch_stride, const void* x, const float* bias,
                                      const float* gamma, const float* mean, const float* rstd, int act, float slope, int B, int C, int HW,
-                                     int io_bf16, void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream)
+                                     int io_bf16, void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, unsigned* tickets, void* stream)
 {
     if (!dy || !y || !x || !mean || !rstd || !dx) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward_slice: null pointer");
     if (B < 1 || C < 1 || HW < 2 || act < 0 || act > 2 || dy_batch_stride < (size_t)C * HW || y_batch_stride < (size_t)C * HW ||
@@ -506,28 +506,28 @@ int ipsr_instnorm_act_backward_slice(const void* dy, size_t dy_batch_stride, con
     if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(x, io_bf16) || !aligned_io(dx, io_bf16) ||
                           !aligned_io(dy2, io_bf16) || ((dy_batch_stride | y_batch_stride | dy2_batch_stride) & 3)))
         return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward_slice: tensors are not vector aligned");
-    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p, sums,
+    return launch_instnorm_act_bwd(dy, y, x, bias, gamma, mean, rstd, act, slope, B, C, HW, io_bf16, dx, dgamma_p, dbeta_p, dbias_p, sums, tickets,
                                    dy_batch_stride, y_batch_stride, dy2, dy2_batch_stride, static_cast<hipStream_t>(stream));
 }
 
 int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx,
-                           float* dbias_p, float* sums, void* stream)
+                           float* dbias_p, float* sums, unsigned* tickets, void* stream)
 {
     if (!dy || !y || !dx) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: null pointer");
     if (B < 1 || C < 1 || HW < 1 || act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: bad argument");
     if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(dx, io_bf16)))
         return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: tensors are not vector aligned");
-    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, sums, nullptr, 0, static_cast<hipStream_t>(stream));
+    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, sums, tickets, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
 int ipsr_bias_act_backward_skip(const void* dy, const void* dy2, size_t dy2_batch_stride, const void* y, int act, float slope, int B, int C, int HW,
-                                int io_bf16, void* dx, float* dbias_p, float* sums, void* stream)
+                                int io_bf16, void* dx, float* dbias_p, float* sums, unsigned* tickets, void* stream)
 {
     if (!dy || !dy2 || !y || !dx) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward_skip: null pointer");
     if (B < 1 || C < 1 || HW < 1 || act < 0 || act > 2 || dy2_batch_stride < (size_t)C * HW) return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward_skip: bad argument");
     if ((HW & 3) == 0 && (!aligned_io(dy, io_bf16) || !aligned_io(dy2, io_bf16) || !aligned_io(y, io_bf16) || !aligned_io(dx, io_bf16) || (dy2_batch_stride & 3)))
         return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward_skip: tensors are not vector aligned");
-    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, sums, dy2, dy2_batch_stride, static_cast<hipStream_t>(stream));
+    return launch_bias_act_bwd(dy, y, act, slope, B, C, HW, io_bf16, dx, dbias_p, sums, tickets, dy2, dy2_batch_stride, static_cast<hipStream_t>(stream));
 }
 
 size_t innercos_workspace_bytes(int B, int Cuse, int N) { return innercos_ws_bytes(B, Cuse, N); }

@@ -15,7 +15,6 @@
 // the reference's nets at 256x256 (netG's outermost level, 64 x 256 x 256) takes 512 threads x 128 elements per plane.
 // fp32 tolerance vs torch (different summation order): ~1e-6 relative, asserted in tests/test_gpu_model.py.
 #include "ipsr_common.h"
-#include <atomic>
 
 namespace ipsr {
 
@@ -35,10 +34,11 @@ __device__ __forceinline__ float block_sum(float v, float* red)
     return t;
 }
 
-// Per-channel tickets for the batch reduction.  A launch takes one row of the pool (round robin on the host), so launches that
-// overlap on different streams do not share counters; the plane that draws ticket B-1 resets the counter for the next user.
-constexpr int TICKET_POOL = 32, TICKET_MAXC = 2048;
-__device__ unsigned g_tickets[TICKET_POOL][TICKET_MAXC];
+// Per-channel tickets for the batch reduction: C words of CALLER memory (the library keeps no device state).  They must be zero when
+// a backward launch starts — the matching FORWARD entry point zeroes them (plane b = 0 of every channel; the forward always precedes its
+// backward on the stream) — and the plane that draws ticket B-1 puts the zero back, so a second backward over the same node
+// (retain_graph) finds them ready.  Every node of the graph owns its words: launches that overlap on other streams cannot alias, and
+// a launch that died leaves nothing behind for anybody else.
 
 // Store a plane's partial so that another XCD can read it: a device-scope (write-through) store — NOT a device-scope release
 // fence, which on this chip writes back the whole L2 (measured: +100 us per launch when every plane's workgroup did one).
@@ -89,10 +89,11 @@ __global__ void __launch_bounds__(T) instnorm_act_fwd_kernel(const IO* __restric
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, int act, float slope, int C, int HW,
                                                              IO* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                             size_t y_bstride, IO* __restrict__ y2, size_t y2_bstride)
+                                                             size_t y_bstride, IO* __restrict__ y2, size_t y2_bstride, unsigned* __restrict__ tickets)
 {
     __shared__ float red[16];
     const int plane = blockIdx.x, c = plane % C, tid = threadIdx.x;
+    if (tickets && tid == 0 && plane < C) tickets[plane] = 0u;          // the backward's per-channel counters start from zero
     const float bv = bias ? bias[c] : 0.0f;
     const IO* xp = x + (size_t)plane * HW;
     IO* yp = y + (size_t)(plane / C) * y_bstride + (size_t)c * HW;      // y may be a channel slice of a wider tensor (skip concatenation)
@@ -335,16 +336,6 @@ __global__ void __launch_bounds__(256) bias_act_bwd_kernel(const IO* __restrict_
     }
 }
 
-// one row of the ticket pool per launch; null when the caller wants the partials only
-static unsigned* next_ticket_row(const float* sums)
-{
-    static std::atomic<unsigned> turn{0};
-    if (!sums) return nullptr;
-    unsigned* base = nullptr;
-    if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
-    return base + (size_t)(turn.fetch_add(1) % TICKET_POOL) * TICKET_MAXC;
-}
-
 constexpr int IN_MAX_HW = 65536;       // 256 x 256: the outermost norm of netG (planes above 16384 must be vector aligned)
 constexpr int IN_MAX_HW_REG = 16384;   // largest plane a 256-thread workgroup holds in registers
 
@@ -359,7 +350,8 @@ constexpr int IN_MAX_HW_REG = 16384;   // largest plane a 256-thread workgroup h
     } while (0)
 
 int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
-                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, size_t ybs, void* y2, size_t y2bs, hipStream_t st)
+                            int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, size_t ybs, void* y2, size_t y2bs, unsigned* tickets,
+                            hipStream_t st)
 {
     if (ybs == 0) ybs = (size_t)C * HW;
     if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: plane of %d elements > %d", HW, IN_MAX_HW);
@@ -368,31 +360,31 @@ int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma
         if (HW & 3) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_forward: a plane of %d elements (> %d) must be a multiple of 4", HW, IN_MAX_HW_REG);
         if (io_bf16)
             instnorm_act_fwd_kernel<bf16_t, 512, 128, true><<<planes, 512, 0, st>>>(static_cast<const bf16_t*>(x), bias, gamma, beta, eps, act, slope,
-                                                                                   C, HW, static_cast<bf16_t*>(y), mean, rstd, ybs, static_cast<bf16_t*>(y2), y2bs);
+                                                                                   C, HW, static_cast<bf16_t*>(y), mean, rstd, ybs, static_cast<bf16_t*>(y2), y2bs, tickets);
         else
             instnorm_act_fwd_kernel<float, 512, 128, true><<<planes, 512, 0, st>>>(static_cast<const float*>(x), bias, gamma, beta, eps, act, slope,
-                                                                                  C, HW, static_cast<float*>(y), mean, rstd, ybs, static_cast<float*>(y2), y2bs);
+                                                                                  C, HW, static_cast<float*>(y), mean, rstd, ybs, static_cast<float*>(y2), y2bs, tickets);
         return check_launch("instnorm_act_fwd_kernel");
     }
     if (io_bf16)
         IN_DISPATCH(instnorm_act_fwd_kernel, bf16_t, static_cast<const bf16_t*>(x), bias, gamma, beta, eps, act, slope, C, HW,
-                    static_cast<bf16_t*>(y), mean, rstd, ybs, static_cast<bf16_t*>(y2), y2bs);
+                    static_cast<bf16_t*>(y), mean, rstd, ybs, static_cast<bf16_t*>(y2), y2bs, tickets);
     else
         IN_DISPATCH(instnorm_act_fwd_kernel, float, static_cast<const float*>(x), bias, gamma, beta, eps, act, slope, C, HW,
-                    static_cast<float*>(y), mean, rstd, ybs, static_cast<float*>(y2), y2bs);
+                    static_cast<float*>(y), mean, rstd, ybs, static_cast<float*>(y2), y2bs, tickets);
     return check_launch("instnorm_act_fwd_kernel");
 }
 
 int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const float* bias, const float* gamma, const float* mean,
                             const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dgamma_p,
-                            float* dbeta_p, float* dbias_p, float* sums, size_t dybs, size_t ybs, const void* dy2, size_t dy2bs, hipStream_t st)
+                            float* dbeta_p, float* dbias_p, float* sums, unsigned* ticket, size_t dybs, size_t ybs, const void* dy2, size_t dy2bs,
+                            hipStream_t st)
 {
     if (dybs == 0) dybs = (size_t)C * HW;
     if (ybs == 0) ybs = (size_t)C * HW;
     if (HW > IN_MAX_HW) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: plane of %d elements > %d", HW, IN_MAX_HW);
-    if (sums && C > TICKET_MAXC) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: batch sums for %d channels > %d", C, TICKET_MAXC);
-    unsigned* ticket = next_ticket_row(sums);
-    if (sums && !ticket) return fail(IPSR_ERR_LAUNCH, "ipsr_instnorm_act_backward: ticket pool address");
+    if (sums && !ticket) return fail(IPSR_ERR_INVALID, "ipsr_instnorm_act_backward: batch sums need the C ticket words the forward entry point zeroed");
+    if (!sums) ticket = nullptr;
     const int planes = B * C;
     if (HW > IN_MAX_HW_REG) {
         if (HW & 3) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_instnorm_act_backward: a plane of %d elements (> %d) must be a multiple of 4", HW, IN_MAX_HW_REG);
@@ -416,11 +408,11 @@ int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const 
 }
 
 int launch_bias_act_bwd(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dbias_p,
-                        float* sums, const void* dy2, size_t dy2bs, hipStream_t st)
+                        float* sums, unsigned* ticket, const void* dy2, size_t dy2bs, hipStream_t st)
 {
-    if (sums && (C > TICKET_MAXC || !dbias_p)) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_bias_act_backward: batch sums need the partials and <= %d channels", TICKET_MAXC);
-    unsigned* ticket = next_ticket_row(sums);
-    if (sums && !ticket) return fail(IPSR_ERR_LAUNCH, "ipsr_bias_act_backward: ticket pool address");
+    if (sums && (!dbias_p || !ticket))
+        return fail(IPSR_ERR_INVALID, "ipsr_bias_act_backward: batch sums need the partials and the C ticket words ipsr_bias_act zeroed");
+    if (!sums) ticket = nullptr;
     if (io_bf16)
         bias_act_bwd_kernel<bf16_t><<<B * C, 256, 0, st>>>(static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(y), act, slope, HW,
                                                            static_cast<bf16_t*>(dx), dbias_p, C, sums, ticket, static_cast<const bf16_t*>(dy2), dy2bs);

@@ -202,7 +202,7 @@ int launch_backward(const float* g, const int32_t* mpi, int M, const float* attn
 
 // pointwise.hip — VGG16 feature net glue (bias / ReLU / 2x2 max-pool in one pass)
 int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* y2, size_t y2_bstride,
-                    hipStream_t st);
+                    unsigned* tickets, hipStream_t st);
 int launch_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, hipStream_t st);
 int launch_cat_relu_fwd(const void* y, const void* x, int B, int C1, int C2, int HW, int io_bf16, void* out, hipStream_t st);
 int launch_cat_relu_bwd(const void* g, const void* out, int B, int C1, int C2, int HW, int io_bf16, void* dy, void* dx, hipStream_t st);
@@ -210,13 +210,13 @@ int launch_cat_relu_bwd(const void* g, const void* out, int B, int C1, int C2, i
 // instnorm.hip — conv-bias + InstanceNorm2d + activation, fused forward / backward (one (sample, channel) plane per workgroup)
 int launch_instnorm_act_fwd(const void* x, const float* bias, const float* gamma, const float* beta, float eps, int act, float slope,
                             int B, int C, int HW, int io_bf16, void* y, float* mean, float* rstd, size_t y_bstride, void* y2, size_t y2_bstride,
-                            hipStream_t st);
+                            unsigned* tickets, hipStream_t st);
 int launch_instnorm_act_bwd(const void* dy, const void* y, const void* x, const float* bias, const float* gamma, const float* mean,
                             const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dgamma_p,
-                            float* dbeta_p, float* dbias_p, float* sums, size_t dy_bstride, size_t y_bstride, const void* dy2, size_t dy2_bstride,
-                            hipStream_t st);
+                            float* dbeta_p, float* dbias_p, float* sums, unsigned* tickets, size_t dy_bstride, size_t y_bstride, const void* dy2,
+                            size_t dy2_bstride, hipStream_t st);
 int launch_bias_act_bwd(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16, void* dx, float* dbias_p,
-                        float* sums, const void* dy2, size_t dy2_bstride, hipStream_t st);
+                        float* sums, unsigned* tickets, const void* dy2, size_t dy2_bstride, hipStream_t st);
 
 size_t innercos_ws_bytes(int B, int Cuse, int N);
 int launch_innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,

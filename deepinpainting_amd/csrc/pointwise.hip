@@ -28,9 +28,11 @@ __device__ __forceinline__ float act_apply(float v, float slope)
 // channel slice given by its batch stride.
 template <typename IO, int ACT>
 __global__ void __launch_bounds__(256) bias_act_kernel(IO* __restrict__ x, const float* __restrict__ bias, int C, int HW, float slope,
-                                                       IO* __restrict__ y2, size_t y2_bstride)
+                                                       IO* __restrict__ y2, size_t y2_bstride, unsigned* __restrict__ tickets)
 {
     const int plane = blockIdx.y;                       // b*C + c
+    // the per-channel counters of the matching backward's in-launch batch sum (instnorm.hip) start from zero
+    if (tickets && blockIdx.x == 0 && threadIdx.x == 0 && plane < C) tickets[plane] = 0u;
     const float bv = bias ? bias[plane % C] : 0.0f;
     IO* p = x + (size_t)plane * HW;
     IO* q = y2 ? y2 + (size_t)(plane / C) * y2_bstride + (size_t)(plane % C) * HW : nullptr;
@@ -163,7 +165,8 @@ int launch_cat_relu_bwd(const void* g, const void* out, int B, int C1, int C2, i
     return check_launch("cat_relu_bwd_kernel");
 }
 
-int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* y2, size_t y2bs, hipStream_t st)
+int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* y2, size_t y2bs, unsigned* tickets,
+                    hipStream_t st)
 {
     const int planes = B * C;
     if (planes > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_bias_act: B*C=%d > 65535 planes", planes);
@@ -174,9 +177,9 @@ int launch_bias_act(void* x, const float* bias, int B, int C, int HW, int act, f
     if (act < 0 || act > 2) return fail(IPSR_ERR_INVALID, "ipsr_bias_act: unknown activation %d", act);
 #define BA_LAUNCH(IO)                                                                                         \
     switch (act) {                                                                                            \
-        case 0: bias_act_kernel<IO, 0><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope, static_cast<IO*>(y2), y2bs); break; \
-        case 1: bias_act_kernel<IO, 1><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope, static_cast<IO*>(y2), y2bs); break; \
-        default: bias_act_kernel<IO, 2><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope, static_cast<IO*>(y2), y2bs); break; \
+        case 0: bias_act_kernel<IO, 0><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope, static_cast<IO*>(y2), y2bs, tickets); break; \
+        case 1: bias_act_kernel<IO, 1><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope, static_cast<IO*>(y2), y2bs, tickets); break; \
+        default: bias_act_kernel<IO, 2><<<grid, 256, 0, st>>>(static_cast<IO*>(x), bias, C, HW, slope, static_cast<IO*>(y2), y2bs, tickets); break; \
     }
     if (io_bf16) { BA_LAUNCH(bf16_t) } else { BA_LAUNCH(float) }
 #undef BA_LAUNCH

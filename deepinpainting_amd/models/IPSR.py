@@ -21,7 +21,8 @@ What is new (none of it changes results):
     unused by the next optimize_parameters (:269-270) (same switch);
   * backward_D sends the fake and the real batch through netD (and netF) in ONE pass of 2B samples (`opt.batch_disc`, default on;
     the reference makes two passes, :196-199): same predictions, the weight gradients become one sum over 2B samples instead of
-    two sums added by autograd — fp32 summation order only (+2 % images/s);
+    two sums added by autograd — fp32 summation order only (+2 % images/s).  Only while the discriminators hold no batch-statistics
+    module (`opt.norm='batch'` puts BatchNorm2d there: the two passes are kept, `_disc_is_per_sample`);
   * bias / InstanceNorm / activation between the convolutions run as fused HIP kernels (models/fused.py), the frozen
     VGG's bias / ReLU / max-pool likewise (models/vgg16.py) — same values up to fp32 rounding;
   * data parallelism: with torch.distributed initialised (one process per GPU, RCCL) the gradients are
@@ -252,6 +253,18 @@ class IPSR(BaseModel):
         self.loss_valid = (self.criterionL1(self.fake_B, self.real_B) + self.criterionL1(self.fake_P, self.real_B)) * self.opt.lambda_A
         return OrderedDict([('GAN', self.loss_valid.data.item())])
 
+    def _disc_is_per_sample(self):
+        """The one-pass form of backward_D is the reference's arithmetic only while no module of netD / netF mixes samples:
+        with `opt.norm='batch'` (still accepted by get_norm_layer, and define_D's default in the reference, networks.py:97-116) a
+        BatchNorm2d would normalise fake and real with SHARED batch statistics and update its running statistics once instead of
+        twice — different predictions, losses and gradients.  Then the reference's two passes are made."""
+        ok = getattr(self, '_disc_per_sample', None)
+        if ok is None:
+            bn = torch.nn.modules.batchnorm._BatchNorm
+            ok = not any(isinstance(m, bn) for net in (self.netD, self.netF) for m in net.modules())
+            self._disc_per_sample = ok
+        return ok
+
     def backward_D(self):
         fake_AB = self.fake_B
         with torch.no_grad(), self._amp():
@@ -265,7 +278,7 @@ class IPSR(BaseModel):
         real_AB = self.real_B
 
         with self._amp():
-            if self.batch_disc and not self.strict_reference:
+            if self.batch_disc and not self.strict_reference and self._disc_is_per_sample():
                 # fake and real batch through each discriminator in ONE pass of 2B samples: InstanceNorm is per sample and the
                 # convolutions per sample, so every prediction is the same number; the weight gradients become one sum over 2B
                 # samples instead of two sums added by autograd (fp32 summation order, nothing else)

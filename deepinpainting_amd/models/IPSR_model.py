@@ -97,6 +97,13 @@ class IPSR_model(nn.Module):
                 cap = int(counts.max().item())      # one host read per new mask, off the per-forward path
             elif cap == "full":
                 cap = n_win
+            else:
+                # a caller-supplied bound is checked against the mask it is used with (the same one host read "auto" makes): the
+                # kernels clamp every count to the capacity, so a bound below the true count would silently drop masked positions
+                need = int(counts.max().item())
+                if need > int(cap):
+                    raise ValueError("IPSR_model.index_capacity = %d, but this mask has %d masked feature positions "
+                                     "(use 'auto', 'full' or a larger bound)" % (int(cap), need))
             cap = min(n_win, max(32, (int(cap) + 31) // 32 * 32))
             self._flag32, self._counts = flag32, counts
             self._mpi32 = mpi32[:, :cap].contiguous()          # entries past counts[b] are never read; the kernels size by `cap`

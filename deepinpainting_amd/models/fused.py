@@ -24,6 +24,14 @@ import torch.nn.functional as F
 from .. import ops
 
 
+def _ticket_words(x, bias):
+    """The per-channel arrival counters of the backward's in-launch bias-gradient sum: C words owned by THIS autograd node, zeroed by
+    the node's forward launch (csrc/instnorm.hip: the library keeps no device state)."""
+    if bias is None or not bias.requires_grad:
+        return None
+    return torch.empty(x.shape[1], dtype=torch.int32, device=x.device)
+
+
 class _InstNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, gamma, beta, eps, act, slope):
@@ -47,17 +55,18 @@ class _BiasAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, act, slope):
-        ops.bias_act_(x, bias, act, slope)
+        tickets = _ticket_words(x, bias)
+        ops.bias_act_(x, bias, act, slope, tickets=tickets)
         ctx.mark_dirty(x)
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, tickets)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias = bias is not None
         return x
 
     @staticmethod
     def backward(ctx, dy):
-        (y,) = ctx.saved_tensors
-        dx, dbias = ops.bias_act_backward(dy, y, ctx.act, ctx.slope, ctx.has_bias and ctx.needs_input_grad[1])
+        y, tickets = ctx.saved_tensors
+        dx, dbias = ops.bias_act_backward(dy, y, ctx.act, ctx.slope, ctx.has_bias and ctx.needs_input_grad[1], tickets=tickets)
         return dx, dbias, None, None
 
 
@@ -69,20 +78,21 @@ class _BiasActSkip(torch.autograd.Function):
     def forward(ctx, x, bias, act, slope, c1):
         B, C2 = x.shape[0], x.shape[1]
         buf = torch.empty((B, c1 + C2) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-        ops.bias_act_(x, bias, act, slope, relu_into=buf, relu_at=c1)
+        tickets = _ticket_words(x, bias)
+        ops.bias_act_(x, bias, act, slope, relu_into=buf, relu_at=c1, tickets=tickets)
         ctx.mark_dirty(x)
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, tickets)
         ctx.act, ctx.slope, ctx.c1 = act, slope, c1
         ctx.has_bias = bias is not None
         return x, buf
 
     @staticmethod
     def backward(ctx, dy, dbuf):
-        (y,) = ctx.saved_tensors
+        y, tickets = ctx.saved_tensors
         if dy is None:
             dy = torch.zeros_like(y)
         dx, dbias = ops.bias_act_backward(dy.contiguous(), y, ctx.act, ctx.slope, ctx.has_bias and ctx.needs_input_grad[1],
-                                          dy2=None if dbuf is None else dbuf.contiguous(), dy2_at=ctx.c1)
+                                          dy2=None if dbuf is None else dbuf.contiguous(), dy2_at=ctx.c1, tickets=tickets)
         return dx, dbias, None, None, None
 
 

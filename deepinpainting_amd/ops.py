@@ -233,25 +233,26 @@ def _f32(t):
     return None if t is None else _req(t, torch.float32, "parameter")
 
 
-def bias_act_(x, bias, act="relu", slope=0.2, relu_into=None, relu_at=0):
+def bias_act_(x, bias, act="relu", slope=0.2, relu_into=None, relu_at=0, tickets=None):
     """In place x[b,c,...] = act(x + bias[c]) on a contiguous fp32/bf16 [B,C,*] tensor.  act: none | relu | leaky.
     relu_into / relu_at: a contiguous [B,Ctot,H,W] tensor whose channels [relu_at, relu_at + C) also receive relu(x + bias) — the skip
-    half of the child level's concatenated tensor."""
+    half of the child level's concatenated tensor.  tickets: an int32 [C] tensor this launch zeroes for `bias_act_backward`'s in-launch
+    batch sum of the bias gradient (the arrival counters live in the caller's memory, one set per autograd node)."""
     if not x.is_contiguous():
         raise RuntimeError("bias_act_ works in place and needs a contiguous tensor")
     x, bf = _req_io(x, "x")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
     if relu_into is None:
-        _lib.check(_lib.lib().ipsr_bias_act(x.data_ptr(), _ptr(_f32(bias)), B, C, hw, ACT_CODE[act], float(slope), bf, _stream()),
+        _lib.check(_lib.lib().ipsr_bias_act(x.data_ptr(), _ptr(_f32(bias)), B, C, hw, ACT_CODE[act], float(slope), bf, _ptr(tickets), _stream()),
                    "ipsr_bias_act")
         return x
     _check_wide(relu_into, x, "bias_act_: `relu_into`")
     if relu_at < 0 or relu_at + C > relu_into.shape[1]:
         raise RuntimeError("bias_act_: channels [%d, %d) outside `relu_into` %s" % (relu_at, relu_at + C, tuple(relu_into.shape)))
     y2p, y2bs = _slot(relu_into, relu_at, hw)
-    _lib.check(_lib.lib().ipsr_bias_act_skip(x.data_ptr(), _ptr(_f32(bias)), B, C, hw, ACT_CODE[act], float(slope), bf, y2p, y2bs, _stream()),
-               "ipsr_bias_act_skip")
+    _lib.check(_lib.lib().ipsr_bias_act_skip(x.data_ptr(), _ptr(_f32(bias)), B, C, hw, ACT_CODE[act], float(slope), bf, y2p, y2bs, _ptr(tickets),
+                                             _stream()), "ipsr_bias_act_skip")
     return x
 
 
@@ -282,13 +283,14 @@ def instnorm_act_forward(x, bias, gamma, beta, eps, act, slope, into=None, into_
     x, bf = _req_io(x, "x")
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // (B * C)
-    mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    # one allocation: mean [B*C] | rstd [B*C] | the C ticket words of the backward's in-launch batch sums, zeroed by this launch
+    stats = torch.empty(2 * B * C + C, dtype=torch.float32, device=x.device)
+    mean, rstd, tickets = stats[:B * C], stats[B * C:2 * B * C], stats[2 * B * C:]
     if into is None and relu_into is None:
         y = torch.empty_like(x)
         _lib.check(_lib.lib().ipsr_instnorm_act_forward(x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps),
                                                         ACT_CODE[act], float(slope), B, C, hw, bf, y.data_ptr(), mean.data_ptr(),
-                                                        rstd.data_ptr(), _stream()), "ipsr_instnorm_act_forward")
+                                                        rstd.data_ptr(), tickets.data_ptr(), _stream()), "ipsr_instnorm_act_forward")
         return y, mean, rstd
     if into is not None:
         _check_wide(into, x, "instnorm_act_forward: `into`")
@@ -306,11 +308,20 @@ def instnorm_act_forward(x, bias, gamma, beta, eps, act, slope, into=None, into_
         y2p, y2bs = _slot(relu_into, relu_at, hw)
     _lib.check(_lib.lib().ipsr_instnorm_act_forward_slice(x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps),
                                                           ACT_CODE[act], float(slope), B, C, hw, bf, yp, ybs, y2p, y2bs,
-                                                          mean.data_ptr(), rstd.data_ptr(), _stream()), "ipsr_instnorm_act_forward_slice")
+                                                          mean.data_ptr(), rstd.data_ptr(), tickets.data_ptr(), _stream()),
+               "ipsr_instnorm_act_forward_slice")
     return y, mean, rstd
 
 
-SUMS_MAX_CHANNELS = 2048       # csrc/instnorm.hip TICKET_MAXC: widest layer whose batch sums come out of the backward launch itself
+def _tickets_behind(mean, rstd, B, C):
+    """The ticket words `instnorm_act_forward` allocated behind its statistics (and zeroed in its launch); statistics that came from
+    somewhere else get fresh zeroed words."""
+    n = B * C
+    if mean.dtype == torch.float32 and mean.numel() == n and rstd.numel() == n and rstd.data_ptr() == mean.data_ptr() + 4 * n \
+            and mean.untyped_storage().nbytes() - 4 * mean.storage_offset() >= 4 * (2 * n + C):
+        return mean.data_ptr() + 8 * n, None
+    t = torch.zeros(C, dtype=torch.int32, device=mean.device)
+    return t.data_ptr(), t
 
 
 def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_affine, need_bias, at=0, dy2=None, dy2_at=0):
@@ -324,13 +335,14 @@ def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_af
     dx = torch.empty_like(x)
     part = torch.empty((3, B, C), dtype=torch.float32, device=x.device)
     # the batch sums of the per-plane partials are written by the same launch (the last plane of each channel to finish)
-    sums = torch.empty((3, C), dtype=torch.float32, device=x.device) if C <= SUMS_MAX_CHANNELS else None
+    sums = torch.empty((3, C), dtype=torch.float32, device=x.device)
+    tick, _keep = _tickets_behind(mean, rstd, B, C)
     L = _lib.lib()
     if dy.shape[1] == C and y.shape[1] == C and dy2 is None:
         _lib.check(L.ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), _ptr(_f32(bias)), _ptr(_f32(gamma)),
                                                 mean.data_ptr(), rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
                                                 dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
-                                                _ptr(sums), _stream()), "ipsr_instnorm_act_backward")
+                                                _ptr(sums), tick, _stream()), "ipsr_instnorm_act_backward")
     else:
         _check_wide(dy, x, "instnorm_act_backward: grad_output")
         _check_wide(y, x, "instnorm_act_backward: output")
@@ -348,22 +360,25 @@ def instnorm_act_backward(dy, y, x, bias, gamma, mean, rstd, act, slope, need_af
         _lib.check(L.ipsr_instnorm_act_backward_slice(dyp, dybs, d2p, d2bs, yp, ybs, x.data_ptr(), _ptr(_f32(bias)),
                                                       _ptr(_f32(gamma)), mean.data_ptr(), rstd.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
                                                       dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
-                                                      _ptr(sums), _stream()), "ipsr_instnorm_act_backward_slice")
-    s = sums if sums is not None else part.sum(1)
+                                                      _ptr(sums), tick, _stream()), "ipsr_instnorm_act_backward_slice")
+    s = sums
     return dx, (s[0] if need_affine else None), (s[1] if need_affine else None), (s[2] if need_bias else None)
 
 
-def bias_act_backward(dy, y, act, slope, need_bias, dy2=None, dy2_at=0):
-    """dx = dy * act'(y) (+ dy2[:, dy2_at : dy2_at + C] * relu'(y): the gradient of bias_act_'s second output), dbias [C] | None."""
+def bias_act_backward(dy, y, act, slope, need_bias, dy2=None, dy2_at=0, tickets=None):
+    """dx = dy * act'(y) (+ dy2[:, dy2_at : dy2_at + C] * relu'(y): the gradient of bias_act_'s second output), dbias [C] | None.
+    tickets: the int32 [C] tensor the forward `bias_act_` zeroed (None: fresh zeroed words are allocated here)."""
     dy, bf = _req_io(dy.to(y.dtype), "grad_output")
     B, C = y.shape[0], y.shape[1]
     hw = y.numel() // (B * C)
     dx = torch.empty_like(y)
     part = torch.empty((B, C), dtype=torch.float32, device=y.device) if need_bias else None
-    sums = torch.empty(C, dtype=torch.float32, device=y.device) if need_bias and C <= SUMS_MAX_CHANNELS else None
+    sums = torch.empty(C, dtype=torch.float32, device=y.device) if need_bias else None
+    if need_bias and tickets is None:
+        tickets = torch.zeros(C, dtype=torch.int32, device=y.device)
     if dy2 is None:
         _lib.check(_lib.lib().ipsr_bias_act_backward(dy.data_ptr(), y.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf, dx.data_ptr(),
-                                                     _ptr(part), _ptr(sums), _stream()), "ipsr_bias_act_backward")
+                                                     _ptr(part), _ptr(sums), _ptr(tickets), _stream()), "ipsr_bias_act_backward")
     else:
         dy2, _ = _req_io(dy2.to(y.dtype), "second grad_output")
         _check_wide(dy2, y, "bias_act_backward: second grad_output")
@@ -371,8 +386,9 @@ def bias_act_backward(dy, y, act, slope, need_bias, dy2=None, dy2_at=0):
             raise RuntimeError("bias_act_backward: channels [%d, %d) outside the second gradient %s" % (dy2_at, dy2_at + C, tuple(dy2.shape)))
         d2p, d2bs = _slot(dy2, dy2_at, hw)
         _lib.check(_lib.lib().ipsr_bias_act_backward_skip(dy.data_ptr(), d2p, d2bs, y.data_ptr(), ACT_CODE[act], float(slope), B, C, hw, bf,
-                                                          dx.data_ptr(), _ptr(part), _ptr(sums), _stream()), "ipsr_bias_act_backward_skip")
-    return dx, ((sums if sums is not None else part.sum(0)) if need_bias else None)
+                                                          dx.data_ptr(), _ptr(part), _ptr(sums), _ptr(tickets), _stream()),
+                   "ipsr_bias_act_backward_skip")
+    return dx, (sums if need_bias else None)
 
 
 def cat_relu_forward(y, x):

@@ -163,7 +163,8 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
  * models/vgg16.py:6-37 (run three times per training step without gradients, models/IPSR.py:163,187,212-213):
  * the convolution is issued without bias and one pass does the rest, with the same arithmetic (bit-identical).
  *   ipsr_bias_act          in place  x[b,c,:] = act(x[b,c,:] + bias[c]);  act: 0 none, 1 ReLU, 2 LeakyReLU(slope);
- *                          bias may be NULL
+ *                          bias may be NULL.  `tickets` (NULL, or C words of caller memory): zeroed here for the matching
+ *                          ipsr_bias_act_backward's in-launch batch sum — see the norm entry points below
  *   ipsr_bias_relu_pool2   y[b,c,i,j] = max over the 2x2 window of relu(x + bias[c]);  y is [B,C,H/2,W/2]
  * io_bf16 (here and in the norm entry points below): 0 = the activation tensors are fp32, 1 = bf16 (BASELINE config 5:
  * convolutions under bf16 autocast); bias/gamma/beta, statistics and all arithmetic are fp32 either way. */
@@ -174,15 +175,15 @@ int ipsr_backward_patch(const float* grad_out, int M, const int32_t* bwd_index, 
 int ipsr_cat_relu_forward(const void* y, const void* x, int B, int C1, int C2, int HW, int io_bf16, void* out, void* stream);
 int ipsr_cat_relu_backward(const void* grad_out, const void* out, int B, int C1, int C2, int HW, int io_bf16,
                            void* dy, void* dx, void* stream);
-int ipsr_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* stream);
+int ipsr_bias_act(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, unsigned* tickets, void* stream);
 int ipsr_bias_relu_pool2(const void* x, const float* bias, int B, int C, int H, int W, int io_bf16, void* y, void* stream);
 /* ipsr_bias_act with a second output y2 = relu(x + bias), a C-channel slice (pointer to its first element + batch stride in
  * elements) of the child level's concatenated tensor, and the matching backward dx = dy * act'(y) + dy2 * relu'(y): the level-1
  * blocks of the U-Nets, whose input comes from a convolution without a norm (see the y2 / dy2 forms of the norm entry points). */
 int ipsr_bias_act_skip(void* x, const float* bias, int B, int C, int HW, int act, float slope, int io_bf16, void* y2, size_t y2_batch_stride,
-                       void* stream);
+                       unsigned* tickets, void* stream);
 int ipsr_bias_act_backward_skip(const void* dy, const void* dy2, size_t dy2_batch_stride, const void* y, int act, float slope, int B, int C, int HW,
-                                int io_bf16, void* dx, float* dbias_p, float* sums, void* stream);
+                                int io_bf16, void* dx, float* dbias_p, float* sums, unsigned* tickets, void* stream);
 
 /* ---- conv-bias + InstanceNorm2d + activation ------------------------------------------------------
  * replaces the chain  Conv2d/ConvTranspose2d bias add -> nn.InstanceNorm2d(affine) -> LeakyReLU(0.2)/ReLU  that follows
@@ -193,15 +194,19 @@ int ipsr_bias_act_backward_skip(const void* dy, const void* dy2, size_t dy2_batc
  *   backward: dx [B,C,HW]; per-plane partials dgamma_p/dbeta_p/dbias_p [B*C] (any may be NULL).  `sums` [3,C] (NULL = the
  *             caller sums the partials itself): sums[k][c] = sum over b = 0..B-1, in that order, of the k-th partial array
  *             (rows of a NULL array are left untouched) — written by the last of channel c's B planes to finish, inside the
- *             same launch; C <= 2048.  `y` is the forward OUTPUT (the activation's derivative is taken from its sign).
+ *             same launch.  `y` is the forward OUTPUT (the activation's derivative is taken from its sign).
+ *   tickets : the per-channel arrival counters of that in-launch sum — C 32-bit words of CALLER memory (the library keeps no
+ *             device state).  Pass the same words to the forward entry point, which zeroes them, and to the backward, which
+ *             needs them zero on entry and leaves them zero (a second backward over the same node finds them ready).  NULL in
+ *             the forward = not zeroed; a backward with `sums` and no tickets -> IPSR_ERR_INVALID.
  *   ipsr_bias_act_backward: backward of ipsr_bias_act: dx = dy * act'(y), dbias_p[b*C+c] = sum of dx over the plane;
  *             `sums` [C] as above (needs dbias_p). */
 int ipsr_instnorm_act_forward(const void* x, const float* bias, const float* gamma, const float* beta, float eps,
                               int act, float slope, int B, int C, int HW, int io_bf16,
-                              void* y, float* mean, float* rstd, void* stream);
+                              void* y, float* mean, float* rstd, unsigned* tickets, void* stream);
 int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, const float* bias, const float* gamma,
                                const float* mean, const float* rstd, int act, float slope, int B, int C, int HW, int io_bf16,
-                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream);
+                               void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, unsigned* tickets, void* stream);
 /* The `_slice` forms: y (forward) / dy and y (backward) are C channels of wider tensors — the output of a skip concatenation
  * torch.cat([y, x], 1) (models/networks.py:270-278) and its gradient — given by a pointer to their first element and their batch
  * strides in elements (>= C*HW); x, dx and the statistics stay dense.  With them a level's last normalisation writes straight into
@@ -211,14 +216,15 @@ int ipsr_instnorm_act_backward(const void* dy, const void* y, const void* x, con
  * its skip connection) then meet inside this backward, dz = dy * act'(y) + dy2 * relu'(y), instead of in an add kernel. */
 int ipsr_instnorm_act_forward_slice(const void* x, const float* bias, const float* gamma, const float* beta, float eps,
                                     int act, float slope, int B, int C, int HW, int io_bf16,
-                                    void* y, size_t y_batch_stride, void* y2, size_t y2_batch_stride, float* mean, float* rstd, void* stream);
+                                    void* y, size_t y_batch_stride, void* y2, size_t y2_batch_stride, float* mean, float* rstd, unsigned* tickets,
+                                    void* stream);
 int ipsr_instnorm_act_backward_slice(const void* dy, size_t dy_batch_stride, const void* dy2, size_t dy2_batch_stride,
                                      const void* y, size_t y_batch_stride, const void* x,
                                      const float* bias, const float* gamma, const float* mean, const float* rstd, int act, float slope,
                                      int B, int C, int HW, int io_bf16,
-                                     void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, void* stream);
+                                     void* dx, float* dgamma_p, float* dbeta_p, float* dbias_p, float* sums, unsigned* tickets, void* stream);
 int ipsr_bias_act_backward(const void* dy, const void* y, int act, float slope, int B, int C, int HW, int io_bf16,
-                           void* dx, float* dbias_p, float* sums, void* stream);
+                           void* dx, float* dbias_p, float* sums, unsigned* tickets, void* stream);
 
 /* ---- convolutions of the surrounding nets ---------------------------------------------------------------
  * replaces nn.Conv2d / nn.ConvTranspose2d (bias-free part; the bias rides in the fused epilogues above) of the U-Nets,

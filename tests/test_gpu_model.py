@@ -926,8 +926,10 @@ def test_fused_instnorm_act_vs_torch(shape, act, affine, with_bias):
 @pytest.mark.parametrize("shape", [(8, 64, 128, 128), (8, 512, 4, 4), (3, 7, 5, 9), (1, 2048, 2, 2), (16, 128, 31, 31), (2, 16, 256, 256)])
 def test_fused_backward_batch_sums_come_from_the_same_launch(shape):
     """dgamma / dbeta / dbias [C] are written by the last of a channel's B planes to finish (csrc/instnorm.hip,
-    batch_sum_by_last_plane): bit-identical to adding the per-plane partials in the order b = 0..B-1, call after call (the
-    per-channel tickets reset themselves; 80 calls wrap the pool of 32 rows) and on two streams at once."""
+    batch_sum_by_last_plane): bit-identical to adding the per-plane partials in the order b = 0..B-1.  The arrival counters are C
+    words of CALLER memory per node (the library keeps no device state): 144 launches interleaved on THREE streams, every one with its
+    own words, cannot alias; one node's words serve backward after backward on a stream (the last plane puts the zero back); the
+    forward entry point is what zeroes them; and asking for the sums without words is an error, not a silent fallback."""
     from deepinpainting_amd import _lib, ops
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(21)
@@ -936,14 +938,17 @@ def test_fused_backward_batch_sums_come_from_the_same_launch(shape):
     dy = torch.randn(shape, device="cuda", generator=g)
     bias, gamma, beta = (torch.randn(C, device="cuda", generator=g) for _ in range(3))
     y, mean, rstd = ops.instnorm_act_forward(x, bias, gamma, beta, 1e-5, "leaky", 0.2)
+    # the forward zeroed the words it allocated behind the statistics (torch.empty memory otherwise)
+    words = torch.empty(0, dtype=torch.int32, device="cuda").set_(mean.untyped_storage(), 2 * B * C, (C,))
+    assert int(words.abs().max()) == 0
 
-    def run(stream):
+    def run(stream, tickets):
         dx = torch.empty_like(x)
         part = torch.empty((3, B, C), device="cuda")
         sums = torch.full((3, C), float("nan"), device="cuda")
         _lib.check(L.ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), bias.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                                 rstd.data_ptr(), 2, 0.2, B, C, H * W, 0, dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(),
-                                                part[2].data_ptr(), sums.data_ptr(), stream.cuda_stream), "ipsr_instnorm_act_backward")
+                                                part[2].data_ptr(), sums.data_ptr(), tickets.data_ptr(), stream.cuda_stream), "ipsr_instnorm_act_backward")
         return dx, part, sums
 
     def ordered(part):
@@ -952,24 +957,48 @@ def test_fused_backward_batch_sums_come_from_the_same_launch(shape):
             t = t + part[..., b, :]
         return t
 
-    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
-    side.wait_stream(main)
+    main = torch.cuda.current_stream()
+    streams = [main, torch.cuda.Stream(), torch.cuda.Stream()]
+    pool = torch.zeros((3, 48, C), dtype=torch.int32, device="cuda")       # one set of words per launch in flight
+    torch.cuda.synchronize()
     outs = []
-    for i in range(40):
-        outs.append(run(main))
-        with torch.cuda.stream(side):
-            outs.append(run(side))
+    for i in range(48):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs.append(run(st, pool[si, i]))
     torch.cuda.synchronize()
     for dx, part, sums in outs:
         assert torch.equal(sums, ordered(part))
         assert torch.equal(dx, outs[0][0]) and torch.equal(part, outs[0][1])
-    # the bias-only epilogue (VGG / outermost layers) shares the mechanism
+    assert int(pool.abs().max()) == 0                                      # every launch left its words zero
+    # one node's words, backward after backward (retain_graph): stream order is enough
+    again = [run(main, words) for _ in range(5)]
+    torch.cuda.synchronize()
+    for dx, part, sums in again:
+        assert torch.equal(sums, outs[0][2])
+    # no words, no sums: refused (the partials-only form, sums = NULL, needs none)
+    sums = torch.empty((3, C), device="cuda")
+    part = torch.empty((3, B, C), device="cuda")
+    dx = torch.empty_like(x)
+    rc = L.ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), bias.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      2, 0.2, B, C, H * W, 0, dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
+                                      sums.data_ptr(), None, main.cuda_stream)
+    assert rc == -1          # IPSR_ERR_INVALID
+    _lib.check(L.ipsr_instnorm_act_backward(dy.data_ptr(), y.data_ptr(), x.data_ptr(), bias.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            2, 0.2, B, C, H * W, 0, dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(),
+                                            None, None, main.cuda_stream), "partials only")
+    torch.cuda.synchronize()
+    assert torch.equal(ordered(part), outs[0][2])
+    # the bias-only epilogue (VGG / outermost layers) shares the mechanism; its forward (ipsr_bias_act) zeroes the words
+    tick = torch.full((C,), 7, dtype=torch.int32, device="cuda")
+    yb = ops.bias_act_(x.clone(), bias, "leaky", 0.2, tickets=tick)
+    assert int(tick.abs().max()) == 0
     for i in range(3):
         dxb = torch.empty_like(x)
         pb = torch.empty((B, C), device="cuda")
         sb = torch.full((C,), float("nan"), device="cuda")
-        _lib.check(L.ipsr_bias_act_backward(dy.data_ptr(), y.data_ptr(), 2, 0.2, B, C, H * W, 0, dxb.data_ptr(), pb.data_ptr(), sb.data_ptr(),
-                                            main.cuda_stream), "ipsr_bias_act_backward")
+        _lib.check(L.ipsr_bias_act_backward(dy.data_ptr(), yb.data_ptr(), 2, 0.2, B, C, H * W, 0, dxb.data_ptr(), pb.data_ptr(), sb.data_ptr(),
+                                            tick.data_ptr(), main.cuda_stream), "ipsr_bias_act_backward")
         assert torch.equal(sb, ordered(pb))
 
 

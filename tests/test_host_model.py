@@ -202,6 +202,39 @@ def test_batched_discriminator_pass_gives_the_same_gradients(tmp_path):
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-5 * gmax
 
 
+def test_batched_discriminator_pass_is_not_taken_with_batchnorm(tmp_path):
+    """`opt.norm='batch'` (accepted by get_norm_layer; define_D's default in the reference, networks.py:97-116) puts BatchNorm2d into
+    netD: one 2B pass would normalise fake and real with shared batch statistics and update the running statistics once instead of
+    twice.  The trainer must then make the reference's two passes whatever `batch_disc` says: gradients, losses and the running
+    statistics are BIT-identical between the two settings — and the one-pass form, forced, is measurably something else."""
+    img, mask, ref = golden_cases.trainer_inputs(B=2)
+    opt = Option(gpu_ids=[], batchSize=2, use_dropout=False, quiet=True, norm='batch', checkpoints_dir=str(tmp_path))
+    m = quiet(cpu_model.create_cpu_model, opt)
+    bn = torch.nn.modules.batchnorm._BatchNorm
+    assert any(isinstance(x, bn) for x in m.netD.modules())
+    m.set_input(img, mask, ref)
+    m.set_ref_latent()
+    m.set_gt_latent()
+    m.forward()
+    state = [{k: v.clone() for k, v in net.state_dict().items()} for net in (m.netD, m.netF)]
+    got = {}
+    for tag, bd, force in (("two-pass", False, False), ("default", True, False), ("forced-one-pass", True, True)):
+        for net, st in zip((m.netD, m.netF), state):
+            net.load_state_dict(st)                      # running statistics back to where they were
+            for p in net.parameters():
+                p.grad = None
+        m.batch_disc = bd
+        m._disc_per_sample = True if force else None
+        m.backward_D()
+        got[tag] = ([p.grad.clone() for net in (m.netD, m.netF) for p in net.parameters()], float(m.loss_D_fake),
+                    [b.clone() for b in m.netD.buffers()])
+    m._disc_per_sample = None
+    assert m._disc_is_per_sample() is False
+    a, b, c = got["two-pass"], got["default"], got["forced-one-pass"]
+    assert a[1] == b[1] and all(torch.equal(x, y) for x, y in zip(a[0], b[0])) and all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert abs(c[1] - a[1]) > 1e-4 * abs(a[1])         # shared batch statistics: a different loss, not a rounding difference
+
+
 def test_trainer_step_matches_reference(trainer):
     """One optimize_parameters() == the reference's, from identical weights and inputs: the four logged
     errors, the InnerCos values, the generated images, post-step weights and the NEXT iteration's errors."""
