@@ -558,6 +558,11 @@ def _ddp_worker(rank, world, port, out_dir, backend="gloo", steps=1):
     from deepinpainting_amd.models.models import create_model
     idist.init_distributed(backend=backend)
     torch.cuda.set_device(dev)
+    # MIOpen's default solvers accumulate atomically — forward included: two passes from identical weights and inputs differ by
+    # 14 % of netG's gradient (tools/exp_repeatability.py, gpurun_out/r4_repeat.txt).  With its deterministic solvers the whole
+    # trainer is BITWISE repeatable (every kernel of this repo is), so the exchanged gradient can be held to the mean of the ranks'
+    # own gradients at rounding level instead of inside a 2-10 % band
+    torch.backends.cudnn.deterministic = True
     torch.manual_seed(100 + rank)                     # DIFFERENT init per rank: the trainer must broadcast rank 0's
     opt = Option(gpu_ids=[dev], batchSize=1, use_dropout=False, quiet=True, ddp_bucket_mb=32,
                  checkpoints_dir=os.path.join(out_dir, "ck%d" % rank))
@@ -607,9 +612,8 @@ def _ddp_worker(rank, world, port, out_dir, backend="gloo", steps=1):
         want = local[tag].clone()
         torch.distributed.all_reduce(want)
         want /= world
-        # relative L2 distance: the two backward passes of one rank are not bitwise repeatable (MIOpen's weight-gradient kernels
-        # accumulate atomically; the L1 loss turns last-bit forward differences into flipped gradient signs — see
-        # test_all_four_nets_gradients_auto_engines_vs_miopen_with_one_truncation), an exchange error is O(1)
+        # relative L2 distance; the two backward passes are bitwise repeatable (deterministic solvers above), what is left is the
+        # rounding of a/2 + b/2 against (a + b)/2
         mean_check[tag] = (float((exchanged[tag] - want).double().norm()), float(want.double().norm()))
     for _ in range(steps):
         m.set_input(img, mask, ref)
@@ -648,7 +652,7 @@ def test_trainer_data_parallel_two_ranks(tmp_path):
 
 def _check_ddp_mean_and_sinks(a, b):
     for sig in (a, b):
-        for tag, band in (("G", 0.1), ("P", 0.05), ("D", 0.02), ("F", 0.02)):
+        for tag, band in (("G", 1e-5), ("P", 1e-5), ("D", 1e-5), ("F", 1e-5)):
             err, scale = sig["mean_check"][tag]
             assert err <= band * scale, "net%s: exchanged gradient differs from the mean of the ranks' gradients (L2 %.3e of %.3e)" % (tag, err, scale)
         sG, sD = sig["sink_stats"]["G"], sig["sink_stats"]["D"]
