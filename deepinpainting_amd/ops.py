@@ -552,6 +552,36 @@ def conv3x3_winograd(op, inp, weight, in_shape, Cout, bias=None, epilogue=None, 
     return out
 
 
+def conv3x3_bf16_supported(op, B, Cin, H, W, Cout):
+    return _lib.lib().ipsr_conv3x3_bf16_workspace_bytes(op, B, Cin, H, W, Cout) > 0
+
+
+def conv3x3_bf16(op, inp, weight, in_shape, Cout, out_dtype=torch.bfloat16):
+    """k3 s1 p1 convolution / transposed convolution / their input gradients as ONE direct implicit GEMM on the bf16 matrix cores
+    (ipsr_conv3x3_bf16, csrc/conv_bf16.hip): bf16 activations in, bf16 or fp32 out, fp32 weights cast inside.  BASELINE config 5."""
+    B, Cin, H, W = in_shape
+    inp, in_bf = _act(inp, "conv input")
+    if not in_bf:
+        raise TypeError("conv3x3_bf16 reads bf16 activations, got %s" % inp.dtype)
+    weight = _req(weight, torch.float32, "conv weight")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("conv3x3_bf16 writes bf16 or fp32, not %s" % out_dtype)
+    fwd = op in (CONV_FWD, CONVT_FWD)
+    want_in = (B, Cin, H, W) if fwd else (B, Cout, H, W)
+    want_w = (Cout, Cin, 3, 3) if op in (CONV_FWD, CONV_BWD_DATA) else (Cin, Cout, 3, 3)
+    if tuple(inp.shape) != want_in or tuple(weight.shape) != want_w:
+        raise RuntimeError("conv3x3_bf16 op %d: input %s / weight %s do not match %s / %s" % (op, tuple(inp.shape), tuple(weight.shape), want_in, want_w))
+    L = _lib.lib()
+    nbytes = L.ipsr_conv3x3_bf16_workspace_bytes(op, B, Cin, H, W, Cout)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv3x3_bf16: op %d on %s is not implemented (%s)" % (op, (B, Cin, H, W, Cout), _lib.lib().ipsr_last_error().decode("utf-8", "replace")))
+    out = torch.empty((B, Cout if fwd else Cin, H, W), dtype=out_dtype, device=inp.device)
+    ws = _workspace(nbytes, inp.device)
+    _lib.check(L.ipsr_conv3x3_bf16(op, inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout, int(out_dtype == torch.bfloat16),
+                                   ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv3x3_bf16")
+    return out
+
+
 GEOM_K4_S2_P3_D2 = 0       # Conv2d(k4, stride 2, pad 3, dilation 2): netG's down convolution
 GEOM_K4_S1_P1 = 1          # Conv2d(k4, stride 1, pad 1): netD's fourth convolution
 

@@ -401,6 +401,18 @@ int ipsr_conv4x4_winograd_mp(int geom, int mode, const void* a, const void* b, v
 int ipsr_conv4x4s2_winograd_mp(int mode, const void* a, const void* b, void* out, int B, int Kc, int Cf, int nh, int nw,
                                int math, int io, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- direct bf16 convolutions (BASELINE config 5: "CDNA4 bf16 MFMA for ... convs") --------------------------------------------
+ * replaces nn.Conv2d / nn.ConvTranspose2d(k3 s1 p1) under bf16 autocast — models/networks.py:220-243 (`downconv_3` / `upconv_3` of
+ * every netG level), models/vgg16.py:9-21 — and their input gradients: ONE implicit-GEMM launch on v_mfma_f32_32x32x16_bf16 (bf16
+ * operands, fp32 accumulation), NCHW bf16 activations in, NCHW bf16 (out_bf16 = 1) or fp32 (0) out, fp32 weights cast inside.
+ * op as in ipsr_conv2d (0 Conv2d forward, 1 Conv2d backward-data, 2 ConvTranspose2d forward, 3 ConvTranspose2d backward-data);
+ * (Cin, H, W) describe the module's input.  Supported: W in {16, 32, 64, 128}, H a multiple of 256 / W, reduction channels a
+ * multiple of 16; anything else -> IPSR_ERR_UNSUPPORTED.  Not bit-comparable with anything: operands are rounded to bf16 (tests
+ * compare with an fp64 convolution of the bf16-rounded operands). */
+size_t ipsr_conv3x3_bf16_workspace_bytes(int op, int B, int Cin, int H, int W, int Cout);
+int ipsr_conv3x3_bf16(int op, const void* in, const float* weight, void* out, int B, int Cin, int H, int W, int Cout, int out_bf16,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* How the reduction of the 36 Winograd GEMMs of a layer is cut over workgroups (csrc/winograd.hip, wino_choose_split): for a GEMM
  * of `rows` x `cols` (multiples of 128: produced channels x tiles, padded) with `reduction` (multiple of 16) terms,
  * out5 = {nsplit, stages per range, xi_split, nsplit_tail, stages per tail range}: the GEMMs of points xi < xi_split run in
