@@ -280,6 +280,230 @@ int launch_conv_bf16(const void* in, const float* w, void* out, int B, int C, in
     return check_launch("conv_bf16_kernel");
 }
 
+// =====================================================================================================================================
+// Weight gradient of the k3 s1 p1 layers on the bf16 matrix cores:
+//      dW[ka][cb][t] = sum_{b, y, x}  a[b][ka][y][x] * w[b][cb][y + dy_t][x + dx_t]            (w zero outside the image)
+// Conv2d: a = dy (Ka = Cout), w = x (Cb = Cin);  ConvTranspose2d: a = x (Ka = Cin), w = dy (Cb = Cout) — dW comes out in the module's
+// own layout either way.  As a GEMM the reduction runs over PIXELS, which NCHW has contiguous: both operands' fragments are 8
+// consecutive pixels of one channel, i.e. aligned 16-byte reads of the natural image — except the dx = +-1 taps, whose windows start
+// one pixel (2 bytes) off.  A lane therefore reads its aligned chunk plus the dword before and after it and builds the two shifted
+// fragments with five v_alignbit_b32 (the three taps of a row share them).
+// Workgroup = 512 threads = 8 waves (4 x 2): 128 a-channels x 64 w-channels x 9 taps; a wave owns 32 x 32 x 9 = nine MFMA tiles.
+// The pixel range is cut over workgroups (`nsplit` runs of whole image rows): every workgroup writes its partial [t][ka][cb] slab and
+// a second small kernel adds the slabs in ascending order (deterministic) into dW[ka][cb][t].  Stage = 128 pixels (RS = 128 / W image
+// rows): the a rows [128][128 px] double-buffered, the w rows in a ring of 2 RS + 2 image rows (a stage needs RS + 2, the next one's
+// RS new rows arrive meanwhile), both by LDS-DMA with the 16-byte chunks of a row XOR-swizzled / the row pitch odd in 16-byte slots so
+// that the 32 channels of a fragment read hit distinct banks.
+constexpr int WB_K = 128, WB_C = 64, WB_THREADS = 512, WB_PX = 128;
+constexpr int WB_A_BYTES = WB_K * WB_PX * 2;                 // 32 KB per buffer
+constexpr int WB_X_BYTES = 96 * 1024;                        // the w-row ring (largest: W = 16 -> 18 rows x 64 c x 5 slots x 16 B = 92 KB)
+
+struct WbGeom {
+    int B, Ka, Cb, H, W, wshift;
+    int RS, NSLOT, pitch;       // image rows per stage, ring rows (2 RS + 2), 16-byte slots per (row, channel): W / 8 + 3
+    int stages_per_wg, nsplit;  // stages of RS rows a workgroup reduces; B * H / (RS * stages_per_wg) runs
+    int ktiles, ctiles;
+};
+
+__device__ __forceinline__ unsigned alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+
+__global__ void __launch_bounds__(WB_THREADS, 1) conv_bf16_wrw_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ w,
+                                                                      const uint4* __restrict__ zero_page, WbGeom g, float* __restrict__ slabs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];          // A[2] | X ring
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = g.ktiles * g.ctiles;
+    const int tile = L % tiles, split = L / tiles;
+    const int kt = tile % g.ktiles, ct = tile / g.ktiles;
+    const int rows_per_wg = g.RS * g.stages_per_wg;
+    const int runs_per_img = g.H / rows_per_wg;
+    const int b = split / runs_per_img, ylo = (split - b * runs_per_img) * rows_per_wg;
+    const size_t HW = (size_t)g.H * g.W;
+    const int cpr = g.W >> 3;                                // 16-byte chunks per image row
+
+    // ---- a rows: slot sigma = k * 16 + cs holds stage chunk c8 = cs ^ (k & 15) of channel k; c8 -> (row rs, chunk cx) -------------------
+    const unsigned short* ga[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sigma = (wave + 8 * j) * 64 + lane;
+        const int k = sigma >> 4, c8 = (sigma & 15) ^ (k & 15);
+        const int rs = c8 / cpr, cx = c8 - rs * cpr;
+        const int ka = kt * WB_K + k;
+        ga[j] = ka < g.Ka ? a + ((size_t)b * g.Ka + ka) * HW + (size_t)(ylo + rs) * g.W + cx * 8 : nullptr;
+    }
+    // ---- w rows: ring slot of image row y = (y + 1) mod NSLOT; per (ring row, channel): [halo][W / 8 chunks][halo][pad] = `pitch` slots ----
+    // a group of RS rows = RS * 64 * pitch slots; slot q = (row rr, channel c, slot sl); 64 * pitch is a multiple of 64, so the 64 lanes of
+    // one DMA instruction never straddle rows: wave-uniform LDS base, per-lane source
+    const int xslots = g.RS * WB_C * g.pitch;
+    const unsigned short* gxw[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int q = tid + WB_THREADS * j;
+        const int qq = q < xslots ? q : 0;
+        const int sl = qq % g.pitch, c = (qq / g.pitch) % WB_C;
+        const int cb = ct * WB_C + c;
+        const bool data = sl >= 1 && sl <= cpr && cb < g.Cb;
+        gxw[j] = data ? w + ((size_t)b * g.Cb + cb) * HW + (sl - 1) * 8 : nullptr;
+    }
+    const int ring_row_slots = WB_C * g.pitch, ring_row_bytes = ring_row_slots * 16;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+
+    auto dma_a = [&](int buf, int stage) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const void* src = ga[j] ? static_cast<const void*>(ga[j] + (size_t)stage * g.RS * g.W) : static_cast<const void*>(zero_page);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + buf * WB_A_BYTES + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+    };
+    // image rows y_first .. y_first + RS - 1 into their ring slots (rows outside the image: zeros)
+    auto dma_x = [&](int y_first) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int q0 = wave * 64 + WB_THREADS * j;        // uniform: first slot of this wave's instruction
+            if (q0 < xslots) {
+                const int rr = q0 / ring_row_slots, within = q0 - rr * ring_row_slots;
+                const int y = y_first + rr;
+                int slot = (y + 1) % g.NSLOT;
+                if (slot < 0) slot += g.NSLOT;
+                const bool ok = gxw[j] != nullptr && (unsigned)y < (unsigned)g.H;
+                const void* src = ok ? static_cast<const void*>(gxw[j] + (size_t)y * g.W) : static_cast<const void*>(zero_page);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + 2 * WB_A_BYTES + slot * ring_row_bytes + within * 16), 16, 0, 0);
+            }
+        }
+    };
+
+    // prologue: a stage 0; w rows ylo - 1 .. ylo + RS (at least)
+    dma_a(0, 0);
+    for (int y = ylo - 1; y <= ylo + g.RS; y += g.RS) dma_x(y);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int a_row = (wk * 32 + r);                          // a fragment: channel row
+    const int bcol = wc * 32 + r;                             // w fragment: channel column
+    for (int s = 0; s < g.stages_per_wg; ++s) {
+        const int cur = s & 1;
+        const int y0 = ylo + s * g.RS;
+        if (s + 1 < g.stages_per_wg) {
+            dma_a(cur ^ 1, s + 1);
+            dma_x(y0 + g.RS + 1);                             // the RS rows the next stage adds: y0 + RS + 1 .. y0 + 2 RS
+        }
+        const unsigned char* A = lds + cur * WB_A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                         // k-steps of 16 pixels
+            const int c8 = 2 * j + h;
+            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(A + ((a_row << 4) + (c8 ^ (a_row & 15))) * 16);
+            const int p0 = 16 * j;                            // stage pixel of the k-step
+            const int rs = p0 >> g.wshift, px = (p0 & (g.W - 1)) + 8 * h;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                int slot = (y0 + rs + dy) % g.NSLOT;          // image row y0 + rs + dy - 1 lives in ring slot (y + 1) mod NSLOT
+                const unsigned char* X = lds + 2 * WB_A_BYTES + slot * ring_row_bytes + (bcol * g.pitch + 1 + (px >> 3)) * 16;
+                const uint4 c4 = *reinterpret_cast<const uint4*>(X);
+                const unsigned prev = *reinterpret_cast<const unsigned*>(X - 4);
+                const unsigned next = *reinterpret_cast<const unsigned*>(X + 16);
+                const unsigned s0 = alignbit16(c4.x, prev), s1 = alignbit16(c4.y, c4.x), s2 = alignbit16(c4.z, c4.y), s3 = alignbit16(c4.w, c4.z),
+                               s4 = alignbit16(next, c4.w);
+                const uint4 left = make_uint4(s0, s1, s2, s3), right = make_uint4(s1, s2, s3, s4);
+                acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, left), acc[dy * 3 + 0], 0, 0, 0);
+                acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, c4), acc[dy * 3 + 1], 0, 0, 0);
+                acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, right), acc[dy * 3 + 2], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // partial result: slab[split][t][ka][cb] (lanes along cb: coalesced)
+    const int Kap = g.ktiles * WB_K, Cbp = g.ctiles * WB_C;
+    float* out = slabs + (size_t)split * 9 * Kap * Cbp;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ka = kt * WB_K + wk * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            out[((size_t)t * Kap + ka) * Cbp + ct * WB_C + bcol] = acc[t][e];
+        }
+}
+
+// dW[ka][cb][t] = sum_s slab[s][t][ka][cb]
+__global__ void __launch_bounds__(256) conv_bf16_wrw_reduce_kernel(const float* __restrict__ slabs, int nsplit, int Ka, int Cb, int Kap, int Cbp,
+                                                                   float* __restrict__ dW)
+{
+    const int cb = blockIdx.x * 256 + threadIdx.x, ka = blockIdx.y;
+    if (cb >= Cb) return;
+    float o[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) o[t] = 0.0f;
+    const size_t slab = (size_t)9 * Kap * Cbp;
+    for (int s = 0; s < nsplit; ++s)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o[t] += slabs[(size_t)s * slab + ((size_t)t * Kap + ka) * Cbp + cb];
+    float* d = dW + ((size_t)ka * Cb + cb) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) d[t] = o[t];
+}
+
+static int wb_geometry(int B, int Ka, int Cb, int H, int W, WbGeom* g)
+{
+    if (W != 16 && W != 32 && W != 64 && W != 128) return fail(IPSR_ERR_UNSUPPORTED, "bf16 weight gradient: image width %d (16, 32, 64 or 128)", W);
+    const int RS = WB_PX / W;
+    if (H % RS != 0) return fail(IPSR_ERR_UNSUPPORTED, "bf16 weight gradient: %d rows are not a multiple of %d", H, RS);
+    g->B = B; g->Ka = Ka; g->Cb = Cb; g->H = H; g->W = W;
+    g->wshift = W == 16 ? 4 : (W == 32 ? 5 : (W == 64 ? 6 : 7));
+    g->RS = RS; g->NSLOT = 2 * RS + 2; g->pitch = W / 8 + 3;
+    g->ktiles = (Ka + WB_K - 1) / WB_K; g->ctiles = (Cb + WB_C - 1) / WB_C;
+    if (g->NSLOT * WB_C * g->pitch * 16 > WB_X_BYTES || RS * WB_C * g->pitch > 5 * WB_THREADS)
+        return fail(IPSR_ERR_UNSUPPORTED, "bf16 weight gradient: the row ring of a %d-wide image does not fit the LDS plan", W);
+    // runs: about two rounds of one workgroup per CU
+    const int groups = H / RS;                                // stages per image
+    int spw = (int)(((long)g->ktiles * g->ctiles * B * groups + 511) / 512);
+    if (spw < 1) spw = 1;
+    if (spw > groups) spw = groups;
+    while (groups % spw) --spw;
+    g->stages_per_wg = spw;
+    g->nsplit = B * (groups / spw);
+    return IPSR_OK;
+}
+
+size_t conv_bf16_wrw_ws_bytes(int B, int Ka, int Cb, int H, int W)
+{
+    WbGeom g;
+    if (wb_geometry(B, Ka, Cb, H, W, &g) != IPSR_OK) return 0;
+    return 256 + (size_t)g.nsplit * 9 * g.ktiles * WB_K * g.ctiles * WB_C * 4;
+}
+
+// a [B,Ka,H,W], w [B,Cb,H,W] bf16 -> dW [Ka][Cb][3][3] fp32
+int launch_conv_bf16_wrw(const void* a, const void* w, float* dW, int B, int Ka, int Cb, int H, int W, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    WbGeom g;
+    if (int rc = wb_geometry(B, Ka, Cb, H, W, &g)) return rc;
+    const size_t need = conv_bf16_wrw_ws_bytes(B, Ka, Cb, H, W);
+    if (ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "bf16 weight gradient: workspace %zu < %zu", ws_bytes, need);
+    uint4* zero_page = static_cast<uint4*>(ws);
+    float* slabs = reinterpret_cast<float*>(zero_page + 16);
+    if (hipMemsetAsync(zero_page, 0, 64, st) != hipSuccess) return fail(IPSR_ERR_LAUNCH, "bf16 weight gradient: hipMemsetAsync failed");
+    const size_t smem = 2 * (size_t)WB_A_BYTES + (size_t)g.NSLOT * WB_C * g.pitch * 16;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wrw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WB_A_BYTES + WB_X_BYTES); attr = true; }
+    const unsigned grid = (unsigned)(g.ktiles * g.ctiles * g.nsplit);
+    profile_mark_start(st, 3);
+    conv_bf16_wrw_kernel<<<grid, WB_THREADS, smem, st>>>(static_cast<const unsigned short*>(a), static_cast<const unsigned short*>(w), zero_page, g, slabs);
+    profile_mark_stop(st, 3, 2.0 * 9.0 * (double)(g.ktiles * WB_K) * (g.ctiles * WB_C) * B * H * W, 2.0 * 9.0 * (double)Ka * Cb * B * H * W);
+    if (int rc = check_launch("conv_bf16_wrw_kernel")) return rc;
+    conv_bf16_wrw_reduce_kernel<<<dim3(cdiv(Cb, 256), Ka), 256, 0, st>>>(slabs, g.nsplit, Ka, Cb, g.ktiles * WB_K, g.ctiles * WB_C, dW);
+    return check_launch("conv_bf16_wrw_reduce_kernel");
+}
+
 }  // namespace ipsr
 
 using namespace ipsr;
@@ -307,6 +531,25 @@ int ipsr_conv3x3_bf16(int op, const void* in, const float* weight, void* out, in
         case 2: return launch_conv_bf16(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, out_bf16, ws, ws_bytes, st);
         default: return launch_conv_bf16(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, out_bf16, ws, ws_bytes, st);
     }
+}
+
+size_t ipsr_conv3x3_bf16_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout)
+{
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
+    return transposed ? conv_bf16_wrw_ws_bytes(B, Cin, Cout, H, W) : conv_bf16_wrw_ws_bytes(B, Cout, Cin, H, W);
+}
+
+int ipsr_conv3x3_bf16_wrw(int transposed, const void* x, const void* dy, float* dw, int B, int Cin, int H, int W, int Cout,
+                          void* ws, size_t ws_bytes, void* stream)
+{
+    if (!x || !dy || !dw || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_bf16_wrw: null pointer");
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_bf16_wrw: bad argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(dy) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_bf16_wrw: x / dy / workspace must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // Conv2d: dW[co][ci][t] = sum dy[co][p] x[ci][p + t];  ConvTranspose2d: dW[ci][co][t] = sum x[ci][p] dy[co][p + t]
+    if (transposed) return launch_conv_bf16_wrw(x, dy, dw, B, Cin, Cout, H, W, ws, ws_bytes, st);
+    return launch_conv_bf16_wrw(dy, x, dw, B, Cout, Cin, H, W, ws, ws_bytes, st);
 }
 
 }  // extern "C"

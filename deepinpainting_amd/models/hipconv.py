@@ -27,7 +27,9 @@ Weight gradients: Winograd F(3x3,4x4) (csrc/winograd.hip) for the 3x3 stride-1 l
 maps (2.0-2.4x MIOpen), MIOpen otherwise (`select_wrw`).
 
 `IPSR_CONV_ENGINE=miopen|direct|winograd|auto` (default auto) forces one engine wherever it is implemented — for the
-per-engine parity tests and for A/B timing.  bf16 autocast and non-contiguous / non-fp32 inputs always take MIOpen.
+per-engine parity tests and for A/B timing.  bf16 activations (BASELINE config 5): "bf16d" (csrc/conv_bf16.hip, the direct bf16
+implicit GEMM, forward / input gradient / weight gradient of the k3 s1 p1 layers) and the split-bf16 Winograd engines where they win;
+non-contiguous inputs and other dtypes take MIOpen.
 """
 import functools
 import os
@@ -43,7 +45,7 @@ _FORCE = None          # test hook: overrides the environment
 # Arithmetic of the Winograd GEMMs (ops.MATH_CODE): "fp32" for fp32 activations (the reference's arithmetic; "bf16x6" / "bf16x3" are
 # opt-in, models/IPSR.py `opt.conv_math`), "bf16x3" for bf16 activations / under bf16 autocast (BASELINE config 5).
 _MATH = {"fp32": "fp32", "bf16": "bf16x3"}
-_BF16_ENGINES = ("winograd", "wino_dil", "wino_s2")         # the engines that read / write bf16 activation tensors
+_BF16_ENGINES = ("winograd", "wino_dil", "wino_s2", "bf16d")         # the engines that read / write bf16 activation tensors
 
 
 def set_conv_math(fp32=None, bf16=None):
@@ -70,10 +72,27 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     the rules query the library (workspace probes), ~150 convolution calls per training step ask.
     bf16: the activations are bf16 tensors — only the Winograd engines read / write those; every other shape takes MIOpen."""
     eng = _select(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0") + os.environ.get("IPSR_NO_THIN", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
-    return eng if (not bf16 or _bf16_wins(eng, Cin, H, W, Cout)) else "miopen"
+    if not bf16:
+        return eng
+    if _bf16_wins(eng, Cin, H, W, Cout):
+        return eng
+    return _bf16_direct(os.environ.get("IPSR_BF16_ENGINES", ""), _mode(), op, B, Cin, H, W, Cout, k, stride, pad, dil)
 
 
-def _bf16_wins(eng, Cin, H, W, Cout):
+@functools.lru_cache(maxsize=4096)
+def _bf16_direct(force, mode, op, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """bf16 activations, and the split-bf16 Winograd engines do not win this shape: the DIRECT bf16 implicit GEMM (csrc/conv_bf16.hip,
+    ops.conv3x3_bf16: one launch, NCHW in and out) where it is implemented — k3 s1 p1 on maps of 16..128 pixels width — else MIOpen.
+    Measured at batch 16 (profiles/r04_conv_bf16_layers.txt): 700-870 TF against MIOpen's 350-570 incl. its layout transposes on
+    every map from 32x32 up; on 16x16 maps MIOpen ties (and the Winograd engines win from 512 channels)."""
+    if force == "none" or mode in ("miopen", "winograd", "direct"):
+        return "miopen"
+    if k == 3 and stride == 1 and pad == 1 and dil == 1 and H * W >= 1024 and ops.conv3x3_bf16_supported(op, B, Cin, H, W, Cout):
+        return "bf16d"
+    return "miopen"
+
+
+def _bf16_wins(eng, Cin, H, W, Cout, wrw=False):
     """bf16 activations (BASELINE config 5).  MIOpen's bf16 implicit GEMMs run ~490 TF and need no transform passes; the Winograd
     engines here must SPLIT their operands (F(4x4,3x3) amplifies rounding ~100x), so their intermediates stay fp32-wide: 4.5x the
     bf16 activation bytes each way.  They win where the channel count amortises that (profiles/r03_bf16_layers.txt, batch 16, forward
@@ -87,7 +106,11 @@ def _bf16_wins(eng, Cin, H, W, Cout):
     if force == "all":
         return True
     if eng == "winograd":
-        return H * W <= 1024 and max(Cin, Cout) >= 512
+        # round 4: against the DIRECT bf16 kernel (csrc/conv_bf16.hip, profiles/r04_conv_bf16_layers.txt) the split engines keep the 16x16
+        # maps (0.056-0.080 vs 0.079-0.146 ms) and the 512-channel weight gradients at 32x32 (0.084-0.121 vs 0.090-0.133)
+        if H * W <= 256:
+            return max(Cin, Cout) >= 512
+        return wrw and H * W <= 1024 and min(Cin, Cout) >= 256 and max(Cin, Cout) == 512
     if eng == "wino_dil":
         return H * W <= 4096 and min(Cin, Cout) >= 256
     return False
@@ -217,7 +240,24 @@ def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     """-> the engine for the weight gradient of one layer (profiles/r02_hipconv_k3_wrw.txt: F(3x3,4x4) is 2.0-2.4x
     MIOpen from 256 channels up on maps of 16x16..64x64; on larger maps its tile-major transforms lose to MIOpen)."""
     eng = _select_wrw(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0"), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
-    return eng if (not bf16 or _bf16_wins(eng, Cin, H, W, Cout)) else "miopen"
+    if not bf16:
+        return eng
+    if _bf16_wins(eng, Cin, H, W, Cout, True):
+        return eng
+    return _bf16_direct_wrw(os.environ.get("IPSR_BF16_ENGINES", ""), _mode(), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+
+
+@functools.lru_cache(maxsize=4096)
+def _bf16_direct_wrw(force, mode, transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
+    """Weight gradient on bf16 activations by the direct kernel (ops.conv3x3_bf16_wrw): 1.3-1.6x MIOpen from two 128 x 64 output tiles
+    up; a single tile (64 -> 128 channels) leaves the chip to the partial-sum traffic and stays on MIOpen."""
+    if force == "none" or mode in ("miopen", "winograd", "direct"):
+        return "miopen"
+    ka, cb = (Cin, Cout) if transposed else (Cout, Cin)
+    if k == 3 and stride == 1 and pad == 1 and dil == 1 and H * W >= 1024 and ((ka + 127) // 128) * ((cb + 63) // 64) >= 2 \
+            and ops.conv3x3_bf16_wrw_supported(transposed, B, Cin, H, W, Cout):
+        return "bf16d"
+    return "miopen"
 
 
 @functools.lru_cache(maxsize=4096)
@@ -275,6 +315,8 @@ class _HipConv(torch.autograd.Function):
             y = ops.conv3x3_winograd(op, xc, w, (B, Cin, H, W), Cout, math=math, out_dtype=act)
         elif eng_fwd == "direct":
             y = ops.conv2d(op, xc, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
+        elif eng_fwd == "bf16d":
+            y = ops.conv3x3_bf16(op, xc if xc.dtype == torch.bfloat16 else xc.to(torch.bfloat16), w, (B, Cin, H, W), Cout, out_dtype=act)
         elif eng_fwd == "wino_dil":
             y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=act)
         elif eng_fwd == "thin":
@@ -311,6 +353,8 @@ class _HipConv(torch.autograd.Function):
                 dx = ops.conv3x3_winograd(op, dy, w, (B, Cin, H, W), Cout, math=math, out_dtype=x.dtype)
             elif eng == "direct":
                 dx = ops.conv2d(op, dy, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
+            elif eng == "bf16d":
+                dx = ops.conv3x3_bf16(op, dy, w, (B, Cin, H, W), Cout, out_dtype=x.dtype)
             elif eng == "wino_dil":
                 dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=x.dtype)
             elif eng == "thin":
@@ -327,10 +371,12 @@ class _HipConv(torch.autograd.Function):
                 _check_hook("input_grad", eng, ctx.geom, (dy, x, w), dx)
         weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16) if ctx.needs_input_grad[1] else None
         # data parallel: write the weight gradient straight into its slice of the armed gradient bucket (dist.py)
-        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2", "smallmap", "one") else None
+        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2", "smallmap", "one", "bf16d") else None
         xw = x if (x.dtype == dy.dtype or weng in (None, "miopen")) else x.to(dy.dtype)      # a weight gradient reads both operands in one dtype
         if weng == "winograd":
             dw = ops.conv3x3_winograd_wrw(transposed, xw, dy, Cout, out=sink, math=math)
+        elif weng == "bf16d":
+            dw = ops.conv3x3_bf16_wrw(transposed, xw, dy, Cout, out=sink)
         elif weng == "wino_dil":
             dw = ops.conv4x4_dilated_winograd(2, xw, dy, (B, Cin, H, W), Cout, out=sink, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math)
         elif weng == "one":
@@ -408,6 +454,9 @@ def conv_nobias(m, x, weight=None):
             return ops.conv3x3_winograd(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, math=math, out_dtype=act)
         elif eng == "direct":
             return ops.conv2d(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, k, stride, pad, dil)
+        elif eng == "bf16d":
+            xb = x.contiguous()
+            return ops.conv3x3_bf16(op, xb if xb.dtype == torch.bfloat16 else xb.to(torch.bfloat16), w.detach(), (B, Cin, H, W), Cout, out_dtype=act)
         elif eng == "wino_dil":
             return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil),
                                                 math=math, out_dtype=act)

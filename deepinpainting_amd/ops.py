@@ -582,6 +582,34 @@ def conv3x3_bf16(op, inp, weight, in_shape, Cout, out_dtype=torch.bfloat16):
     return out
 
 
+def conv3x3_bf16_wrw_supported(transposed, B, Cin, H, W, Cout):
+    return _lib.lib().ipsr_conv3x3_bf16_wrw_workspace_bytes(int(transposed), B, Cin, H, W, Cout) > 0
+
+
+def conv3x3_bf16_wrw(transposed, x, dy, Cout, out=None):
+    """Weight gradient of a k3 s1 p1 Conv2d (-> [Cout,Cin,3,3]) / ConvTranspose2d (-> [Cin,Cout,3,3]) on the bf16 matrix cores
+    (ipsr_conv3x3_bf16_wrw): x, dy bf16; the result fp32 (optionally written into `out`, e.g. a slice of a gradient bucket)."""
+    x, x_bf = _act(x, "conv input")
+    dy, dy_bf = _act(dy, "grad_output")
+    if not (x_bf and dy_bf):
+        raise TypeError("conv3x3_bf16_wrw reads bf16 tensors")
+    B, Cin, H, W = x.shape
+    if tuple(dy.shape) != (B, Cout, H, W):
+        raise RuntimeError("conv3x3_bf16_wrw: grad_output %s does not match %s" % (tuple(dy.shape), (B, Cout, H, W)))
+    shape = (Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3)
+    if out is not None and (tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device):
+        raise RuntimeError("conv3x3_bf16_wrw: `out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
+    L = _lib.lib()
+    nbytes = L.ipsr_conv3x3_bf16_wrw_workspace_bytes(int(transposed), B, Cin, H, W, Cout)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv3x3_bf16_wrw: %s is not implemented (%s)" % ((B, Cin, H, W, Cout), L.ipsr_last_error().decode("utf-8", "replace")))
+    dw = out if out is not None else torch.empty(shape, dtype=torch.float32, device=x.device)
+    ws = _workspace(nbytes, x.device)
+    _lib.check(L.ipsr_conv3x3_bf16_wrw(int(transposed), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, ws.data_ptr(), ws.numel(),
+                                       _stream()), "ipsr_conv3x3_bf16_wrw")
+    return dw
+
+
 GEOM_K4_S2_P3_D2 = 0       # Conv2d(k4, stride 2, pad 3, dilation 2): netG's down convolution
 GEOM_K4_S1_P1 = 1          # Conv2d(k4, stride 1, pad 1): netD's fourth convolution
 

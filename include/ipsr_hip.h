@@ -412,6 +412,12 @@ int ipsr_conv4x4s2_winograd_mp(int mode, const void* a, const void* b, void* out
 size_t ipsr_conv3x3_bf16_workspace_bytes(int op, int B, int Cin, int H, int W, int Cout);
 int ipsr_conv3x3_bf16(int op, const void* in, const float* weight, void* out, int B, int Cin, int H, int W, int Cout, int out_bf16,
                       void* ws, size_t ws_bytes, void* stream);
+/* their weight gradient: x [B,Cin,H,W], dy [B,Cout,H,W] bf16 -> dw fp32 in the module's layout (transposed = 0: Conv2d [Cout][Cin][3][3];
+ * 1: ConvTranspose2d [Cin][Cout][3][3]).  The reduction over pixels is cut over workgroups; the partial results are added in a fixed
+ * order by a second launch (deterministic).  Same shape limits as above. */
+size_t ipsr_conv3x3_bf16_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout);
+int ipsr_conv3x3_bf16_wrw(int transposed, const void* x, const void* dy, float* dw, int B, int Cin, int H, int W, int Cout,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* How the reduction of the 36 Winograd GEMMs of a layer is cut over workgroups (csrc/winograd.hip, wino_choose_split): for a GEMM
  * of `rows` x `cols` (multiples of 128: produced channels x tiles, padded) with `reduction` (multiple of 16) terms,

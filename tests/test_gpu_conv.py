@@ -586,6 +586,72 @@ def test_every_engine_call_of_a_training_step_checked_in_situ(tmp_path):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("tr,Cin,H,W,Cout,B", [(False, 32, 16, 16, 48, 2), (False, 128, 32, 32, 160, 3), (True, 64, 32, 64, 48, 2), (False, 16, 128, 128, 16, 1),
+                                               (True, 256, 8, 32, 304, 2), (False, 64, 64, 64, 64, 2), (True, 144, 64, 16, 208, 1), (False, 512, 32, 32, 512, 16)])
+def test_direct_bf16_conv_all_passes(tr, Cin, H, W, Cout, B):
+    """csrc/conv_bf16.hip (BASELINE config 5): the k3 s1 p1 layers as direct implicit GEMMs on v_mfma_f32_32x32x16_bf16 — forward, input
+    gradient (bf16 and fp32 outputs) and weight gradient — against fp64 of the SAME bf16-rounded operands: what is left is the fp32
+    accumulation (measured <= 2e-6) plus, for bf16 outputs, the rounding of the result, 2^-8.  Shapes: every supported width, channel
+    counts that are not tile multiples, non-square maps, the step's largest layer at batch 16."""
+    from deepinpainting_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(29)
+    x = torch.randn(B, Cin, H, W, device="cuda", generator=g).to(torch.bfloat16)
+    dy = torch.randn(B, Cout, H, W, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn((Cin, Cout, 3, 3) if tr else (Cout, Cin, 3, 3), device="cuda", generator=g) * 0.1
+    f = (lambda a, ww: F.conv_transpose2d(a, ww, None, 1, 1)) if tr else (lambda a, ww: F.conv2d(a, ww, None, 1, 1))
+    y64, dx64, _ = _f64(f, x, w.to(torch.bfloat16), dy)            # the kernel rounds the weights to bf16
+    _, _, dw64 = _f64(f, x, w, dy)                                 # the weight gradient does not depend on the weights
+    fop, bop = (ops.CONVT_FWD, ops.CONVT_BWD_DATA) if tr else (ops.CONV_FWD, ops.CONV_BWD_DATA)
+    assert ops.conv3x3_bf16_supported(fop, B, Cin, H, W, Cout)
+    y32 = ops.conv3x3_bf16(fop, x, w, (B, Cin, H, W), Cout, out_dtype=torch.float32)
+    dx32 = ops.conv3x3_bf16(bop, dy, w, (B, Cin, H, W), Cout, out_dtype=torch.float32)
+    y16 = ops.conv3x3_bf16(fop, x, w, (B, Cin, H, W), Cout)
+    dx16 = ops.conv3x3_bf16(bop, dy, w, (B, Cin, H, W), Cout)
+    dw = ops.conv3x3_bf16_wrw(tr, x, dy, Cout)
+    assert y16.dtype == torch.bfloat16 and dx16.dtype == torch.bfloat16 and dw.dtype == torch.float32 and dw.shape == w.shape
+    errs = dict(y=_relerr(y32, y64), dx=_relerr(dx32, dx64), dw=_relerr(dw, dw64), y16=_relerr(y16, y64), dx16=_relerr(dx16, dx64))
+    assert errs["y"] <= 1e-5 and errs["dx"] <= 1e-5 and errs["dw"] <= 1e-5, errs
+    assert errs["y16"] <= 2.0 ** -8 and errs["dx16"] <= 2.0 ** -8, errs
+    # writes into a caller's buffer (a gradient bucket slice) and refuses what it cannot do
+    sink = torch.full_like(w, float("nan"))
+    assert ops.conv3x3_bf16_wrw(tr, x, dy, Cout, out=sink) is sink and torch.equal(sink, dw)
+    assert not ops.conv3x3_bf16_supported(fop, B, Cin, H, 24, Cout) and not ops.conv3x3_bf16_supported(fop, B, Cin + 3, H, W, Cout)
+    with pytest.raises(NotImplementedError):
+        ops.conv3x3_bf16(fop, torch.zeros(1, 16, 12, 24, device="cuda", dtype=torch.bfloat16), torch.zeros((16, 16, 3, 3), device="cuda"), (1, 16, 12, 24), 16)
+
+
+def test_direct_bf16_conv_through_the_modules_under_autocast():
+    """models/hipconv.py with bf16 activations: the k3 s1 p1 modules run forward, input gradient and weight gradient on the direct
+    bf16 engine ("bf16d") from 32x32 maps up — asserted through the dispatcher's own hook — and match the fp32 module to bf16 accuracy."""
+    from deepinpainting_amd import ops
+    from deepinpainting_amd.models import hipconv
+    torch.manual_seed(5)
+    seen = []
+    hipconv._check_hook = lambda kind, eng, geom, operands, result: seen.append((kind, eng))
+    try:
+        for m, H, W in ((nn.Conv2d(128, 256, 3, 1, 1), 64, 64), (nn.ConvTranspose2d(256, 128, 3, 1, 1), 32, 32)):
+            m = m.cuda()
+            x = torch.randn(4, m.in_channels, H, W, device="cuda", requires_grad=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = hipconv.conv_nobias(m, x)
+            assert y.dtype == torch.bfloat16
+            dy = torch.randn_like(y, dtype=torch.float32)
+            dx, dw = torch.autograd.grad(y.float(), (x, m.weight), dy)
+            xr = x.detach().clone().requires_grad_(True)
+            yr = F.conv_transpose2d(xr, m.weight, None, 1, 1) if isinstance(m, nn.ConvTranspose2d) else F.conv2d(xr, m.weight, None, 1, 1)
+            dxr, dwr = torch.autograd.grad(yr, (xr, m.weight), dy)
+            for a, b in ((y.float(), yr), (dx, dxr), (dw, dwr)):
+                assert float((a - b).abs().max() / b.abs().max()) <= 2e-2          # bf16 operands and results: 2^-8 each
+    finally:
+        hipconv._check_hook = None
+    assert seen.count(("forward", "bf16d")) == 2 and seen.count(("input_grad", "bf16d")) == 2 and seen.count(("weight_grad", "bf16d")) == 2, seen
+    assert hipconv.select(ops.CONV_FWD, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"          # where split-bf16 Winograd still wins
+    assert hipconv.select(ops.CONV_FWD, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d" and hipconv.select_wrw(False, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "winograd"
+    assert hipconv.select(ops.CONV_FWD, 16, 128, 128, 128, 128, 3, 1, 1, 1, True) == "bf16d"
+    assert hipconv.select_wrw(False, 16, 64, 128, 128, 128, 3, 1, 1, 1, True) == "miopen"              # one output tile: partial-sum bound
+    assert hipconv.select(ops.CONV_FWD, 16, 128, 128, 128, 128, 3, 1, 1, 1, False) == "winograd"       # fp32 activations: untouched
+
+
 def test_dispatcher_rules_and_refusals():
     from deepinpainting_amd import ops
     from deepinpainting_amd.models import hipconv
