@@ -39,31 +39,48 @@ typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
 
 constexpr int CB_K = 128, CB_P = 256, CB_C = 16, CB_THREADS = 512, CB_MAXTAP = 9;
 constexpr int CB_A_BYTES = CB_MAXTAP * 2 * CB_K * 16;       // [tap][c group][128 k][8 c] bf16 = 36 KB
-constexpr int CB_RAW_BYTES = 16384;                         // [16 c][rows + halo][W] bf16, W <= 128: 16 x 4 x 256 B
-constexpr int CB_T_BYTES = 17408;                           // [2][positions][8 c]: (R + 2) x (W + 2) <= 4 x 130 = 520 positions (+ slack)
-constexpr int CB_TR_MAX = 4;                                // transposition blocks (4 channels x 16 pixels) per 16-lane group and stage
+constexpr int CB_RAW_BYTES = 20480;                         // [16 c][raw rows][input width] bf16: k3 16 x 4 x 256 B; stride 2: 16 x 5 x 256 B
+constexpr int CB_T_BYTES = 21504;                           // [planes][2 c groups][positions][8 c]: k3 2 x 520 x 16 B; stride 2: 4 x 325 x 16 B
+constexpr int CB_TR_MAX = 5;                                // transposition blocks (4 channels x 16 pixels) per 16-lane group and stage
 constexpr int CB_BUF = CB_A_BYTES + CB_RAW_BYTES + CB_T_BYTES;
+static_assert(2 * CB_BUF <= 160 * 1024, "LDS plan");
+
+// The three forms (all: out = sum over (channel, tap) of packed weight x shifted input; lanes = pixels of the LANE grid Hl x Wl):
+//   S1   k3 s1 p1                     lane grid = image; 9 taps; raw tile = R + 2 rows of the image, T = [cg][R + 2][W + 2]
+//   F2C  k4 s2 p1, fine -> coarse     (Conv2d forward, ConvTranspose2d input gradient) lane grid = COARSE output, in(2o - 1 + r).  A stage =
+//        16 channels x the 8 taps whose input ROW parity is ey: raw tile = the R + 1 fine rows of that parity (full fine width), the
+//        transposition splits them into the two COLUMN phases, T = [ex][cg][R + 1][Wl + 1] — every tap a unit-stride shift again.
+//   C2F  k4 s2 p1, coarse -> fine     (ConvTranspose2d forward, Conv2d input gradient) lane grid = COARSE input; a workgroup produces the
+//        fine rows of ONE row parity ey' and both column parities (two accumulator sets of 2 x 2 taps each: 8 taps per stage), raw / T as
+//        S1 on the coarse image; the epilogue interleaves the two column phases into whole fine rows.
+enum { CB_S1 = 0, CB_F2C = 1, CB_C2F = 2 };
 
 struct CbGeom {
-    int B, C, K, H, W;          // C reduction channels (multiple of 16), K produced channels
-    int wshift;                 // log2 W
-    int R, NR, PW, NPOS;        // image rows per tile (256 / W), raw rows (R + 2), padded width (W + 2), positions NR * PW
-    int ntap;                   // 9
-    int tapoff[CB_MAXTAP];      // (dy + 1) * PW + (dx + 1)
-    int ktiles, ptiles;         // ceil(K / 128), B * H / R
-    int nstage;                 // C / 16
+    int B, C, K;                // C reduction channels (multiple of 16), K produced channels
+    int Hin, Win;               // the tensor the kernel reads
+    int Hl, Wl, wshift;         // lane grid (rows, width = power of two), log2 Wl
+    int Hout, Wout;             // the tensor written
+    int R, NR, PW, NPOS;        // lane-grid rows per tile (256 / Wl), raw rows, padded width, positions NR * PW per (plane, c group)
+    int ymul, rowstep, yoff[2]; // input row of raw row i of sub-stage e: ymul * y0 + yoff[e] + rowstep * i
+    int nsub, nphase;           // stages per channel block (F2C: 2), output row phases = workgroups per (k tile, pixel tile) (C2F: 2)
+    int ntap;
+    int tapoff[2][CB_MAXTAP];   // per sub-stage (F2C) / row phase (C2F): plane * 2 * NPOS + drow * PW + dcol
+    int ktiles, ptiles, nstage; // ceil(K / 128), B * Hl / R, (C / 16) * nsub
 };
 
-// weight element (k, c, t) at w[c * sc + k * sk + tap], tap = flip ? 8 - t : t  ->  Wp[kt][cb][t][cg][k & 127][c & 7] bf16 (zero for k >= K)
-__global__ void __launch_bounds__(256) cb_pack_weights_kernel(const float* __restrict__ w, int C, int K, long sc, long sk, int flip, int ntap,
+// packed weights: Wp[kt][phase][cb][sub][t][cg][k & 127][c & 7] bf16 (zero for k >= K); source element (k, c, tap) at w[c * sc + k * sk + srctap]
+struct CbPack { int ntap, nsub, nphase, ksz2; int srctap[2][2][CB_MAXTAP]; };      // [phase][sub][t]
+
+__global__ void __launch_bounds__(256) cb_pack_weights_kernel(const float* __restrict__ w, int C, int K, long sc, long sk, CbPack pk,
                                                               uint4* __restrict__ Wp, uint4* __restrict__ zero_page)
 {
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 4) zero_page[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     const int k = blockIdx.x * 256 + threadIdx.x;          // padded produced channel
-    const int c8 = blockIdx.y, t = blockIdx.z;
+    const int c8 = blockIdx.y;
+    const int t = blockIdx.z % pk.ntap, ps = blockIdx.z / pk.ntap, sub = ps % pk.nsub, phase = ps / pk.nsub;
     const int ktiles = (K + CB_K - 1) / CB_K;
     if (k >= ktiles * CB_K) return;
-    const int tap = flip ? ntap - 1 - t : t;
+    const int tap = pk.srctap[phase][sub][t];
     unsigned short h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -75,74 +92,89 @@ __global__ void __launch_bounds__(256) cb_pack_weights_kernel(const float* __res
     o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
     o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
     const int kt = k >> 7, kl = k & 127, cb = c8 >> 1, cg = c8 & 1;
-    const int nstage = C / CB_C;
-    Wp[((((size_t)kt * nstage + cb) * ntap + t) * 2 + cg) * CB_K + kl] = o;
+    const int ncb = C / CB_C;
+    Wp[((((((size_t)kt * pk.nphase + phase) * ncb + cb) * pk.nsub + sub) * pk.ntap + t) * 2 + cg) * CB_K + kl] = o;
 }
 
-template <int NTAP, typename TOUT>
+template <int MODE, typename TOUT>
 __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned short* __restrict__ in, const uint4* __restrict__ Wp,
                                                                   const uint4* __restrict__ zero_page, CbGeom g, TOUT* __restrict__ out)
 {
+    constexpr int NTAP = MODE == CB_S1 ? 9 : 8;
+    constexpr int NSET = MODE == CB_C2F ? 2 : 1;               // accumulator sets (C2F: the two column phases of the fine output)
+    constexpr int TPSET = NTAP / NSET;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];          // 2 x (A | raw | T)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int r = lane & 31, h = lane >> 5;
 
-    // tile: all k tiles of one pixel tile are neighbours (they share the activation tile in L2)
+    // tile: all (k tile, row phase) workgroups of one pixel tile are neighbours (they share the activation tile in L2)
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const int kt = L % g.ktiles, pt = L / g.ktiles;
-    const int tiles_per_img = g.H / g.R;
+    const int per_pt = g.ktiles * g.nphase;
+    const int pt = L / per_pt, kp = L - pt * per_pt;
+    const int kt = kp % g.ktiles, phase = kp / g.ktiles;
+    const int tiles_per_img = g.Hl / g.R;
     const int b = pt / tiles_per_img, y0 = (pt - b * tiles_per_img) * g.R;
 
     // ---- stage-invariant addresses ------------------------------------------------------------------------------------------
-    // raw tile DMA: chunk q (16 bytes = 8 pixels) = (c, row, seg), LDS image linear in q
-    const int segs = g.W >> 3, nchunk = CB_C * g.NR * segs;
-    const unsigned short* gx[2];
-    bool xlive[2];
+    // raw tile DMA: chunk q (16 bytes = 8 pixels) = (c, row, seg), LDS image linear in q; per sub-stage its own row set
+    const int segs = g.Win >> 3, nchunk = CB_C * g.NR * segs;
+    constexpr int XJ = 3;                                  // 16-byte chunks per thread: up to 1280 (stride 2, 64-wide coarse grid)
+    const unsigned short* gx[XJ][MODE == CB_F2C ? 2 : 1];
+    bool xlive[XJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < XJ; ++j) {
         const int q = tid + CB_THREADS * j;
         xlive[j] = q < nchunk;
         const int qq = xlive[j] ? q : 0;
         const int seg = qq % segs, row = (qq / segs) % g.NR, c = qq / (segs * g.NR);
-        const int y = y0 - 1 + row;
-        const bool inside = (unsigned)y < (unsigned)g.H;
-        gx[j] = inside ? in + (((size_t)b * g.C + c) * g.H + y) * g.W + seg * 8 : nullptr;
+#pragma unroll
+        for (int e = 0; e < (MODE == CB_F2C ? 2 : 1); ++e) {
+            const int y = g.ymul * y0 + g.yoff[e] + g.rowstep * row;
+            const bool inside = (unsigned)y < (unsigned)g.Hin;
+            gx[j][e] = inside ? in + (((size_t)b * g.C + c) * g.Hin + y) * g.Win + seg * 8 : nullptr;
+        }
     }
-    const size_t xstride = (size_t)CB_C * g.H * g.W;
-    // A tile DMA: NTAP * 4 pieces of 1 KiB, piece = wave + 8 j
+    const size_t xstride = (size_t)CB_C * g.Hin * g.Win;
+    // A tile DMA: NTAP * 4 pieces of 1 KiB, piece = wave + 8 j; the stages of (kt, phase) are contiguous
     constexpr int NPIECE = NTAP * 4, APW = (NPIECE + 7) / 8;
-    const uint4* ga = Wp + ((size_t)kt * g.nstage) * (NTAP * 2 * CB_K) + lane;
+    const uint4* ga = Wp + ((size_t)(kt * g.nphase + phase) * g.nstage) * (NTAP * 2 * CB_K) + lane;
     // transposition: block u = (c quad, row, 16-pixel block); lane 4q+p of a 16-lane group supplies row q, pixels 4p..4p+3
     const int grp = tid >> 4, li = tid & 15;
-    const int cb16s = g.W >> 4, nblk = 4 * g.NR * cb16s;
+    const int cb16s = g.Win >> 4, nblk = 4 * g.NR * cb16s;
     int tr_rd[CB_TR_MAX], tr_wr[CB_TR_MAX];
 #pragma unroll
     for (int j = 0; j < CB_TR_MAX; ++j) {
         int u = grp + 32 * j;
         if (u >= nblk) u = nblk - 1;                       // duplicates the last block (same data to the same place): EXEC stays full
         const int cb16 = u % cb16s, row = (u / cb16s) % g.NR, cq = u / (cb16s * g.NR);
-        tr_rd[j] = (((cq * 4 + (li >> 2)) * g.NR + row) * g.W + cb16 * 16 + (li & 3) * 4) * 2;
-        tr_wr[j] = (((cq >> 1) * g.NPOS + row * g.PW + cb16 * 16 + li + 1) * 8 + (cq & 1) * 4) * 2;
+        tr_rd[j] = (((cq * 4 + (li >> 2)) * g.NR + row) * g.Win + cb16 * 16 + (li & 3) * 4) * 2;
+        const int x = cb16 * 16 + li;
+        int pos;
+        if (MODE == CB_F2C) { const int ex = x & 1; pos = (ex * 2 + (cq >> 1)) * g.NPOS + row * g.PW + (x >> 1) + ex; }      // x = 2 j + ex; plane 1 starts at j = -1
+        else pos = (cq >> 1) * g.NPOS + row * g.PW + x + 1;
+        tr_wr[j] = (pos * 8 + (cq & 1) * 4) * 2;
     }
     const int ntr = (nblk + 31) / 32;
-    // fragments: A rows wm*64 + {0,32} + r; B pixels wn*64 + {0,32} + r
+    // fragments: A rows wm*64 + {0,32} + r; B lane-grid pixels wn*64 + {0,32} + r
     const int a_off = (h * CB_K + wm * 64 + r) * 16;
     int b_off[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int p = wn * 64 + j * 32 + r;
-        b_off[j] = (h * g.NPOS + (p >> g.wshift) * g.PW + (p & (g.W - 1))) * 16;
+        b_off[j] = (h * g.NPOS + (p >> g.wshift) * g.PW + (p & (g.Wl - 1))) * 16;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[NSET][2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int q = 0; q < NSET; ++q)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[q][i][j][e] = 0.0f;
 
     auto dma_a = [&](int buf, int stage) {
         const uint4* src = ga + (size_t)stage * (NTAP * 2 * CB_K);
@@ -154,10 +186,12 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
         }
     };
     auto dma_x = [&](int buf, int stage) {
+        const int cb = MODE == CB_F2C ? stage >> 1 : stage, e = MODE == CB_F2C ? stage & 1 : 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < XJ; ++j) {
             if (xlive[j]) {
-                const void* src = gx[j] ? static_cast<const void*>(gx[j] + (size_t)stage * xstride) : static_cast<const void*>(zero_page);
+                const unsigned short* base = (MODE == CB_F2C && e) ? gx[j][MODE == CB_F2C ? 1 : 0] : gx[j][0];
+                const void* src = base ? static_cast<const void*>(base + (size_t)cb * xstride) : static_cast<const void*>(zero_page);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + buf * CB_BUF + CB_A_BYTES + (wave * 64 + CB_THREADS * j) * 16), 16, 0, 0);
             }
         }
@@ -174,10 +208,10 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
             if (j < ntr) *reinterpret_cast<s16x4*>(T + tr_wr[j]) = v[j];
     };
 
-    // halo columns of both T images: zero, never written again (tiles span the full image width)
-    for (int i = tid; i < 2 * 2 * g.NR * 2; i += CB_THREADS) {
-        const int side = i & 1, row = (i >> 1) % g.NR, cg = ((i >> 1) / g.NR) & 1, buf = (i >> 1) / (2 * g.NR);
-        *reinterpret_cast<uint4*>(lds + buf * CB_BUF + CB_A_BYTES + CB_RAW_BYTES + (cg * g.NPOS + row * g.PW + (side ? g.PW - 1 : 0)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    // both T images start as zeros: the halo columns are never written (tiles span the full image width)
+    for (int i = tid; i < 2 * (CB_T_BYTES / 16); i += CB_THREADS) {
+        const int buf = i / (CB_T_BYTES / 16), o = i - buf * (CB_T_BYTES / 16);
+        *reinterpret_cast<uint4*>(lds + buf * CB_BUF + CB_A_BYTES + CB_RAW_BYTES + o * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
     // prologue: A[0], raw[0] <- stage 0; raw[1] <- stage 1
     dma_a(0, 0);
@@ -195,54 +229,130 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
         if (s + 1 < g.nstage) transpose(nxt);                  // raw[nxt] (stage s+1) landed before the barrier that ended stage s-1
         const unsigned char* A = lds + cur * CB_BUF + a_off;
         const unsigned char* T = lds + cur * CB_BUF + CB_A_BYTES + CB_RAW_BYTES;
+        const int* toff = g.tapoff[MODE == CB_F2C ? (s & 1) : (MODE == CB_C2F ? phase : 0)];
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
+            const int q = t / TPSET;
             const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + (t * 2 * CB_K) * 16);
             const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + (t * 2 * CB_K + 32) * 16);
-            const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(T + b_off[0] + g.tapoff[t] * 16);
-            const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(T + b_off[1] + g.tapoff[t] * 16);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+            const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(T + b_off[0] + toff[t] * 16);
+            const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(T + b_off[1] + toff[t] * 16);
+            acc[q][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[q][0][0], 0, 0, 0);
+            acc[q][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[q][0][1], 0, 0, 0);
+            acc[q][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[q][1][0], 0, 0, 0);
+            acc[q][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[q][1][1], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this stage's DMAs are the next stage's operands
         __syncthreads();
     }
 
-    // epilogue: lane = pixel, register = channel
-    const size_t HW = (size_t)g.H * g.W;
+    // epilogue: lane = lane-grid pixel, register = channel
+    const size_t HWo = (size_t)g.Hout * g.Wout;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int p = wn * 64 + j * 32 + r;
-        TOUT* op = out + (size_t)b * g.K * HW + (size_t)(y0 + (p >> g.wshift)) * g.W + (p & (g.W - 1));
+        const int py = y0 + (p >> g.wshift), px = p & (g.Wl - 1);
+        if (MODE == CB_C2F) {
+            // fine row 2 py + phase, fine columns 2 px and 2 px + 1 (the two accumulator sets): one 2-element store
+            TOUT* op = out + (size_t)b * g.K * HWo + (size_t)(2 * py + phase) * g.Wout + 2 * px;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = kt * CB_K + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (k < g.K) st1(op, (size_t)k * HW, acc[i][j][e]);
-            }
+                for (int e = 0; e < 16; ++e) {
+                    const int k = kt * CB_K + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (k < g.K) {
+                        if (sizeof(TOUT) == 2) {
+                            const unsigned pk = (unsigned)f2bf(acc[0][i][j][e]) | ((unsigned)f2bf(acc[NSET - 1][i][j][e]) << 16);
+                            *reinterpret_cast<unsigned*>(op + (size_t)k * HWo) = pk;
+                        } else {
+                            *reinterpret_cast<float2*>(op + (size_t)k * HWo) = make_float2(acc[0][i][j][e], acc[NSET - 1][i][j][e]);
+                        }
+                    }
+                }
+        } else {
+            const bool live = py < g.Hout && px < g.Wout;      // (lane grid == output grid here)
+            TOUT* op = out + (size_t)b * g.K * HWo + (size_t)py * g.Wout + px;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = kt * CB_K + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (live && k < g.K) st1(op, (size_t)k * HWo, acc[0][i][j][e]);
+                }
+        }
     }
 }
 
+static int cb_lane_grid(int Hl, int Wl, CbGeom* g, const char* who)
+{
+    if (Wl != 16 && Wl != 32 && Wl != 64 && Wl != 128) return fail(IPSR_ERR_UNSUPPORTED, "%s: grid width %d (16, 32, 64 or 128)", who, Wl);
+    const int R = CB_P / Wl;
+    if (Hl % R != 0) return fail(IPSR_ERR_UNSUPPORTED, "%s: %d rows are not a multiple of the %d rows of a tile", who, Hl, R);
+    g->Hl = Hl; g->Wl = Wl; g->R = R;
+    g->wshift = Wl == 16 ? 4 : (Wl == 32 ? 5 : (Wl == 64 ? 6 : 7));
+    return IPSR_OK;
+}
+
+static int cb_finish(CbGeom* g, const char* who)
+{
+    g->NPOS = g->NR * g->PW;
+    g->ktiles = (g->K + CB_K - 1) / CB_K;
+    g->ptiles = g->B * (g->Hl / g->R);
+    g->nstage = (g->C / CB_C) * g->nsub;
+    const int planes = g->nsub;                               // F2C keeps the two column phases
+    if (CB_C * g->NR * g->Win * 2 > CB_RAW_BYTES || planes * 2 * g->NPOS * 16 > CB_T_BYTES || 4 * g->NR * (g->Win / 16) > 32 * CB_TR_MAX ||
+        CB_C * g->NR * (g->Win / 8) > 3 * CB_THREADS)
+        return fail(IPSR_ERR_UNSUPPORTED, "%s: a tile of %d rows x %d does not fit the LDS plan", who, g->NR, g->Win);
+    return IPSR_OK;
+}
+
+// k3 s1 p1
 static int cb_geometry(int B, int C, int K, int H, int W, CbGeom* g)
 {
-    if (W != 16 && W != 32 && W != 64 && W != 128) return fail(IPSR_ERR_UNSUPPORTED, "bf16 direct conv: image width %d (16, 32, 64 or 128)", W);
-    const int R = CB_P / W;
-    if (H % R != 0) return fail(IPSR_ERR_UNSUPPORTED, "bf16 direct conv: %d rows are not a multiple of the %d rows of a tile", H, R);
     if (C % CB_C != 0) return fail(IPSR_ERR_UNSUPPORTED, "bf16 direct conv: %d reduction channels are not a multiple of %d", C, CB_C);
-    g->B = B; g->C = C; g->K = K; g->H = H; g->W = W;
-    g->wshift = W == 16 ? 4 : (W == 32 ? 5 : (W == 64 ? 6 : 7));
-    g->R = R; g->NR = R + 2; g->PW = W + 2; g->NPOS = g->NR * g->PW;
-    g->ntap = 9;
-    for (int t = 0; t < 9; ++t) g->tapoff[t] = (t / 3) * g->PW + (t % 3);
-    g->ktiles = (K + CB_K - 1) / CB_K;
-    g->ptiles = B * (H / R);
-    g->nstage = C / CB_C;
-    if (CB_C * g->NR * W * 2 > CB_RAW_BYTES || 2 * g->NPOS * 16 > CB_T_BYTES || 4 * g->NR * (W / 16) > 32 * CB_TR_MAX)
-        return fail(IPSR_ERR_UNSUPPORTED, "bf16 direct conv: tile of %d rows x %d does not fit the LDS plan", g->NR, W);
-    return IPSR_OK;
+    if (int rc = cb_lane_grid(H, W, g, "bf16 direct conv")) return rc;
+    g->B = B; g->C = C; g->K = K; g->Hin = H; g->Win = W; g->Hout = H; g->Wout = W;
+    g->NR = g->R + 2; g->PW = W + 2;
+    g->ymul = 1; g->rowstep = 1; g->yoff[0] = -1; g->yoff[1] = -1;
+    g->nsub = 1; g->nphase = 1; g->ntap = 9;
+    for (int t = 0; t < 9; ++t) g->tapoff[0][t] = g->tapoff[1][t] = (t / 3) * g->PW + (t % 3);
+    return cb_finish(g, "bf16 direct conv");
+}
+
+// k4 s2 p1: fine [.,Cf,2nh,2nw], coarse [.,Kc,nh,nw].  form 0: fine -> coarse (C = Cf reduced, K = Kc produced); 1: coarse -> fine
+static int cb_geometry_s2(int form, int B, int C, int K, int nh, int nw, CbGeom* g)
+{
+    if (C % CB_C != 0) return fail(IPSR_ERR_UNSUPPORTED, "bf16 direct 4x4 stride-2 conv: %d reduction channels are not a multiple of %d", C, CB_C);
+    if (int rc = cb_lane_grid(nh, nw, g, "bf16 direct 4x4 stride-2 conv")) return rc;
+    g->B = B; g->C = C; g->K = K;
+    if (form == 0) {
+        g->Hin = 2 * nh; g->Win = 2 * nw; g->Hout = nh; g->Wout = nw;
+        g->NR = g->R + 1; g->PW = nw + 1;
+        g->ymul = 2; g->rowstep = 2; g->yoff[0] = 0; g->yoff[1] = -1;       // sub-stage e = input row parity: rows 2 (y0 + i) + e - 2 e
+        g->nsub = 2; g->nphase = 1; g->ntap = 8;
+        g->NPOS = g->NR * g->PW;
+        // tap t = ri * 4 + s of sub-stage e: r = e ? {0, 2}[ri] : {1, 3}[ri]; input row 2 oy - 1 + r = 2 (oy + drow - (e ? 1 : 0)) + e  ->  drow = ri
+        // column 2 ox - 1 + s: s even -> odd column (plane 1, j = ox - 1 + s / 2, stored at j + 1), s odd -> even column (plane 0, j = ox + s / 2)
+        for (int e = 0; e < 2; ++e)
+            for (int t = 0; t < 8; ++t) {
+                const int ri = t >> 2, sx = t & 3, ex = (sx & 1) ? 0 : 1, dcol = sx >> 1;
+                g->tapoff[e][t] = ex * 2 * g->NPOS + ri * g->PW + dcol;
+            }
+    } else {
+        g->Hin = nh; g->Win = nw; g->Hout = 2 * nh; g->Wout = 2 * nw;
+        g->NR = g->R + 2; g->PW = nw + 2;
+        g->ymul = 1; g->rowstep = 1; g->yoff[0] = -1; g->yoff[1] = -1;
+        g->nsub = 1; g->nphase = 2; g->ntap = 8;
+        g->NPOS = g->NR * g->PW;
+        // row phase ey' (workgroup), column phase ex' (accumulator set), taps (ai, bi): fine row 2 i + ey' takes coarse rows
+        // ey' = 0: {i (r = 1), i - 1 (r = 3)};  ey' = 1: {i + 1 (r = 0), i (r = 2)}  ->  raw row (i - y0) + 1 + d, d = ey' - ai
+        for (int ey = 0; ey < 2; ++ey)
+            for (int t = 0; t < 8; ++t) {
+                const int ex = t >> 2, ai = (t >> 1) & 1, bi = t & 1;
+                g->tapoff[ey][t] = (1 + ey - ai) * g->PW + (1 + ex - bi);
+            }
+    }
+    return cb_finish(g, "bf16 direct 4x4 stride-2 conv");
 }
 
 size_t conv_bf16_ws_bytes(int B, int C, int K, int H, int W)
@@ -250,6 +360,38 @@ size_t conv_bf16_ws_bytes(int B, int C, int K, int H, int W)
     CbGeom g;
     if (cb_geometry(B, C, K, H, W, &g) != IPSR_OK) return 0;
     return 256 + (size_t)g.ktiles * g.nstage * 9 * 2 * CB_K * 16;
+}
+
+size_t conv_bf16_s2_ws_bytes(int form, int B, int C, int K, int nh, int nw)
+{
+    CbGeom g;
+    if (cb_geometry_s2(form, B, C, K, nh, nw, &g) != IPSR_OK) return 0;
+    return 256 + (size_t)g.ktiles * g.nphase * g.nstage * 8 * 2 * CB_K * 16;
+}
+
+template <int MODE>
+static int cb_launch(const CbGeom& g, const CbPack& pk, const void* in, const float* w, void* out, long sc, long sk, int out_bf16, void* ws,
+                     hipStream_t st, double taps_per_out)
+{
+    uint4* zero_page = static_cast<uint4*>(ws);
+    uint4* Wp = zero_page + 16;
+    cb_pack_weights_kernel<<<dim3(cdiv(g.ktiles * CB_K, 256), g.C / 8, pk.ntap * pk.nsub * pk.nphase), 256, 0, st>>>(w, g.C, g.K, sc, sk, pk, Wp, zero_page);
+    if (int rc = check_launch("cb_pack_weights_kernel")) return rc;
+    const unsigned grid = (unsigned)(g.ktiles * g.nphase * g.ptiles);
+    const size_t smem = 2 * (size_t)CB_BUF;
+    profile_mark_start(st, 3);
+    if (out_bf16) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+        conv_bf16_kernel<MODE, bf16_t><<<grid, CB_THREADS, smem, st>>>(static_cast<const unsigned short*>(in), Wp, zero_page, g, static_cast<bf16_t*>(out));
+    } else {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+        conv_bf16_kernel<MODE, float><<<grid, CB_THREADS, smem, st>>>(static_cast<const unsigned short*>(in), Wp, zero_page, g, static_cast<float*>(out));
+    }
+    const double outs = (double)g.B * g.Hout * g.Wout;
+    profile_mark_stop(st, 3, 2.0 * taps_per_out * g.C * (double)(g.ktiles * CB_K) * outs, 2.0 * taps_per_out * g.C * (double)g.K * outs);
+    return check_launch("conv_bf16_kernel");
 }
 
 // in [B,C,H,W] bf16, weight fp32 with element (c, k, tap) at w[c*sc + k*sk + tap] (taps flipped when `flip`), out [B,K,H,W] bf16 / fp32
@@ -260,24 +402,41 @@ int launch_conv_bf16(const void* in, const float* w, void* out, int B, int C, in
     if (int rc = cb_geometry(B, C, K, H, W, &g)) return rc;
     const size_t need = conv_bf16_ws_bytes(B, C, K, H, W);
     if (ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "bf16 direct conv: workspace %zu < %zu", ws_bytes, need);
-    uint4* zero_page = static_cast<uint4*>(ws);
-    uint4* Wp = zero_page + 16;
-    cb_pack_weights_kernel<<<dim3(cdiv(g.ktiles * CB_K, 256), C / 8, 9), 256, 0, st>>>(w, C, K, sc, sk, flip, 9, Wp, zero_page);
-    if (int rc = check_launch("cb_pack_weights_kernel")) return rc;
-    const unsigned grid = (unsigned)(g.ktiles * g.ptiles);
-    const size_t smem = 2 * (size_t)CB_BUF;
-    profile_mark_start(st, 3);
-    if (out_bf16) {
-        static bool attr_b = false;
-        if (!attr_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<9, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_b = true; }
-        conv_bf16_kernel<9, bf16_t><<<grid, CB_THREADS, smem, st>>>(static_cast<const unsigned short*>(in), Wp, zero_page, g, static_cast<bf16_t*>(out));
-    } else {
-        static bool attr_f = false;
-        if (!attr_f) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<9, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_f = true; }
-        conv_bf16_kernel<9, float><<<grid, CB_THREADS, smem, st>>>(static_cast<const unsigned short*>(in), Wp, zero_page, g, static_cast<float*>(out));
+    CbPack pk{};
+    pk.ntap = 9; pk.nsub = 1; pk.nphase = 1;
+    for (int t = 0; t < 9; ++t) pk.srctap[0][0][t] = flip ? 8 - t : t;
+    return cb_launch<CB_S1>(g, pk, in, w, out, sc, sk, out_bf16, ws, st, 9.0);
+}
+
+// k4 s2 p1.  weight [Kc][Cf][4][4]: element (coarse channel kc, fine channel cf, r, s) at w[kc * skc + cf * scf + r * 4 + s].
+// form 0 (fine -> coarse): in = fine [B,Cf,2nh,2nw], out = coarse [B,Kc,nh,nw].   form 1 (coarse -> fine): in = coarse, out = fine.
+int launch_conv_bf16_s2(int form, const void* in, const float* w, void* out, int B, int Kc, int Cf, int nh, int nw, long skc, long scf,
+                        int out_bf16, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    CbGeom g;
+    const int C = form == 0 ? Cf : Kc, K = form == 0 ? Kc : Cf;
+    if (int rc = cb_geometry_s2(form, B, C, K, nh, nw, &g)) return rc;
+    const size_t need = conv_bf16_s2_ws_bytes(form, B, C, K, nh, nw);
+    if (ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "bf16 direct 4x4 stride-2 conv: workspace %zu < %zu", ws_bytes, need);
+    CbPack pk{};
+    pk.ntap = 8;
+    if (form == 0) {
+        pk.nsub = 2; pk.nphase = 1;
+        for (int e = 0; e < 2; ++e)
+            for (int t = 0; t < 8; ++t) {
+                const int ri = t >> 2, sx = t & 3, rr = e ? 2 * ri : 2 * ri + 1;
+                pk.srctap[0][e][t] = rr * 4 + sx;
+            }
+        return cb_launch<CB_F2C>(g, pk, in, w, out, scf, skc, out_bf16, ws, st, 16.0);
     }
-    profile_mark_stop(st, 3, 2.0 * 9.0 * C * (double)(g.ktiles * CB_K) * B * H * W, 2.0 * 9.0 * C * (double)K * B * H * W);
-    return check_launch("conv_bf16_kernel");
+    pk.nsub = 1; pk.nphase = 2;
+    for (int ey = 0; ey < 2; ++ey)
+        for (int t = 0; t < 8; ++t) {
+            const int ex = t >> 2, ai = (t >> 1) & 1, bi = t & 1;
+            const int rr = ey == 0 ? (ai ? 3 : 1) : (ai ? 2 : 0), ss = ex == 0 ? (bi ? 3 : 1) : (bi ? 2 : 0);
+            pk.srctap[ey][0][t] = rr * 4 + ss;
+        }
+    return cb_launch<CB_C2F>(g, pk, in, w, out, skc, scf, out_bf16, ws, st, 4.0);
 }
 
 // =====================================================================================================================================
@@ -531,6 +690,23 @@ int ipsr_conv3x3_bf16(int op, const void* in, const float* weight, void* out, in
         case 2: return launch_conv_bf16(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, out_bf16, ws, ws_bytes, st);
         default: return launch_conv_bf16(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, out_bf16, ws, ws_bytes, st);
     }
+}
+
+size_t ipsr_conv4x4s2_bf16_workspace_bytes(int mode, int B, int Kc, int Cf, int nh, int nw)
+{
+    if (mode < 0 || mode > 1 || B < 1 || Kc < 1 || Cf < 1 || nh < 1 || nw < 1) return 0;
+    return conv_bf16_s2_ws_bytes(mode, B, mode == 0 ? Cf : Kc, mode == 0 ? Kc : Cf, nh, nw);
+}
+
+int ipsr_conv4x4s2_bf16(int mode, const void* in, const float* weight, void* out, int B, int Kc, int Cf, int nh, int nw, int out_bf16,
+                        void* ws, size_t ws_bytes, void* stream)
+{
+    if (!in || !weight || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_bf16: null pointer");
+    if (mode < 0 || mode > 1 || B < 1 || Kc < 1 || Cf < 1 || nh < 1 || nw < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_bf16: bad argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(in) & 15u) || (reinterpret_cast<uintptr_t>(out) & 7u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_bf16: in / out / workspace must be 16-byte aligned");
+    // weight [Kc][Cf][4][4] in both modules (Conv2d: [Cout][Cin], ConvTranspose2d: [Cin][Cout]), as in ipsr_conv4x4s2_winograd
+    return launch_conv_bf16_s2(mode, in, weight, out, B, Kc, Cf, nh, nw, (long)Cf * 16, 16, out_bf16, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t ipsr_conv3x3_bf16_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout)

@@ -48,6 +48,12 @@ _MATH = {"fp32": "fp32", "bf16": "bf16x3"}
 _BF16_ENGINES = ("winograd", "wino_dil", "wino_s2", "bf16d")         # the engines that read / write bf16 activation tensors
 
 
+# fp32 engines whose operands are small next to their weight stream / single pass (the innermost levels, netD's one-channel head): under
+# bf16 activations they run on fp32 copies of the activations (a cast of a few hundred KB) instead of falling back to MIOpen's
+# transposes + 40-160 us kernels
+_CAST_ENGINES = ("one", "smallmap")
+
+
 def set_conv_math(fp32=None, bf16=None):
     """Choose the arithmetic of the Winograd engines for fp32 activations and for bf16 activations (autocast)."""
     from .. import ops as _ops
@@ -74,7 +80,7 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     eng = _select(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0") + os.environ.get("IPSR_NO_THIN", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
     if not bf16:
         return eng
-    if _bf16_wins(eng, Cin, H, W, Cout):
+    if _bf16_wins(eng, Cin, H, W, Cout) or eng in _CAST_ENGINES:
         return eng
     return _bf16_direct(os.environ.get("IPSR_BF16_ENGINES", ""), _mode(), op, B, Cin, H, W, Cout, k, stride, pad, dil)
 
@@ -89,6 +95,14 @@ def _bf16_direct(force, mode, op, B, Cin, H, W, Cout, k, stride, pad, dil):
         return "miopen"
     if k == 3 and stride == 1 and pad == 1 and dil == 1 and H * W >= 1024 and ops.conv3x3_bf16_supported(op, B, Cin, H, W, Cout):
         return "bf16d"
+    g = _s2_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
+    if g is not None and ops.conv4x4s2_bf16_supported(_s2_mode(op), B, *g):
+        # the 4x4 stride-2 family (profiles/r04_conv_bf16_layers.txt, batch 16): 1.3-2x MIOpen wherever the launch has enough tiles;
+        # a 16x16 coarse grid gives one pixel tile per image (64 workgroups at 512 channels) and MIOpen ties or wins
+        Kc, Cf, nh, nw = g
+        if _s2_mode(op) == ops.S2_FINE_TO_COARSE:
+            return "bf16d" if nw >= 32 and ((Kc + 127) // 128) * B * nh * nw // 256 >= 128 else "miopen"
+        return "bf16d" if not (nw == 16 and Kc >= 1024) else "miopen"
     return "miopen"
 
 
@@ -242,7 +256,7 @@ def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     eng = _select_wrw(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0"), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
     if not bf16:
         return eng
-    if _bf16_wins(eng, Cin, H, W, Cout, True):
+    if _bf16_wins(eng, Cin, H, W, Cout, True) or eng in _CAST_ENGINES:
         return eng
     return _bf16_direct_wrw(os.environ.get("IPSR_BF16_ENGINES", ""), _mode(), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
 
@@ -287,6 +301,13 @@ def _select_wrw(mode, _nosm, transposed, B, Cin, H, W, Cout, k, stride, pad, dil
     return "miopen"
 
 
+def _bf16_direct_call(op, inp, w, transposed, B, Cin, H, W, Cout, k, stride, pad, dil, out_dtype):
+    """One pass of a module on the direct bf16 kernels (csrc/conv_bf16.hip): k3 s1 p1, or k4 s2 p1 in its coarse / fine form."""
+    if k == 3:
+        return ops.conv3x3_bf16(op, inp, w, (B, Cin, H, W), Cout, out_dtype=out_dtype)
+    return ops.conv4x4s2_bf16(_s2_mode(op), inp, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out_dtype=out_dtype)
+
+
 def _miopen_forward(x, w, transposed, stride, pad, dil):
     if x.dtype != w.dtype and not torch.is_autocast_enabled():
         w = w.to(x.dtype)
@@ -316,15 +337,15 @@ class _HipConv(torch.autograd.Function):
         elif eng_fwd == "direct":
             y = ops.conv2d(op, xc, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng_fwd == "bf16d":
-            y = ops.conv3x3_bf16(op, xc if xc.dtype == torch.bfloat16 else xc.to(torch.bfloat16), w, (B, Cin, H, W), Cout, out_dtype=act)
+            y = _bf16_direct_call(op, xc if xc.dtype == torch.bfloat16 else xc.to(torch.bfloat16), w, transposed, B, Cin, H, W, Cout, k, stride, pad, dil, act)
         elif eng_fwd == "wino_dil":
             y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=act)
         elif eng_fwd == "thin":
             y = ops.conv3x3_thin(op, xc, w, (B, Cin, H, W), Cout)
         elif eng_fwd == "one":
-            y = ops.conv_to_one(xc, w, pad)
+            y = ops.conv_to_one(xc.float(), w, pad).to(act)
         elif eng_fwd == "smallmap":
-            y = ops.conv_smallmap(_smallmap_op(op), xc, w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
+            y = ops.conv_smallmap(_smallmap_op(op), xc.float(), w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)).to(act)
         elif eng_fwd == "wino_s2":
             y = ops.conv4x4s2_winograd(_s2_mode(op), xc, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), math=math, out_dtype=act)
         else:
@@ -354,13 +375,13 @@ class _HipConv(torch.autograd.Function):
             elif eng == "direct":
                 dx = ops.conv2d(op, dy, w, (B, Cin, H, W), Cout, k, stride, pad, dil)
             elif eng == "bf16d":
-                dx = ops.conv3x3_bf16(op, dy, w, (B, Cin, H, W), Cout, out_dtype=x.dtype)
+                dx = _bf16_direct_call(op, dy, w, transposed, B, Cin, H, W, Cout, k, stride, pad, dil, x.dtype)
             elif eng == "wino_dil":
                 dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=x.dtype)
             elif eng == "thin":
                 dx = ops.conv3x3_thin(op, dy, w, (B, Cin, H, W), Cout)
             elif eng == "smallmap":
-                dx = ops.conv_smallmap(_smallmap_op(op), dy, w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
+                dx = ops.conv_smallmap(_smallmap_op(op), dy.float(), w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)).to(x.dtype)
             elif eng == "wino_s2":
                 dx = ops.conv4x4s2_winograd(_s2_mode(op), dy, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), math=math, out_dtype=x.dtype)
             else:
@@ -380,9 +401,9 @@ class _HipConv(torch.autograd.Function):
         elif weng == "wino_dil":
             dw = ops.conv4x4_dilated_winograd(2, xw, dy, (B, Cin, H, W), Cout, out=sink, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math)
         elif weng == "one":
-            dw = ops.conv_to_one_wrw(x, dy, k, pad, out=sink)
+            dw = ops.conv_to_one_wrw(x.float(), dy.float(), k, pad, out=sink)
         elif weng == "smallmap":
-            coarse, fine = (x, dy) if transposed else (dy, x)
+            coarse, fine = (x.float(), dy.float()) if transposed else (dy.float(), x.float())
             dw = ops.conv_smallmap(ops.SM_WRW, coarse, fine, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out=sink)
         elif weng == "wino_s2":
             fine, coarse = (dy, xw) if transposed else (xw, dy)
@@ -456,16 +477,16 @@ def conv_nobias(m, x, weight=None):
             return ops.conv2d(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, k, stride, pad, dil)
         elif eng == "bf16d":
             xb = x.contiguous()
-            return ops.conv3x3_bf16(op, xb if xb.dtype == torch.bfloat16 else xb.to(torch.bfloat16), w.detach(), (B, Cin, H, W), Cout, out_dtype=act)
+            return _bf16_direct_call(op, xb if xb.dtype == torch.bfloat16 else xb.to(torch.bfloat16), w.detach(), transposed, B, Cin, H, W, Cout, k, stride, pad, dil, act)
         elif eng == "wino_dil":
             return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil),
                                                 math=math, out_dtype=act)
         elif eng == "thin":
             return ops.conv3x3_thin(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout)
         elif eng == "one":
-            return ops.conv_to_one(x.contiguous(), w.detach(), pad)
+            return ops.conv_to_one(x.contiguous().float(), w.detach(), pad).to(act)
         elif eng == "smallmap":
-            return ops.conv_smallmap(_smallmap_op(op), x.contiguous(), w.detach(), *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil))
+            return ops.conv_smallmap(_smallmap_op(op), x.contiguous().float(), w.detach(), *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)).to(act)
         elif eng == "wino_s2":
             return ops.conv4x4s2_winograd(_s2_mode(op), x.contiguous(), w.detach(), B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil),
                                           math=math, out_dtype=act)

@@ -582,6 +582,35 @@ def conv3x3_bf16(op, inp, weight, in_shape, Cout, out_dtype=torch.bfloat16):
     return out
 
 
+def conv4x4s2_bf16_supported(mode, B, Kc, Cf, nh, nw):
+    return mode in (S2_FINE_TO_COARSE, S2_COARSE_TO_FINE) and _lib.lib().ipsr_conv4x4s2_bf16_workspace_bytes(mode, B, Kc, Cf, nh, nw) > 0
+
+
+def conv4x4s2_bf16(mode, inp, weight, B, Kc, Cf, nh, nw, out_dtype=torch.bfloat16):
+    """The k4 s2 p1 layers as ONE direct implicit GEMM on the bf16 matrix cores (ipsr_conv4x4s2_bf16), in the coarse / fine terms of
+    conv4x4s2_winograd: mode S2_FINE_TO_COARSE: inp = fine [B,Cf,2nh,2nw] -> coarse [B,Kc,nh,nw]; S2_COARSE_TO_FINE: the reverse.
+    weight [Kc,Cf,4,4] fp32 (Conv2d: [Cout,Cin]; ConvTranspose2d: [Cin,Cout])."""
+    inp, in_bf = _act(inp, "conv input")
+    if not in_bf:
+        raise TypeError("conv4x4s2_bf16 reads bf16 activations, got %s" % inp.dtype)
+    weight = _req(weight, torch.float32, "conv weight")
+    if mode not in (S2_FINE_TO_COARSE, S2_COARSE_TO_FINE):
+        raise ValueError("conv4x4s2_bf16: mode %r" % (mode,))
+    want_in = (B, Cf, 2 * nh, 2 * nw) if mode == S2_FINE_TO_COARSE else (B, Kc, nh, nw)
+    if tuple(inp.shape) != want_in or tuple(weight.shape) != (Kc, Cf, 4, 4):
+        raise RuntimeError("conv4x4s2_bf16 mode %d: input %s / weight %s do not match %s / %s" % (mode, tuple(inp.shape), tuple(weight.shape), want_in, (Kc, Cf, 4, 4)))
+    L = _lib.lib()
+    nbytes = L.ipsr_conv4x4s2_bf16_workspace_bytes(mode, B, Kc, Cf, nh, nw)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv4x4s2_bf16: mode %d on %s is not implemented (%s)" % (mode, (B, Kc, Cf, nh, nw), L.ipsr_last_error().decode("utf-8", "replace")))
+    oshape = (B, Kc, nh, nw) if mode == S2_FINE_TO_COARSE else (B, Cf, 2 * nh, 2 * nw)
+    out = torch.empty(oshape, dtype=out_dtype, device=inp.device)
+    ws = _workspace(nbytes, inp.device)
+    _lib.check(L.ipsr_conv4x4s2_bf16(mode, inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Kc, Cf, nh, nw, int(out_dtype == torch.bfloat16),
+                                     ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv4x4s2_bf16")
+    return out
+
+
 def conv3x3_bf16_wrw_supported(transposed, B, Cin, H, W, Cout):
     return _lib.lib().ipsr_conv3x3_bf16_wrw_workspace_bytes(int(transposed), B, Cin, H, W, Cout) > 0
 

@@ -412,6 +412,14 @@ int ipsr_conv4x4s2_winograd_mp(int mode, const void* a, const void* b, void* out
 size_t ipsr_conv3x3_bf16_workspace_bytes(int op, int B, int Cin, int H, int W, int Cout);
 int ipsr_conv3x3_bf16(int op, const void* in, const float* weight, void* out, int B, int Cin, int H, int W, int Cout, int out_bf16,
                       void* ws, size_t ws_bytes, void* stream);
+/* the 4x4 stride-2 pad-1 layers (every down convolution of netP / netD / netF, every up convolution of netP / netG: models/networks.py:
+ * 235-243, 404-432, 470-495, 510-515) in the coarse / fine terms of ipsr_conv4x4s2_winograd: fine = the 2n-grid tensor [B,Cf,2nh,2nw],
+ * coarse = the n-grid one [B,Kc,nh,nw], weight [Kc][Cf][4][4] for both modules.  mode 0: fine -> coarse (Conv2d forward,
+ * ConvTranspose2d input gradient); mode 1: coarse -> fine (ConvTranspose2d forward, Conv2d input gradient).  Supported: nw in
+ * {16, 32, 64} (mode 1 also 128), nh a multiple of 256 / nw, reduction channels a multiple of 16. */
+size_t ipsr_conv4x4s2_bf16_workspace_bytes(int mode, int B, int Kc, int Cf, int nh, int nw);
+int ipsr_conv4x4s2_bf16(int mode, const void* in, const float* weight, void* out, int B, int Kc, int Cf, int nh, int nw, int out_bf16,
+                        void* ws, size_t ws_bytes, void* stream);
 /* their weight gradient: x [B,Cin,H,W], dy [B,Cout,H,W] bf16 -> dw fp32 in the module's layout (transposed = 0: Conv2d [Cout][Cin][3][3];
  * 1: ConvTranspose2d [Cin][Cout][3][3]).  The reduction over pixels is cut over workgroups; the partial results are added in a fixed
  * order by a second launch (deterministic).  Same shape limits as above. */

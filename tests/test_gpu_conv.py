@@ -620,6 +620,31 @@ def test_direct_bf16_conv_all_passes(tr, Cin, H, W, Cout, B):
         ops.conv3x3_bf16(fop, torch.zeros(1, 16, 12, 24, device="cuda", dtype=torch.bfloat16), torch.zeros((16, 16, 3, 3), device="cuda"), (1, 16, 12, 24), 16)
 
 
+@pytest.mark.parametrize("Kc,Cf,nh,nw,B", [(128, 64, 64, 64, 2), (48, 32, 16, 16, 3), (256, 128, 16, 32, 2), (200, 16, 32, 32, 1), (64, 64, 4, 64, 2), (512, 128, 32, 32, 16)])
+def test_direct_bf16_stride2_family(Kc, Cf, nh, nw, B):
+    """The k4 s2 p1 layers on the direct bf16 kernels: fine -> coarse (Conv2d forward / ConvTranspose2d input gradient: the input row
+    parity is a sub-stage, the column parities two planes of the LDS image) and coarse -> fine (ConvTranspose2d forward / Conv2d input
+    gradient: one workgroup per output row parity, the two column parities interleaved in the store) against fp64 of the bf16-rounded
+    operands — fp32 and bf16 outputs, non-square grids, channel counts off the tile sizes."""
+    from deepinpainting_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(31)
+    fine = torch.randn(B, Cf, 2 * nh, 2 * nw, device="cuda", generator=g).to(torch.bfloat16)
+    coarse = torch.randn(B, Kc, nh, nw, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(Kc, Cf, 4, 4, device="cuda", generator=g) * 0.1
+    wd = w.to(torch.bfloat16).double()
+    c64 = F.conv2d(fine.double(), wd, None, 2, 1)
+    f64 = F.conv_transpose2d(coarse.double(), wd, None, 2, 1)
+    if Cf % 16 == 0:
+        c32 = ops.conv4x4s2_bf16(ops.S2_FINE_TO_COARSE, fine, w, B, Kc, Cf, nh, nw, out_dtype=torch.float32)
+        c16 = ops.conv4x4s2_bf16(ops.S2_FINE_TO_COARSE, fine, w, B, Kc, Cf, nh, nw)
+        assert c16.dtype == torch.bfloat16 and _relerr(c32, c64) <= 1e-5 and _relerr(c16, c64) <= 2.0 ** -8, (_relerr(c32, c64), _relerr(c16, c64))
+    if Kc % 16 == 0:
+        f32 = ops.conv4x4s2_bf16(ops.S2_COARSE_TO_FINE, coarse, w, B, Kc, Cf, nh, nw, out_dtype=torch.float32)
+        f16 = ops.conv4x4s2_bf16(ops.S2_COARSE_TO_FINE, coarse, w, B, Kc, Cf, nh, nw)
+        assert f16.dtype == torch.bfloat16 and _relerr(f32, f64) <= 1e-5 and _relerr(f16, f64) <= 2.0 ** -8, (_relerr(f32, f64), _relerr(f16, f64))
+    assert not ops.conv4x4s2_bf16_supported(ops.S2_FINE_TO_COARSE, B, Kc, Cf, nh, 24) and not ops.conv4x4s2_bf16_supported(ops.S2_WEIGHT_GRAD, B, Kc, Cf, nh, nw)
+
+
 def test_direct_bf16_conv_through_the_modules_under_autocast():
     """models/hipconv.py with bf16 activations: the k3 s1 p1 modules run forward, input gradient and weight gradient on the direct
     bf16 engine ("bf16d") from 32x32 maps up — asserted through the dispatcher's own hook — and match the fp32 module to bf16 accuracy."""
@@ -629,22 +654,23 @@ def test_direct_bf16_conv_through_the_modules_under_autocast():
     seen = []
     hipconv._check_hook = lambda kind, eng, geom, operands, result: seen.append((kind, eng))
     try:
-        for m, H, W in ((nn.Conv2d(128, 256, 3, 1, 1), 64, 64), (nn.ConvTranspose2d(256, 128, 3, 1, 1), 32, 32)):
+        for m, H, W in ((nn.Conv2d(128, 256, 3, 1, 1), 64, 64), (nn.ConvTranspose2d(256, 128, 3, 1, 1), 32, 32), (nn.Conv2d(64, 128, 4, 2, 1), 128, 128),
+                        (nn.ConvTranspose2d(256, 64, 4, 2, 1), 64, 64)):
             m = m.cuda()
-            x = torch.randn(4, m.in_channels, H, W, device="cuda", requires_grad=True)
+            x = torch.randn(8, m.in_channels, H, W, device="cuda", requires_grad=True)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y = hipconv.conv_nobias(m, x)
             assert y.dtype == torch.bfloat16
             dy = torch.randn_like(y, dtype=torch.float32)
             dx, dw = torch.autograd.grad(y.float(), (x, m.weight), dy)
             xr = x.detach().clone().requires_grad_(True)
-            yr = F.conv_transpose2d(xr, m.weight, None, 1, 1) if isinstance(m, nn.ConvTranspose2d) else F.conv2d(xr, m.weight, None, 1, 1)
+            yr = F.conv_transpose2d(xr, m.weight, None, m.stride, m.padding) if isinstance(m, nn.ConvTranspose2d) else F.conv2d(xr, m.weight, None, m.stride, m.padding)
             dxr, dwr = torch.autograd.grad(yr, (xr, m.weight), dy)
             for a, b in ((y.float(), yr), (dx, dxr), (dw, dwr)):
                 assert float((a - b).abs().max() / b.abs().max()) <= 2e-2          # bf16 operands and results: 2^-8 each
     finally:
         hipconv._check_hook = None
-    assert seen.count(("forward", "bf16d")) == 2 and seen.count(("input_grad", "bf16d")) == 2 and seen.count(("weight_grad", "bf16d")) == 2, seen
+    assert seen.count(("forward", "bf16d")) == 4 and seen.count(("input_grad", "bf16d")) == 4 and seen.count(("weight_grad", "bf16d")) == 2, seen
     assert hipconv.select(ops.CONV_FWD, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"          # where split-bf16 Winograd still wins
     assert hipconv.select(ops.CONV_FWD, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d" and hipconv.select_wrw(False, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "winograd"
     assert hipconv.select(ops.CONV_FWD, 16, 128, 128, 128, 128, 3, 1, 1, 1, True) == "bf16d"

@@ -38,11 +38,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--check", type=int, default=1)
+    ap.add_argument("--only-s2", action="store_true")
     a = ap.parse_args()
     B = a.batch
     g = torch.Generator(device="cuda").manual_seed(5)
     print("layer (batch %d)         | pass  | direct bf16   ms     TF | MIOpen bf16  ms     TF | split-wino ms | err vs fp64(bf16 operands)" % B)
-    for kind, Cin, H, Cout in LAYERS:
+    for kind, Cin, H, Cout in ([] if a.only_s2 else LAYERS):
         tr = kind == "convT"
         wshape = (Cin, Cout, 3, 3) if tr else (Cout, Cin, 3, 3)
         w = torch.randn(wshape, device="cuda", generator=g) * (1.0 / (3.0 * (Cin ** 0.5)))
@@ -90,6 +91,49 @@ def main():
                 err = float((got - ref).abs().max() / ref.abs().max())
             print("%-5s %4d->%-4d @%-3d   | %-5s | %10.4f %7.1f | %10.4f %7.1f | %10.4f    | %.2e" %
                   (kind, Cin, Cout, H, "wrw", t_d, flops / t_d / 1e9, t_m, flops / t_m / 1e9, t_w, err), flush=True)
+
+
+    # ---- 4x4 stride-2 pad-1 family: Conv2d (fine -> coarse forward) and ConvTranspose2d (coarse -> fine forward), + their input gradients
+    print()
+    S2 = [("conv", 64, 128, 128), ("conv", 128, 64, 256), ("conv", 256, 32, 512), ("conv", 512, 16, 512),
+          ("convT", 512, 16, 512), ("convT", 1024, 16, 256), ("convT", 512, 32, 128), ("convT", 256, 32, 256), ("convT", 256, 64, 64), ("convT", 128, 64, 128),
+          ("convT", 64, 128, 64), ("convT", 128, 128, 3)]
+    for kind, Cin, H, Cout in S2:
+        tr = kind == "convT"
+        Kc, Cf = (Cin, Cout) if tr else (Cout, Cin)           # weight [Kc][Cf][4][4] in both modules
+        nh = H if tr else H // 2
+        w = torch.randn(Kc, Cf, 4, 4, device="cuda", generator=g) * (1.0 / (4.0 * (Cin ** 0.5)))
+        fine = torch.randn(B, Cf, 2 * nh, 2 * nh, device="cuda", generator=g).to(torch.bfloat16)
+        coarse = torch.randn(B, Kc, nh, nh, device="cuda", generator=g).to(torch.bfloat16)
+        wb = w.to(torch.bfloat16)
+        flops = 2.0 * 16 * Kc * Cf * B * nh * nh
+        x, dy = (coarse, fine) if tr else (fine, coarse)
+        for name in ("fwd", "bwdD"):
+            mode = (ops.S2_COARSE_TO_FINE if name == "fwd" else ops.S2_FINE_TO_COARSE) if tr else (ops.S2_FINE_TO_COARSE if name == "fwd" else ops.S2_COARSE_TO_FINE)
+            inp = x if name == "fwd" else dy
+            if not ops.conv4x4s2_bf16_supported(mode, B, Kc, Cf, nh, nh):
+                print("%-5s %4d->%-4d @%-3d k4s2 | %-5s | unsupported" % (kind, Cin, Cout, H, name))
+                continue
+            t_d = timeit(lambda: ops.conv4x4s2_bf16(mode, inp, w, B, Kc, Cf, nh, nh))
+            if name == "fwd":
+                mi = (lambda: F.conv_transpose2d(x, w.to(torch.bfloat16), None, 2, 1)) if tr else (lambda: F.conv2d(x, w.to(torch.bfloat16), None, 2, 1))
+            else:
+                mi = lambda: torch.ops.aten.convolution_backward(dy, x, w.to(torch.bfloat16), None, [2, 2], [1, 1], [1, 1], tr, [0, 0], 1, [True, False, False])
+            t_m = timeit(mi)
+            try:
+                t_w = timeit(lambda: ops.conv4x4s2_winograd(mode, inp, w, B, Kc, Cf, nh, nh, math="bf16x3", out_dtype=torch.bfloat16))
+            except Exception:
+                t_w = float("nan")
+            err = float("nan")
+            if a.check:
+                got = ops.conv4x4s2_bf16(mode, inp, w, B, Kc, Cf, nh, nh, out_dtype=torch.float32)[:2].double()
+                if mode == ops.S2_FINE_TO_COARSE:
+                    ref = F.conv2d(fine[:2].double(), wb.double(), None, 2, 1)
+                else:
+                    ref = F.conv_transpose2d(coarse[:2].double(), wb.double(), None, 2, 1)
+                err = float((got - ref).abs().max() / ref.abs().max())
+            print("%-5s %4d->%-4d @%-3d k4s2 | %-5s | %10.4f %7.1f | %10.4f %7.1f | %10.4f    | %.2e" %
+                  (kind, Cin, Cout, H, name, t_d, flops / t_d / 1e9, t_m, flops / t_m / 1e9, t_w, err), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Which engine runs which convolution call of one training step (BASELINE config 2: batch 8, 256x256, fp32), and what the calls
+"""Which engine runs which convolution call of one training step (BASELINE config 2: batch 8, 256x256, fp32; `--dtype bf16 --batch 16`:
+config 5), and what the calls
 that stay on MIOpen cost.  Every call of models/hipconv.py (the U-Nets and discriminators; the frozen VGG16 goes through
 models/vgg16.py's own path and is listed from the dispatcher) reports (pass, engine, geometry) through hipconv._check_hook; the
 MIOpen ones are then timed stand-alone on tensors of the same shapes (median of 10, HIP events, transposes included).
@@ -44,13 +45,20 @@ def time_ms(fn, n=10):
 
 
 def main():
-    opt = Option(gpu_ids=[0], batchSize=8, use_dropout=True, quiet=True, allow_random_vgg=True, checkpoints_dir=tempfile.mkdtemp())
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="bf16 = BASELINE config 5 (convolutions under bf16 autocast)")
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    B, bf = a.batch, a.dtype == "bf16"
+    act = torch.bfloat16 if bf else torch.float32
+    opt = Option(gpu_ids=[0], batchSize=B, use_dropout=True, quiet=True, allow_random_vgg=True, amp_bf16=bf, checkpoints_dir=tempfile.mkdtemp())
     torch.manual_seed(5)
     with contextlib.redirect_stdout(io.StringIO()):
         m = create_model(opt)
     g = torch.Generator(device="cuda").manual_seed(21)
-    img = torch.rand(8, 3, 256, 256, device="cuda", generator=g) * 2 - 1
-    ref = torch.rand(8, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    img = torch.rand(B, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    ref = torch.rand(B, 3, 256, 256, device="cuda", generator=g) * 2 - 1
     mask = torch.zeros(1, 1, 256, 256, dtype=torch.bool, device="cuda")
     mask[:, :, 64:192, 64:192] = 1
     calls = collections.Counter()
@@ -103,15 +111,15 @@ def main():
     for (kind, engine, tr, xs, ws, st, pd, dl), n in calls.items():
         if engine != "miopen":
             continue
-        x = torch.randn(xs, device="cuda")
-        w = torch.randn(ws, device="cuda") * 0.05
-        f = (lambda a, b: F.conv_transpose2d(a, b, None, st, pd, 0, 1, dl)) if tr else (lambda a, b: F.conv2d(a, b, None, st, pd, dl))
+        x = torch.randn(xs, device="cuda").to(act)
+        w = torch.randn(ws, device="cuda") * 0.05                   # fp32 parameter: under autocast every call casts it (timed, as in the step)
+        f = (lambda a, b: F.conv_transpose2d(a, b.to(act), None, st, pd, 0, 1, dl)) if tr else (lambda a, b: F.conv2d(a, b.to(act), None, st, pd, dl))
         if kind == "forward":
             ms = time_ms(lambda: f(x, w))
         else:
             dy = torch.randn_like(f(x, w))
             which = [kind == "input_grad", kind == "weight_grad", False]
-            ms = time_ms(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pd, pd], [dl, dl], tr, [0, 0], 1, which))
+            ms = time_ms(lambda: torch.ops.aten.convolution_backward(dy, x, w.to(act), None, [st, st], [pd, pd], [dl, dl], tr, [0, 0], 1, which))
         rows.append((ms * n, "  %-12s %-5s x %-18s w %-20s s%d p%d d%d   %d x %.3f ms" % (kind, "convT" if tr else "conv", "x".join(map(str, xs)),
                                                                                          "x".join(map(str, ws)), st, pd, dl, n, ms)))
         total += ms * n
@@ -122,13 +130,13 @@ def main():
     total2, rows = 0.0, []
     for (kind, xs, ws, st, pd, dl, gx, gw), n in plain.items():
         tr = kind == "convT"
-        x = torch.randn(xs, device="cuda")
+        x = torch.randn(xs, device="cuda").to(act)
         w = torch.randn(ws, device="cuda") * 0.05
-        f = (lambda a, b: real_convT(a, b, None, st, pd, 0, 1, dl)) if tr else (lambda a, b: real_conv2d(a, b, None, st, pd, dl))
+        f = (lambda a, b: real_convT(a, b.to(act), None, st, pd, 0, 1, dl)) if tr else (lambda a, b: real_conv2d(a, b.to(act), None, st, pd, dl))
         ms = [time_ms(lambda: f(x, w))]
         dy = torch.randn_like(f(x, w))
         for need, which in ((gx, [True, False, False]), (gw, [False, True, False])):
-            ms.append(time_ms(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pd, pd], [dl, dl], tr, [0, 0], 1, which)) if need else 0.0)
+            ms.append(time_ms(lambda: torch.ops.aten.convolution_backward(dy, x, w.to(act), None, [st, st], [pd, pd], [dl, dl], tr, [0, 0], 1, which)) if need else 0.0)
         rows.append((sum(ms) * n, "  %-5s x %-18s w %-20s s%d p%d d%d   %d x (fwd %.3f + dx %.3f + dw %.3f ms)" % (
             kind, "x".join(map(str, xs)), "x".join(map(str, ws)), st, pd, dl, n, ms[0], ms[1], ms[2])))
         total2 += sum(ms) * n
