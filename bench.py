@@ -527,16 +527,28 @@ def main():
     # region 3: every launch of the convolutions' matrix-core kernel (Winograd GEMM), with its flops — in a few EXTRA steps
     # after the timed loop (~100 more event records per step would perturb the headline number)
     gsteps = 3
-    lib.ipsr_profile_enable_mask(gsteps, 0x8)
+    ncap = 256 * gsteps
+    lib.ipsr_profile_enable_mask(gsteps, 0x18)
     for _ in range(gsteps):
         train_step(model, img, mask, ref)
     torch.cuda.synchronize()
-    ncap = 256 * gsteps
-    gms, gwork, guse = (ctypes.c_float * ncap)(), (ctypes.c_double * ncap)(), (ctypes.c_double * ncap)()
-    ng = lib.ipsr_profile_read_region_work2(3, ctypes.cast(gms, ctypes.c_void_p), ctypes.cast(gwork, ctypes.c_void_p),
-                                            ctypes.cast(guse, ctypes.c_void_p), ncap)
+
+    def read_work(region):
+        ms, work, use = (ctypes.c_float * ncap)(), (ctypes.c_double * ncap)(), (ctypes.c_double * ncap)()
+        n = lib.ipsr_profile_read_region_work2(region, ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(work, ctypes.c_void_p), ctypes.cast(use, ctypes.c_void_p), ncap)
+        return n, ms, work, use
+    ng, gms, gwork, guse = read_work(3)
+    nd, dms, dwork, duse = read_work(4)                   # the direct bf16 convolution kernels (config 5 only)
     gemm_ms, gemm_flops = sum(gms[i] for i in range(ng)), sum(gwork[i] for i in range(ng))
     gemm_useful = sum(guse[i] for i in range(ng))
+    direct = None
+    if nd:
+        d_ms, d_flops, d_use = sum(dms[i] for i in range(nd)), sum(dwork[i] for i in range(nd)), sum(duse[i] for i in range(nd))
+        direct = {"kernel": "ipsr::conv_bf16_kernel / conv_bf16_wrw_kernel (direct implicit GEMM on v_mfma_f32_32x32x16_bf16, bf16 operands, fp32 accumulate)",
+                  "bound": "mfma", "achieved": round(d_use / (d_ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(d_use / (d_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4), "executed_tflops": round(d_flops / (d_ms * 1e-3) / 1e12, 2),
+                  "padding_share_of_executed_flops": round(1.0 - d_use / d_flops, 4), "launches_per_step": round(nd / gsteps, 1),
+                  "kernel_ms_per_step": round(d_ms / gsteps, 3)}
     if os.environ.get("IPSR_BENCH_GEMM_DUMP"):          # one line per launch: ms, flops, TFLOP/s (for tuning the tile/split choice)
         with open(os.environ["IPSR_BENCH_GEMM_DUMP"], "w") as fh:
             for i in range(ng):
@@ -608,6 +620,7 @@ def main():
     value = args.batch * world * args.steps / elapsed
     n_feat = H_FEAT * H_FEAT
     flops = 2.0 * n_feat * n_feat * C_FEAT * args.batch
+    corr_peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS      # the kernel of the layer that actually ran
     kms = statistics.mean(kern_ms) if kern_ms else float("nan")
     achieved = flops / (kms * 1e-3) / 1e12 if kern_ms else None
     traffic, traffic_src = None, None
@@ -652,9 +665,10 @@ def main():
                                                 "(real signed conv features, batch %d)" % args.batch}},
         "ipsr_layer_ms_bf16corr": layer_timing_bf16corr(device),
         "ipsr_layer_ms_other_configs": layer_timing_other_configs(device),
-        "roofline": {"kernel": "ipsr::corr_argmax_kernel (fp32 MFMA correlation + arg-max)", "bound": "mfma",
-                     "achieved": round(achieved, 3) if achieved else None, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,
+        "roofline": {"kernel": "ipsr::corr_argmax_kernel (fp32 MFMA correlation + arg-max)" if args.dtype == "f32" else
+                               "ipsr::corr_argmax_bf16_kernel (correlation + arg-max on v_mfma_f32_32x32x16_bf16, operands rounded to bf16)", "bound": "mfma",
+                     "achieved": round(achieved, 3) if achieved else None, "peak": corr_peak,
+                     "unit": "TFLOP/s", "frac": round(achieved / corr_peak, 4) if achieved else None,
                      "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": flops, "kernel_ms": round(kms, 5), "launches_timed": len(kern_ms)},
         # the whole step against the same roofline: direct-convolution FLOPs of the step AS EXECUTED here
         # the convolutions' own matrix-core kernel: every launch of ipsr::wino_gemm_kernel (the 36 GEMMs of the Winograd
@@ -663,6 +677,7 @@ def main():
         # `achieved` / `frac`: USEFUL flops (unpadded channels / tiles) over the kernel's time; `executed_*`: the flops the kernel
         # really issues (rows / columns rounded up to the 128 x 128 tile — the difference is arithmetic on zero padding)
         "conv_roofline": conv_roofline(args, ng, gsteps, gemm_ms, gemm_flops, gemm_useful),
+        "conv_roofline_direct_bf16": direct,
         "step_roofline": {"bound": "mfma", "flops_per_image": STEP_FLOPS_PER_IMAGE,
                           "achieved_direct_equivalent": round(STEP_FLOPS_PER_IMAGE * value / world / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                           "unit": "TFLOP/s per GPU",

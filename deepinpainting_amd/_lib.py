@@ -99,6 +99,7 @@ SIGNATURES = {
     "ipsr_conv4x4s2_winograd_mp": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ipsr_conv3x3_bf16_workspace_bytes": (c_size_t, [c_int] * 6),
     "ipsr_conv3x3_bf16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ipsr_conv3x3_bf16_packed": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ipsr_conv4x4s2_bf16_workspace_bytes": (c_size_t, [c_int] * 6),
     "ipsr_conv4x4s2_bf16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ipsr_conv3x3_bf16_wrw_workspace_bytes": (c_size_t, [c_int] * 6),

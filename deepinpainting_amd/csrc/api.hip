@@ -36,8 +36,9 @@ int check_launch(const char* what)
 
 // ---- opt-in profiling rings ----------------------------------------------------------------------------
 // region 0: the correlation + arg-max kernel; 1: a whole ipsr_forward; 2: a whole ipsr_backward(_patch);
-// 3: every launch of the Winograd GEMM kernel (the convolutions' matrix-core kernel), with the launch's flop count
-constexpr int N_REGIONS = 4;
+// 3: every launch of the Winograd GEMM kernel (the convolutions' matrix-core kernel), with the launch's flop count;
+// 4: every launch of the direct bf16 convolution kernels (conv_bf16.hip), likewise
+constexpr int N_REGIONS = 5;
 struct EvRing {
     hipEvent_t* ev = nullptr;      // 2*capacity events: start0, stop0, start1, ...
     double* work = nullptr;        // per entry: work units the caller attached (flops as EXECUTED, padded sizes), 0 if none
@@ -156,7 +157,7 @@ int ipsr_profile_enable_mask(int capacity, unsigned region_mask)
     for (int ri = 0; ri < N_REGIONS; ++ri) {
         if (!((region_mask >> ri) & 1u)) continue;
         EvRing& r = g_ring[ri];
-        const int cap_r = ri == 3 ? 256 * capacity : capacity;        // tens of GEMM launches per training step
+        const int cap_r = ri >= 3 ? 256 * capacity : capacity;        // tens of GEMM / direct-convolution launches per training step
         r.work = new double[(size_t)cap_r];
         r.work2 = new double[(size_t)cap_r];
         r.ev = new hipEvent_t[2 * (size_t)cap_r];

@@ -38,12 +38,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
 
 constexpr int CB_K = 128, CB_P = 256, CB_C = 16, CB_THREADS = 512, CB_MAXTAP = 9;
-constexpr int CB_A_BYTES = CB_MAXTAP * 2 * CB_K * 16;       // [tap][c group][128 k][8 c] bf16 = 36 KB
-constexpr int CB_RAW_BYTES = 20480;                         // [16 c][raw rows][input width] bf16: k3 16 x 4 x 256 B; stride 2: 16 x 5 x 256 B
-constexpr int CB_T_BYTES = 21504;                           // [planes][2 c groups][positions][8 c]: k3 2 x 520 x 16 B; stride 2: 4 x 325 x 16 B
-constexpr int CB_TR_MAX = 5;                                // transposition blocks (4 channels x 16 pixels) per 16-lane group and stage
-constexpr int CB_BUF = CB_A_BYTES + CB_RAW_BYTES + CB_T_BYTES;
-static_assert(2 * CB_BUF <= 160 * 1024, "LDS plan");
+constexpr int CB_TR_MAX = 6;                                // transposition blocks (4 channels x 16 pixels) per 16-lane group and stage
+constexpr int CB_LDS_MAX = 160 * 1024;
+// LDS plan (per geometry, cb_finish): A[2] | T[2] | raw[2 or 1].  A stage = ntap x 4 KB ([tap][c group][128 k][8 c] bf16), raw = [16 c][raw
+// rows][input width] bf16, T = [planes][2 c groups][positions][8 c].  k3 at W <= 128: 2 x (36 + 16 + 16.3) KB; stride 2: 2 x (32 + 20 + 20.4);
+// k3 at W = 256 (one image row per tile): 2 x 36 + 2 x 24.3 + ONE raw buffer of 24 KB — the transposition then follows the stage's
+// multiplications instead of running beside them (`raw1`).
 
 // The three forms (all: out = sum over (channel, tap) of packed weight x shifted input; lanes = pixels of the LANE grid Hl x Wl):
 //   S1   k3 s1 p1                     lane grid = image; 9 taps; raw tile = R + 2 rows of the image, T = [cg][R + 2][W + 2]
@@ -66,10 +66,12 @@ struct CbGeom {
     int ntap;
     int tapoff[2][CB_MAXTAP];   // per sub-stage (F2C) / row phase (C2F): plane * 2 * NPOS + drow * PW + dcol
     int ktiles, ptiles, nstage; // ceil(K / 128), B * Hl / R, (C / 16) * nsub
+    int a_bytes, t_bytes, raw_bytes, raw1;      // LDS plan: stage sizes, one raw buffer instead of two
+    int kt;                     // produced channels per workgroup tile: 128, or 64 when K <= 64
 };
 
 // packed weights: Wp[kt][phase][cb][sub][t][cg][k & 127][c & 7] bf16 (zero for k >= K); source element (k, c, tap) at w[c * sc + k * sk + srctap]
-struct CbPack { int ntap, nsub, nphase, ksz2; int srctap[2][2][CB_MAXTAP]; };      // [phase][sub][t]
+struct CbPack { int ntap, nsub, nphase, kt; int srctap[2][2][CB_MAXTAP]; };      // kt: rows per k tile (128 or 64); srctap[phase][sub][t]
 
 __global__ void __launch_bounds__(256) cb_pack_weights_kernel(const float* __restrict__ w, int C, int K, long sc, long sk, CbPack pk,
                                                               uint4* __restrict__ Wp, uint4* __restrict__ zero_page)
@@ -78,8 +80,8 @@ __global__ void __launch_bounds__(256) cb_pack_weights_kernel(const float* __res
     const int k = blockIdx.x * 256 + threadIdx.x;          // padded produced channel
     const int c8 = blockIdx.y;
     const int t = blockIdx.z % pk.ntap, ps = blockIdx.z / pk.ntap, sub = ps % pk.nsub, phase = ps / pk.nsub;
-    const int ktiles = (K + CB_K - 1) / CB_K;
-    if (k >= ktiles * CB_K) return;
+    const int ktiles = (K + pk.kt - 1) / pk.kt;
+    if (k >= ktiles * pk.kt) return;
     const int tap = pk.srctap[phase][sub][t];
     unsigned short h[8];
 #pragma unroll
@@ -91,22 +93,25 @@ __global__ void __launch_bounds__(256) cb_pack_weights_kernel(const float* __res
     uint4 o;
     o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
     o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
-    const int kt = k >> 7, kl = k & 127, cb = c8 >> 1, cg = c8 & 1;
+    const int kt = k / pk.kt, kl = k - kt * pk.kt, cb = c8 >> 1, cg = c8 & 1;
     const int ncb = C / CB_C;
-    Wp[((((((size_t)kt * pk.nphase + phase) * ncb + cb) * pk.nsub + sub) * pk.ntap + t) * 2 + cg) * CB_K + kl] = o;
+    Wp[((((((size_t)kt * pk.nphase + phase) * ncb + cb) * pk.nsub + sub) * pk.ntap + t) * 2 + cg) * pk.kt + kl] = o;
 }
 
-template <int MODE, typename TOUT>
+// KT = produced channels per workgroup tile: 128 (waves 2 x 4, a wave 64 x 64), or 64 for layers that produce <= 64 channels (waves 1 x 8, a
+// wave 64 x 32) — a 128-row tile on a 64-channel layer multiplies zeros half of the time (VGG conv1_2, the outermost U-Net levels).
+template <int MODE, int KT, typename TOUT>
 __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned short* __restrict__ in, const uint4* __restrict__ Wp,
                                                                   const uint4* __restrict__ zero_page, CbGeom g, TOUT* __restrict__ out)
 {
     constexpr int NTAP = MODE == CB_S1 ? 9 : 8;
     constexpr int NSET = MODE == CB_C2F ? 2 : 1;               // accumulator sets (C2F: the two column phases of the fine output)
     constexpr int TPSET = NTAP / NSET;
+    constexpr int WN = KT == 128 ? 4 : 8, NJ = 8 / WN;         // wave columns; 32-pixel MFMA tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];          // 2 x (A | raw | T)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = KT == 128 ? wave >> 2 : 0, wn = KT == 128 ? wave & 3 : wave;
     const int r = lane & 31, h = lane >> 5;
 
     // tile: all (k tile, row phase) workgroups of one pixel tile are neighbours (they share the activation tile in L2)
@@ -138,8 +143,8 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
     }
     const size_t xstride = (size_t)CB_C * g.Hin * g.Win;
     // A tile DMA: NTAP * 4 pieces of 1 KiB, piece = wave + 8 j; the stages of (kt, phase) are contiguous
-    constexpr int NPIECE = NTAP * 4, APW = (NPIECE + 7) / 8;
-    const uint4* ga = Wp + ((size_t)(kt * g.nphase + phase) * g.nstage) * (NTAP * 2 * CB_K) + lane;
+    constexpr int NPIECE = NTAP * KT / 32, APW = (NPIECE + 7) / 8;
+    const uint4* ga = Wp + ((size_t)(kt * g.nphase + phase) * g.nstage) * (NTAP * 2 * KT) + lane;
     // transposition: block u = (c quad, row, 16-pixel block); lane 4q+p of a 16-lane group supplies row q, pixels 4p..4p+3
     const int grp = tid >> 4, li = tid & 15;
     const int cb16s = g.Win >> 4, nblk = 4 * g.NR * cb16s;
@@ -157,32 +162,33 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
         tr_wr[j] = (pos * 8 + (cq & 1) * 4) * 2;
     }
     const int ntr = (nblk + 31) / 32;
+    const int t_base = 2 * g.a_bytes, raw_base = t_base + 2 * g.t_bytes;
     // fragments: A rows wm*64 + {0,32} + r; B lane-grid pixels wn*64 + {0,32} + r
-    const int a_off = (h * CB_K + wm * 64 + r) * 16;
-    int b_off[2];
+    const int a_off = (h * KT + wm * 64 + r) * 16;
+    int b_off[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = wn * 64 + j * 32 + r;
+    for (int j = 0; j < NJ; ++j) {
+        const int p = wn * (32 * NJ) + j * 32 + r;
         b_off[j] = (h * g.NPOS + (p >> g.wshift) * g.PW + (p & (g.Wl - 1))) * 16;
     }
 
-    f32x16 acc[NSET][2][2];
+    f32x16 acc[NSET][2][NJ];
 #pragma unroll
     for (int q = 0; q < NSET; ++q)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[q][i][j][e] = 0.0f;
 
     auto dma_a = [&](int buf, int stage) {
-        const uint4* src = ga + (size_t)stage * (NTAP * 2 * CB_K);
+        const uint4* src = ga + (size_t)stage * (NTAP * 2 * KT);
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
             const int piece = wave + 8 * j;
             if (piece < NPIECE)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 64), (lptr_t)(lds + buf * CB_BUF + piece * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 64), (lptr_t)(lds + buf * g.a_bytes + piece * 1024), 16, 0, 0);
         }
     };
     auto dma_x = [&](int buf, int stage) {
@@ -192,13 +198,13 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
             if (xlive[j]) {
                 const unsigned short* base = (MODE == CB_F2C && e) ? gx[j][MODE == CB_F2C ? 1 : 0] : gx[j][0];
                 const void* src = base ? static_cast<const void*>(base + (size_t)cb * xstride) : static_cast<const void*>(zero_page);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + buf * CB_BUF + CB_A_BYTES + (wave * 64 + CB_THREADS * j) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + raw_base + buf * g.raw_bytes + (wave * 64 + CB_THREADS * j) * 16), 16, 0, 0);
             }
         }
     };
-    auto transpose = [&](int buf) {                            // raw[buf] -> T[buf]
-        unsigned char* raw = lds + buf * CB_BUF + CB_A_BYTES;
-        unsigned char* T = raw + CB_RAW_BYTES;
+    auto transpose = [&](int rbuf, int tbuf) {                 // raw[rbuf] -> T[tbuf]
+        unsigned char* raw = lds + raw_base + rbuf * g.raw_bytes;
+        unsigned char* T = lds + t_base + tbuf * g.t_bytes;
         s16x4 v[CB_TR_MAX];
 #pragma unroll
         for (int j = 0; j < CB_TR_MAX; ++j)
@@ -209,48 +215,54 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
     };
 
     // both T images start as zeros: the halo columns are never written (tiles span the full image width)
-    for (int i = tid; i < 2 * (CB_T_BYTES / 16); i += CB_THREADS) {
-        const int buf = i / (CB_T_BYTES / 16), o = i - buf * (CB_T_BYTES / 16);
-        *reinterpret_cast<uint4*>(lds + buf * CB_BUF + CB_A_BYTES + CB_RAW_BYTES + o * 16) = make_uint4(0u, 0u, 0u, 0u);
-    }
-    // prologue: A[0], raw[0] <- stage 0; raw[1] <- stage 1
+    for (int i = tid; i < 2 * (g.t_bytes / 16); i += CB_THREADS)
+        *reinterpret_cast<uint4*>(lds + t_base + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    // prologue: A[0], raw[0] <- stage 0; raw[1] <- stage 1 (two raw buffers)
     dma_a(0, 0);
     dma_x(0, 0);
-    if (g.nstage > 1) dma_x(1, 1);
+    if (!g.raw1 && g.nstage > 1) dma_x(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    transpose(0);
+    transpose(0, 0);
     __syncthreads();
 
     for (int s = 0; s < g.nstage; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
         if (s + 1 < g.nstage) dma_a(nxt, s + 1);               // A[nxt] was last read in stage s-1
-        if (s + 2 < g.nstage) dma_x(cur, s + 2);               // raw[cur] was transposed in stage s-1
-        if (s + 1 < g.nstage) transpose(nxt);                  // raw[nxt] (stage s+1) landed before the barrier that ended stage s-1
-        const unsigned char* A = lds + cur * CB_BUF + a_off;
-        const unsigned char* T = lds + cur * CB_BUF + CB_A_BYTES + CB_RAW_BYTES;
+        if (!g.raw1) {
+            if (s + 2 < g.nstage) dma_x(cur, s + 2);           // raw[cur] was transposed in stage s-1
+            if (s + 1 < g.nstage) transpose(nxt, nxt);         // raw[nxt] (stage s+1) landed before the barrier that ended stage s-1
+        } else if (s + 1 < g.nstage) {
+            dma_x(0, s + 1);                                   // the one raw buffer was transposed at the end of stage s-1
+        }
+        const unsigned char* A = lds + cur * g.a_bytes + a_off;
+        const unsigned char* T = lds + t_base + cur * g.t_bytes;
         const int* toff = g.tapoff[MODE == CB_F2C ? (s & 1) : (MODE == CB_C2F ? phase : 0)];
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
             const int q = t / TPSET;
-            const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + (t * 2 * CB_K) * 16);
-            const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + (t * 2 * CB_K + 32) * 16);
-            const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(T + b_off[0] + toff[t] * 16);
-            const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(T + b_off[1] + toff[t] * 16);
-            acc[q][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[q][0][0], 0, 0, 0);
-            acc[q][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[q][0][1], 0, 0, 0);
-            acc[q][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[q][1][0], 0, 0, 0);
-            acc[q][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[q][1][1], 0, 0, 0);
+            const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + (t * 2 * KT) * 16);
+            const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + (t * 2 * KT + 32) * 16);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(T + b_off[j] + toff[t] * 16);
+                acc[q][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[q][0][j], 0, 0, 0);
+                acc[q][1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[q][1][j], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this stage's DMAs are the next stage's operands
         __syncthreads();
+        if (g.raw1 && s + 1 < g.nstage) {                      // one raw buffer: the next stage's tile crosses LDS now, behind the multiplications
+            transpose(0, nxt);
+            __syncthreads();
+        }
     }
 
     // epilogue: lane = lane-grid pixel, register = channel
     const size_t HWo = (size_t)g.Hout * g.Wout;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = wn * 64 + j * 32 + r;
+    for (int j = 0; j < NJ; ++j) {
+        const int p = wn * (32 * NJ) + j * 32 + r;
         const int py = y0 + (p >> g.wshift), px = p & (g.Wl - 1);
         if (MODE == CB_C2F) {
             // fine row 2 py + phase, fine columns 2 px and 2 px + 1 (the two accumulator sets): one 2-element store
@@ -259,7 +271,7 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int k = kt * CB_K + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int k = kt * KT + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (k < g.K) {
                         if (sizeof(TOUT) == 2) {
                             const unsigned pk = (unsigned)f2bf(acc[0][i][j][e]) | ((unsigned)f2bf(acc[NSET - 1][i][j][e]) << 16);
@@ -276,7 +288,7 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int k = kt * CB_K + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int k = kt * KT + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (live && k < g.K) st1(op, (size_t)k * HWo, acc[0][i][j][e]);
                 }
         }
@@ -285,22 +297,27 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
 
 static int cb_lane_grid(int Hl, int Wl, CbGeom* g, const char* who)
 {
-    if (Wl != 16 && Wl != 32 && Wl != 64 && Wl != 128) return fail(IPSR_ERR_UNSUPPORTED, "%s: grid width %d (16, 32, 64 or 128)", who, Wl);
+    if (Wl != 16 && Wl != 32 && Wl != 64 && Wl != 128 && Wl != 256) return fail(IPSR_ERR_UNSUPPORTED, "%s: grid width %d (16 .. 256, a power of two)", who, Wl);
     const int R = CB_P / Wl;
     if (Hl % R != 0) return fail(IPSR_ERR_UNSUPPORTED, "%s: %d rows are not a multiple of the %d rows of a tile", who, Hl, R);
     g->Hl = Hl; g->Wl = Wl; g->R = R;
-    g->wshift = Wl == 16 ? 4 : (Wl == 32 ? 5 : (Wl == 64 ? 6 : 7));
+    g->wshift = Wl == 16 ? 4 : (Wl == 32 ? 5 : (Wl == 64 ? 6 : (Wl == 128 ? 7 : 8)));
     return IPSR_OK;
 }
 
 static int cb_finish(CbGeom* g, const char* who)
 {
     g->NPOS = g->NR * g->PW;
-    g->ktiles = (g->K + CB_K - 1) / CB_K;
+    g->kt = g->K <= 64 ? 64 : CB_K;
+    g->ktiles = (g->K + g->kt - 1) / g->kt;
     g->ptiles = g->B * (g->Hl / g->R);
     g->nstage = (g->C / CB_C) * g->nsub;
     const int planes = g->nsub;                               // F2C keeps the two column phases
-    if (CB_C * g->NR * g->Win * 2 > CB_RAW_BYTES || planes * 2 * g->NPOS * 16 > CB_T_BYTES || 4 * g->NR * (g->Win / 16) > 32 * CB_TR_MAX ||
+    g->a_bytes = g->ntap * 2 * g->kt * 16;
+    g->t_bytes = (int)align_up((size_t)planes * 2 * g->NPOS * 16, 256);
+    g->raw_bytes = (int)align_up((size_t)CB_C * g->NR * g->Win * 2, 1024);
+    g->raw1 = 2 * (g->a_bytes + g->t_bytes + g->raw_bytes) > CB_LDS_MAX;
+    if (2 * (g->a_bytes + g->t_bytes) + (g->raw1 ? 1 : 2) * g->raw_bytes > CB_LDS_MAX || 4 * g->NR * (g->Win / 16) > 32 * CB_TR_MAX ||
         CB_C * g->NR * (g->Win / 8) > 3 * CB_THREADS)
         return fail(IPSR_ERR_UNSUPPORTED, "%s: a tile of %d rows x %d does not fit the LDS plan", who, g->NR, g->Win);
     return IPSR_OK;
@@ -359,44 +376,53 @@ size_t conv_bf16_ws_bytes(int B, int C, int K, int H, int W)
 {
     CbGeom g;
     if (cb_geometry(B, C, K, H, W, &g) != IPSR_OK) return 0;
-    return 256 + (size_t)g.ktiles * g.nstage * 9 * 2 * CB_K * 16;
+    return 256 + (size_t)g.ktiles * g.nstage * 9 * 2 * g.kt * 16;
 }
 
 size_t conv_bf16_s2_ws_bytes(int form, int B, int C, int K, int nh, int nw)
 {
     CbGeom g;
     if (cb_geometry_s2(form, B, C, K, nh, nw, &g) != IPSR_OK) return 0;
-    return 256 + (size_t)g.ktiles * g.nphase * g.nstage * 8 * 2 * CB_K * 16;
+    return 256 + (size_t)g.ktiles * g.nphase * g.nstage * 8 * 2 * g.kt * 16;
+}
+
+template <int MODE, int KT, typename TOUT>
+static void cb_launch_kernel(const CbGeom& g, const void* in, const uint4* Wp, const uint4* zero_page, void* out, unsigned grid, size_t smem, hipStream_t st)
+{
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, KT, TOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_MAX); attr = true; }
+    conv_bf16_kernel<MODE, KT, TOUT><<<grid, CB_THREADS, smem, st>>>(static_cast<const unsigned short*>(in), Wp, zero_page, g, static_cast<TOUT*>(out));
 }
 
 template <int MODE>
-static int cb_launch(const CbGeom& g, const CbPack& pk, const void* in, const float* w, void* out, long sc, long sk, int out_bf16, void* ws,
-                     hipStream_t st, double taps_per_out)
+static int cb_launch(const CbGeom& g, CbPack pk, const void* in, const float* w, void* out, long sc, long sk, int out_bf16, void* ws,
+                     hipStream_t st, double taps_per_out, int pack_valid = 0)
 {
     uint4* zero_page = static_cast<uint4*>(ws);
     uint4* Wp = zero_page + 16;
-    cb_pack_weights_kernel<<<dim3(cdiv(g.ktiles * CB_K, 256), g.C / 8, pk.ntap * pk.nsub * pk.nphase), 256, 0, st>>>(w, g.C, g.K, sc, sk, pk, Wp, zero_page);
-    if (int rc = check_launch("cb_pack_weights_kernel")) return rc;
+    pk.kt = g.kt;
+    if (!pack_valid) {
+        cb_pack_weights_kernel<<<dim3(cdiv(g.ktiles * g.kt, 256), g.C / 8, pk.ntap * pk.nsub * pk.nphase), 256, 0, st>>>(w, g.C, g.K, sc, sk, pk, Wp, zero_page);
+        if (int rc = check_launch("cb_pack_weights_kernel")) return rc;
+    }
     const unsigned grid = (unsigned)(g.ktiles * g.nphase * g.ptiles);
-    const size_t smem = 2 * (size_t)CB_BUF;
-    profile_mark_start(st, 3);
-    if (out_bf16) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-        conv_bf16_kernel<MODE, bf16_t><<<grid, CB_THREADS, smem, st>>>(static_cast<const unsigned short*>(in), Wp, zero_page, g, static_cast<bf16_t*>(out));
+    const size_t smem = 2 * (size_t)(g.a_bytes + g.t_bytes) + (size_t)(g.raw1 ? 1 : 2) * g.raw_bytes;
+    profile_mark_start(st, 4);
+    if (g.kt == 64) {
+        if (out_bf16) cb_launch_kernel<MODE, 64, bf16_t>(g, in, Wp, zero_page, out, grid, smem, st);
+        else cb_launch_kernel<MODE, 64, float>(g, in, Wp, zero_page, out, grid, smem, st);
     } else {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-        conv_bf16_kernel<MODE, float><<<grid, CB_THREADS, smem, st>>>(static_cast<const unsigned short*>(in), Wp, zero_page, g, static_cast<float*>(out));
+        if (out_bf16) cb_launch_kernel<MODE, 128, bf16_t>(g, in, Wp, zero_page, out, grid, smem, st);
+        else cb_launch_kernel<MODE, 128, float>(g, in, Wp, zero_page, out, grid, smem, st);
     }
     const double outs = (double)g.B * g.Hout * g.Wout;
-    profile_mark_stop(st, 3, 2.0 * taps_per_out * g.C * (double)(g.ktiles * CB_K) * outs, 2.0 * taps_per_out * g.C * (double)g.K * outs);
+    profile_mark_stop(st, 4, 2.0 * taps_per_out * g.C * (double)(g.ktiles * g.kt) * outs, 2.0 * taps_per_out * g.C * (double)g.K * outs);
     return check_launch("conv_bf16_kernel");
 }
 
 // in [B,C,H,W] bf16, weight fp32 with element (c, k, tap) at w[c*sc + k*sk + tap] (taps flipped when `flip`), out [B,K,H,W] bf16 / fp32
 int launch_conv_bf16(const void* in, const float* w, void* out, int B, int C, int K, int H, int W, long sc, long sk, int flip, int out_bf16,
-                     void* ws, size_t ws_bytes, hipStream_t st)
+                     void* ws, size_t ws_bytes, hipStream_t st, int pack_valid = 0)
 {
     CbGeom g;
     if (int rc = cb_geometry(B, C, K, H, W, &g)) return rc;
@@ -405,7 +431,7 @@ int launch_conv_bf16(const void* in, const float* w, void* out, int B, int C, in
     CbPack pk{};
     pk.ntap = 9; pk.nsub = 1; pk.nphase = 1;
     for (int t = 0; t < 9; ++t) pk.srctap[0][0][t] = flip ? 8 - t : t;
-    return cb_launch<CB_S1>(g, pk, in, w, out, sc, sk, out_bf16, ws, st, 9.0);
+    return cb_launch<CB_S1>(g, pk, in, w, out, sc, sk, out_bf16, ws, st, 9.0, pack_valid);
 }
 
 // k4 s2 p1.  weight [Kc][Cf][4][4]: element (coarse channel kc, fine channel cf, r, s) at w[kc * skc + cf * scf + r * 4 + s].
@@ -655,9 +681,9 @@ int launch_conv_bf16_wrw(const void* a, const void* w, float* dW, int B, int Ka,
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wrw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WB_A_BYTES + WB_X_BYTES); attr = true; }
     const unsigned grid = (unsigned)(g.ktiles * g.ctiles * g.nsplit);
-    profile_mark_start(st, 3);
+    profile_mark_start(st, 4);
     conv_bf16_wrw_kernel<<<grid, WB_THREADS, smem, st>>>(static_cast<const unsigned short*>(a), static_cast<const unsigned short*>(w), zero_page, g, slabs);
-    profile_mark_stop(st, 3, 2.0 * 9.0 * (double)(g.ktiles * WB_K) * (g.ctiles * WB_C) * B * H * W, 2.0 * 9.0 * (double)Ka * Cb * B * H * W);
+    profile_mark_stop(st, 4, 2.0 * 9.0 * (double)(g.ktiles * WB_K) * (g.ctiles * WB_C) * B * H * W, 2.0 * 9.0 * (double)Ka * Cb * B * H * W);
     if (int rc = check_launch("conv_bf16_wrw_kernel")) return rc;
     conv_bf16_wrw_reduce_kernel<<<dim3(cdiv(Cb, 256), Ka), 256, 0, st>>>(slabs, g.nsplit, Ka, Cb, g.ktiles * WB_K, g.ctiles * WB_C, dW);
     return check_launch("conv_bf16_wrw_reduce_kernel");
@@ -679,16 +705,22 @@ size_t ipsr_conv3x3_bf16_workspace_bytes(int op, int B, int Cin, int H, int W, i
 int ipsr_conv3x3_bf16(int op, const void* in, const float* weight, void* out, int B, int Cin, int H, int W, int Cout, int out_bf16,
                       void* ws, size_t ws_bytes, void* stream)
 {
+    return ipsr_conv3x3_bf16_packed(op, in, weight, out, B, Cin, H, W, Cout, out_bf16, 0, ws, ws_bytes, stream);
+}
+
+int ipsr_conv3x3_bf16_packed(int op, const void* in, const float* weight, void* out, int B, int Cin, int H, int W, int Cout, int out_bf16,
+                             int pack_valid, void* ws, size_t ws_bytes, void* stream)
+{
     if (!in || !weight || !out || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_bf16: null pointer");
     if (op < 0 || op > 3 || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_bf16: bad argument");
     if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(in) & 15u))
         return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_bf16: in / workspace must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (op) {       // (sc, sk, flip) as in ipsr_conv3x3_winograd_mp: C = reduction channels, K = produced channels
-        case 0: return launch_conv_bf16(in, weight, out, B, Cin, Cout, H, W, 9, (long)Cin * 9, 0, out_bf16, ws, ws_bytes, st);
-        case 1: return launch_conv_bf16(in, weight, out, B, Cout, Cin, H, W, (long)Cin * 9, 9, 1, out_bf16, ws, ws_bytes, st);
-        case 2: return launch_conv_bf16(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, out_bf16, ws, ws_bytes, st);
-        default: return launch_conv_bf16(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, out_bf16, ws, ws_bytes, st);
+        case 0: return launch_conv_bf16(in, weight, out, B, Cin, Cout, H, W, 9, (long)Cin * 9, 0, out_bf16, ws, ws_bytes, st, pack_valid);
+        case 1: return launch_conv_bf16(in, weight, out, B, Cout, Cin, H, W, (long)Cin * 9, 9, 1, out_bf16, ws, ws_bytes, st, pack_valid);
+        case 2: return launch_conv_bf16(in, weight, out, B, Cin, Cout, H, W, (long)Cout * 9, 9, 1, out_bf16, ws, ws_bytes, st, pack_valid);
+        default: return launch_conv_bf16(in, weight, out, B, Cout, Cin, H, W, 9, (long)Cout * 9, 0, out_bf16, ws, ws_bytes, st, pack_valid);
     }
 }
 

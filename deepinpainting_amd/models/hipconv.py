@@ -304,7 +304,7 @@ def _select_wrw(mode, _nosm, transposed, B, Cin, H, W, Cout, k, stride, pad, dil
 def _bf16_direct_call(op, inp, w, transposed, B, Cin, H, W, Cout, k, stride, pad, dil, out_dtype):
     """One pass of a module on the direct bf16 kernels (csrc/conv_bf16.hip): k3 s1 p1, or k4 s2 p1 in its coarse / fine form."""
     if k == 3:
-        return ops.conv3x3_bf16(op, inp, w, (B, Cin, H, W), Cout, out_dtype=out_dtype)
+        return ops.conv3x3_bf16(op, inp, w, (B, Cin, H, W), Cout, out_dtype=out_dtype, keep_packed=not w.requires_grad and not torch.is_grad_enabled())
     return ops.conv4x4s2_bf16(_s2_mode(op), inp, w, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out_dtype=out_dtype)
 
 

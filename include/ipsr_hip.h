@@ -363,6 +363,7 @@ int innercos_loss_backward(const float* x, int B, int Cx, int Cuse, int N, const
  *   region 1  every whole ipsr_forward call (all its kernels)
  *   region 2  every whole ipsr_backward / ipsr_backward_patch call
  *   region 3  every launch of the Winograd GEMM kernel (see ipsr_profile_read_region_work)
+ *   region 4  every launch of the direct bf16 convolution kernels (ipsr_conv3x3_bf16 / ipsr_conv4x4s2_bf16 / their weight gradient)
  * so that a training step can report the layer's time ON ITS REAL INPUTS.  ipsr_profile_read_region synchronises the
  * recorded pairs of one region, writes their elapsed times (ms) to the HOST array `ms` and resets that ring; it returns
  * the number written.  ipsr_profile_read(ms, n) == ipsr_profile_read_region(0, ms, n).  ipsr_profile_enable(capacity)
@@ -406,12 +407,16 @@ int ipsr_conv4x4s2_winograd_mp(int mode, const void* a, const void* b, void* out
  * every netG level), models/vgg16.py:9-21 — and their input gradients: ONE implicit-GEMM launch on v_mfma_f32_32x32x16_bf16 (bf16
  * operands, fp32 accumulation), NCHW bf16 activations in, NCHW bf16 (out_bf16 = 1) or fp32 (0) out, fp32 weights cast inside.
  * op as in ipsr_conv2d (0 Conv2d forward, 1 Conv2d backward-data, 2 ConvTranspose2d forward, 3 ConvTranspose2d backward-data);
- * (Cin, H, W) describe the module's input.  Supported: W in {16, 32, 64, 128}, H a multiple of 256 / W, reduction channels a
+ * (Cin, H, W) describe the module's input.  Supported: W in {16, 32, 64, 128, 256}, H a multiple of 256 / W, reduction channels a
  * multiple of 16; anything else -> IPSR_ERR_UNSUPPORTED.  Not bit-comparable with anything: operands are rounded to bf16 (tests
  * compare with an fp64 convolution of the bf16-rounded operands). */
 size_t ipsr_conv3x3_bf16_workspace_bytes(int op, int B, int Cin, int H, int W, int Cout);
 int ipsr_conv3x3_bf16(int op, const void* in, const float* weight, void* out, int B, int Cin, int H, int W, int Cout, int out_bf16,
                       void* ws, size_t ws_bytes, void* stream);
+/* _packed: `ws` doubles as the caller-owned cache of the re-packed bf16 weights (same size as the workspace query): pack_valid = 0
+ * packs into it, pack_valid = 1 reuses what an earlier call on the SAME weights, op and channel counts left there (frozen VGG16). */
+int ipsr_conv3x3_bf16_packed(int op, const void* in, const float* weight, void* out, int B, int Cin, int H, int W, int Cout, int out_bf16,
+                             int pack_valid, void* ws, size_t ws_bytes, void* stream);
 /* the 4x4 stride-2 pad-1 layers (every down convolution of netP / netD / netF, every up convolution of netP / netG: models/networks.py:
  * 235-243, 404-432, 470-495, 510-515) in the coarse / fine terms of ipsr_conv4x4s2_winograd: fine = the 2n-grid tensor [B,Cf,2nh,2nw],
  * coarse = the n-grid one [B,Kc,nh,nw], weight [Kc][Cf][4][4] for both modules.  mode 0: fine -> coarse (Conv2d forward,
