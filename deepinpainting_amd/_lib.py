@@ -102,6 +102,8 @@ SIGNATURES = {
     "ipsr_conv3x3_bf16_packed": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ipsr_conv4x4s2_bf16_workspace_bytes": (c_size_t, [c_int] * 6),
     "ipsr_conv4x4s2_bf16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ipsr_conv4x4s2_bf16_wrw_workspace_bytes": (c_size_t, [c_int] * 5),
+    "ipsr_conv4x4s2_bf16_wrw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ipsr_conv3x3_bf16_wrw_workspace_bytes": (c_size_t, [c_int] * 6),
     "ipsr_conv3x3_bf16_wrw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ipsr_wino_gemm_split": (c_int, [c_int, c_int, c_int, c_void_p]),

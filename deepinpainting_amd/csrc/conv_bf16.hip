@@ -689,6 +689,234 @@ int launch_conv_bf16_wrw(const void* a, const void* w, float* dW, int B, int Ka,
     return check_launch("conv_bf16_wrw_reduce_kernel");
 }
 
+// =====================================================================================================================================
+// Weight gradient of the k4 s2 p1 layers (Conv2d [Kc][Cf] and ConvTranspose2d [Kc][Cf] alike, in the coarse / fine terms above):
+//      dW[kc][cf][r][s] = sum_{b, oy, ox}  coarse[b][kc][oy][ox] * fine[b][cf][2 oy - 1 + r][2 ox - 1 + s]
+// The reduction runs over COARSE pixels: the coarse operand's fragments are aligned 16-byte reads as in the k3 kernel; the fine
+// operand's 8 consecutive reduction elements are every OTHER pixel of a fine row: a lane reads the 16 fine pixels they span (two
+// aligned 16-byte reads + the dword before and after) and picks the even / odd halves with four v_perm_b32 per column tap.
+// Workgroup = 8 waves = 4 (kc) x 2 (row taps r in {0,1} / {2,3}): 128 kc x 32 cf x 16 taps, a wave 32 x 32 x 8 taps; stage = 64 coarse
+// pixels (RS = 64 / nw coarse rows); the fine rows live in a ring of 4 RS + 2 image rows handled in PAIRS (row 2 i - 1 and 2 i:
+// 64 x pitch slots, so a DMA instruction never straddles ring entries); runs of coarse rows are cut over workgroups, the partial
+// [t][kc][cf] slabs added in order by the second launch.
+constexpr int W2_K = 128, W2_C = 32, W2_PX = 64;
+constexpr int W2_A_BYTES = W2_K * W2_PX * 2;                 // 16 KB per buffer
+
+struct W2Geom {
+    int B, Kc, Cf, nh, nw, wshift;      // coarse grid nh x nw (fine 2nh x 2nw)
+    int RS, NPAIR, pitch;               // coarse rows per stage, ring entries (pairs of fine rows: 2 RS + 1), slots per (fine row, channel)
+    int stages_per_wg, nsplit, ktiles, ctiles;
+};
+
+__device__ __forceinline__ unsigned pack_hi(unsigned x, unsigned y) { return __builtin_amdgcn_perm(y, x, 0x07060302u); }   // {x.hi16, y.hi16}
+__device__ __forceinline__ unsigned pack_lo(unsigned x, unsigned y) { return __builtin_amdgcn_perm(y, x, 0x05040100u); }   // {x.lo16, y.lo16}
+
+__global__ void __launch_bounds__(512, 1) conv_bf16_wrw_s2_kernel(const unsigned short* __restrict__ coarse, const unsigned short* __restrict__ fine,
+                                                                   const uint4* __restrict__ zero_page, W2Geom g, float* __restrict__ slabs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];          // A[2] | fine-row ring
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave >> 1, rh = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = g.ktiles * g.ctiles;
+    const int tile = L % tiles, split = L / tiles;
+    const int kt = tile % g.ktiles, ct = tile / g.ktiles;
+    const int rows_per_wg = g.RS * g.stages_per_wg;
+    const int runs_per_img = g.nh / rows_per_wg;
+    const int b = split / runs_per_img, ylo = (split - b * runs_per_img) * rows_per_wg;
+    const int Hf = 2 * g.nh, Wf = 2 * g.nw;
+    const size_t HWc = (size_t)g.nh * g.nw, HWf = (size_t)Hf * Wf;
+    const int cprc = g.nw >> 3;                              // 16-byte chunks per coarse row
+    const int cprf = Wf >> 3;                                // ... per fine row
+
+    // ---- coarse rows: slot sigma = k * 8 + cs holds stage chunk c8 = cs ^ (k & 7) of channel k; c8 -> (coarse row rs, chunk cx) ----------
+    const unsigned short* ga[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sigma = (wave + 8 * j) * 64 + lane;
+        const int k = sigma >> 3, c8 = (sigma & 7) ^ (k & 7);
+        const int rs = c8 / cprc, cx = c8 - rs * cprc;
+        const int kc = kt * W2_K + k;
+        ga[j] = kc < g.Kc ? coarse + ((size_t)b * g.Kc + kc) * HWc + (size_t)(ylo + rs) * g.nw + cx * 8 : nullptr;
+    }
+    // ---- fine rows: ring entry of the row pair (2 i - 1, 2 i) = i mod NPAIR; per (row, channel): [halo][Wf / 8 chunks][halo][pad] ---------
+    const int pair_slots = 2 * W2_C * g.pitch;               // a multiple of 64
+    const unsigned short* gf[5];
+    int f_row[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int q = tid + 512 * j;
+        const int within = q % pair_slots;
+        const int pr = within / (W2_C * g.pitch), rem = within - pr * (W2_C * g.pitch);
+        const int c = rem / g.pitch, sl = rem - c * g.pitch;
+        const int cf = ct * W2_C + c;
+        f_row[j] = 2 * (q / pair_slots) + pr;                // fine row offset from the first row of the group
+        const bool data = sl >= 1 && sl <= cprf && cf < g.Cf;
+        gf[j] = data ? fine + ((size_t)b * g.Cf + cf) * HWf + (sl - 1) * 8 : nullptr;
+    }
+    const int pair_bytes = pair_slots * 16;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+
+    auto dma_a = [&](int buf, int stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const void* src = ga[j] ? static_cast<const void*>(ga[j] + (size_t)stage * g.RS * g.nw) : static_cast<const void*>(zero_page);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + buf * W2_A_BYTES + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+    };
+    // `npairs` row pairs starting with the pair (2 i0 - 1, 2 i0)
+    auto dma_f = [&](int i0, int npairs) {
+        const int nslots = npairs * pair_slots;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int q0 = wave * 64 + 512 * j;              // uniform
+            if (q0 < nslots) {
+                const int pp = q0 / pair_slots, within = q0 - pp * pair_slots;
+                int entry = (i0 + pp) % g.NPAIR;
+                if (entry < 0) entry += g.NPAIR;
+                const int yf = 2 * i0 - 1 + f_row[j];
+                const bool ok = gf[j] != nullptr && (unsigned)yf < (unsigned)Hf;
+                const void* src = ok ? static_cast<const void*>(gf[j] + (size_t)yf * Wf) : static_cast<const void*>(zero_page);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + 2 * W2_A_BYTES + entry * pair_bytes + within * 16), 16, 0, 0);
+            }
+        }
+    };
+
+    // a stage on coarse rows y0 .. y0 + RS - 1 reads the fine rows 2 y0 - 1 .. 2 (y0 + RS - 1) + 2 = the pairs y0 .. y0 + RS
+    dma_a(0, 0);
+    dma_f(ylo, g.RS + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int a_row = wk * 32 + r;
+    const int row_bytes = W2_C * g.pitch * 16;
+    for (int s = 0; s < g.stages_per_wg; ++s) {
+        const int cur = s & 1;
+        const int y0 = ylo + s * g.RS;
+        if (s + 1 < g.stages_per_wg) {
+            dma_a(cur ^ 1, s + 1);
+            dma_f(y0 + g.RS + 1, g.RS);                       // the pairs the next stage adds
+        }
+        const unsigned char* A = lds + cur * W2_A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                         // k-steps of 16 coarse pixels
+            const int c8 = 2 * j + h;
+            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(A + ((a_row << 3) + (c8 ^ (a_row & 7))) * 16);
+            const int p0 = 16 * j;
+            const int rs = p0 >> g.wshift, ox0 = (p0 & (g.nw - 1)) + 8 * h;
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) {
+                // fine row 2 (y0 + rs) - 1 + (2 rh + ri) = row (1 - ...) of a pair: row index u = 2 (y0 + rs) + 2 rh + ri  ->  pair u / 2, member u & 1
+                const int u = 2 * (y0 + rs) + 2 * rh + ri;    // = fine row + 1
+                const int entry = (u >> 1) % g.NPAIR;
+                const unsigned char* X = lds + 2 * W2_A_BYTES + entry * pair_bytes + (u & 1) * row_bytes + (r * g.pitch + 1 + (ox0 >> 2)) * 16;
+                const uint4 lo4 = *reinterpret_cast<const uint4*>(X);
+                const uint4 hi4 = *reinterpret_cast<const uint4*>(X + 16);
+                const unsigned prev = *reinterpret_cast<const unsigned*>(X - 4);
+                const unsigned next = *reinterpret_cast<const unsigned*>(X + 32);
+                const unsigned d0 = lo4.x, d1 = lo4.y, d2 = lo4.z, d3 = lo4.w, d4 = hi4.x, d5 = hi4.y, d6 = hi4.z, d7 = hi4.w;
+                const uint4 f0 = make_uint4(pack_hi(prev, d0), pack_hi(d1, d2), pack_hi(d3, d4), pack_hi(d5, d6));
+                const uint4 f1 = make_uint4(pack_lo(d0, d1), pack_lo(d2, d3), pack_lo(d4, d5), pack_lo(d6, d7));
+                const uint4 f2 = make_uint4(pack_hi(d0, d1), pack_hi(d2, d3), pack_hi(d4, d5), pack_hi(d6, d7));
+                const uint4 f3 = make_uint4(pack_lo(d1, d2), pack_lo(d3, d4), pack_lo(d5, d6), pack_lo(d7, next));
+                acc[ri * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, f0), acc[ri * 4 + 0], 0, 0, 0);
+                acc[ri * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, f1), acc[ri * 4 + 1], 0, 0, 0);
+                acc[ri * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, f2), acc[ri * 4 + 2], 0, 0, 0);
+                acc[ri * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, f3), acc[ri * 4 + 3], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // partial result: slab[split][t = r * 4 + s][kc][cf] (lanes along cf)
+    const int Kp = g.ktiles * W2_K, Cp = g.ctiles * W2_C;
+    float* out = slabs + (size_t)split * 16 * Kp * Cp;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int kc = kt * W2_K + wk * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            out[((size_t)(rh * 8 + t) * Kp + kc) * Cp + ct * W2_C + r] = acc[t][e];
+        }
+}
+
+// dW[kc][cf][t] = sum_s slab[s][t][kc][cf], t = 0..15
+__global__ void __launch_bounds__(256) conv_bf16_wrw_s2_reduce_kernel(const float* __restrict__ slabs, int nsplit, int Kc, int Cf, int Kp, int Cp,
+                                                                      float* __restrict__ dW)
+{
+    const int cf = blockIdx.x * 256 + threadIdx.x, kc = blockIdx.y;
+    if (cf >= Cf) return;
+    float o[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) o[t] = 0.0f;
+    const size_t slab = (size_t)16 * Kp * Cp;
+    for (int s = 0; s < nsplit; ++s)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[t] += slabs[(size_t)s * slab + ((size_t)t * Kp + kc) * Cp + cf];
+    float4* d = reinterpret_cast<float4*>(dW + ((size_t)kc * Cf + cf) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+}
+
+static int w2_geometry(int B, int Kc, int Cf, int nh, int nw, W2Geom* g)
+{
+    if (nw != 16 && nw != 32 && nw != 64) return fail(IPSR_ERR_UNSUPPORTED, "bf16 4x4 stride-2 weight gradient: coarse width %d (16, 32 or 64)", nw);
+    const int RS = W2_PX / nw;
+    if (nh % RS != 0) return fail(IPSR_ERR_UNSUPPORTED, "bf16 4x4 stride-2 weight gradient: %d coarse rows are not a multiple of %d", nh, RS);
+    g->B = B; g->Kc = Kc; g->Cf = Cf; g->nh = nh; g->nw = nw;
+    g->wshift = nw == 16 ? 4 : (nw == 32 ? 5 : 6);
+    g->RS = RS; g->NPAIR = 2 * RS + 1; g->pitch = 2 * nw / 8 + 3;
+    g->ktiles = (Kc + W2_K - 1) / W2_K; g->ctiles = (Cf + W2_C - 1) / W2_C;
+    if ((RS + 1) * 2 * W2_C * g->pitch > 5 * 512) return fail(IPSR_ERR_UNSUPPORTED, "bf16 4x4 stride-2 weight gradient: row ring of a %d-wide grid", nw);
+    const int groups = nh / RS;
+    int spw = (int)(((long)g->ktiles * g->ctiles * B * groups + 255) / 256);
+    if (spw < 1) spw = 1;
+    if (spw > groups) spw = groups;
+    while (groups % spw) --spw;
+    g->stages_per_wg = spw;
+    g->nsplit = B * (groups / spw);
+    return IPSR_OK;
+}
+
+size_t conv_bf16_wrw_s2_ws_bytes(int B, int Kc, int Cf, int nh, int nw)
+{
+    W2Geom g;
+    if (w2_geometry(B, Kc, Cf, nh, nw, &g) != IPSR_OK) return 0;
+    return 256 + (size_t)g.nsplit * 16 * g.ktiles * W2_K * g.ctiles * W2_C * 4;
+}
+
+// fine [B,Cf,2nh,2nw], coarse [B,Kc,nh,nw] bf16 -> dW [Kc][Cf][4][4] fp32
+int launch_conv_bf16_wrw_s2(const void* fine, const void* coarse, float* dW, int B, int Kc, int Cf, int nh, int nw, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    W2Geom g;
+    if (int rc = w2_geometry(B, Kc, Cf, nh, nw, &g)) return rc;
+    const size_t need = conv_bf16_wrw_s2_ws_bytes(B, Kc, Cf, nh, nw);
+    if (ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "bf16 4x4 stride-2 weight gradient: workspace %zu < %zu", ws_bytes, need);
+    uint4* zero_page = static_cast<uint4*>(ws);
+    float* slabs = reinterpret_cast<float*>(zero_page + 16);
+    if (hipMemsetAsync(zero_page, 0, 64, st) != hipSuccess) return fail(IPSR_ERR_LAUNCH, "bf16 4x4 stride-2 weight gradient: hipMemsetAsync failed");
+    const size_t smem = 2 * (size_t)W2_A_BYTES + (size_t)g.NPAIR * 2 * W2_C * g.pitch * 16;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wrw_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_MAX); attr = true; }
+    if (smem > (size_t)CB_LDS_MAX) return fail(IPSR_ERR_UNSUPPORTED, "bf16 4x4 stride-2 weight gradient: %zu bytes of LDS", smem);
+    const unsigned grid = (unsigned)(g.ktiles * g.ctiles * g.nsplit);
+    profile_mark_start(st, 4);
+    conv_bf16_wrw_s2_kernel<<<grid, 512, smem, st>>>(static_cast<const unsigned short*>(coarse), static_cast<const unsigned short*>(fine), zero_page, g, slabs);
+    profile_mark_stop(st, 4, 2.0 * 16.0 * (double)(g.ktiles * W2_K) * (g.ctiles * W2_C) * B * nh * nw, 2.0 * 16.0 * (double)Kc * Cf * B * nh * nw);
+    if (int rc = check_launch("conv_bf16_wrw_s2_kernel")) return rc;
+    conv_bf16_wrw_s2_reduce_kernel<<<dim3(cdiv(Cf, 256), Kc), 256, 0, st>>>(slabs, g.nsplit, Kc, Cf, g.ktiles * W2_K, g.ctiles * W2_C, dW);
+    return check_launch("conv_bf16_wrw_s2_reduce_kernel");
+}
+
 }  // namespace ipsr
 
 using namespace ipsr;
@@ -739,6 +967,22 @@ int ipsr_conv4x4s2_bf16(int mode, const void* in, const float* weight, void* out
         return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_bf16: in / out / workspace must be 16-byte aligned");
     // weight [Kc][Cf][4][4] in both modules (Conv2d: [Cout][Cin], ConvTranspose2d: [Cin][Cout]), as in ipsr_conv4x4s2_winograd
     return launch_conv_bf16_s2(mode, in, weight, out, B, Kc, Cf, nh, nw, (long)Cf * 16, 16, out_bf16, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t ipsr_conv4x4s2_bf16_wrw_workspace_bytes(int B, int Kc, int Cf, int nh, int nw)
+{
+    if (B < 1 || Kc < 1 || Cf < 1 || nh < 1 || nw < 1) return 0;
+    return conv_bf16_wrw_s2_ws_bytes(B, Kc, Cf, nh, nw);
+}
+
+int ipsr_conv4x4s2_bf16_wrw(const void* fine, const void* coarse, float* dw, int B, int Kc, int Cf, int nh, int nw, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!fine || !coarse || !dw || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_bf16_wrw: null pointer");
+    if (B < 1 || Kc < 1 || Cf < 1 || nh < 1 || nw < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_bf16_wrw: bad argument");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || (reinterpret_cast<uintptr_t>(fine) & 15u) || (reinterpret_cast<uintptr_t>(coarse) & 15u) ||
+        (reinterpret_cast<uintptr_t>(dw) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv4x4s2_bf16_wrw: operands / workspace must be 16-byte aligned");
+    return launch_conv_bf16_wrw_s2(fine, coarse, dw, B, Kc, Cf, nh, nw, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t ipsr_conv3x3_bf16_wrw_workspace_bytes(int transposed, int B, int Cin, int H, int W, int Cout)

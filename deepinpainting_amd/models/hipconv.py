@@ -271,6 +271,9 @@ def _bf16_direct_wrw(force, mode, transposed, B, Cin, H, W, Cout, k, stride, pad
     if k == 3 and stride == 1 and pad == 1 and dil == 1 and H * W >= 1024 and ((ka + 127) // 128) * ((cb + 63) // 64) >= 2 \
             and ops.conv3x3_bf16_wrw_supported(transposed, B, Cin, H, W, Cout):
         return "bf16d"
+    g = _s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+    if g is not None and g[3] >= 32 and ((g[0] + 127) // 128) * ((g[1] + 31) // 32) >= 4 and ops.conv4x4s2_bf16_wrw_supported(B, *g):
+        return "bf16d"           # 1.2-1.4x MIOpen from four 128 x 32 output tiles up on coarse grids >= 32 wide; 16-wide grids and single tiles lose
     return "miopen"
 
 
@@ -396,8 +399,11 @@ class _HipConv(torch.autograd.Function):
         xw = x if (x.dtype == dy.dtype or weng in (None, "miopen")) else x.to(dy.dtype)      # a weight gradient reads both operands in one dtype
         if weng == "winograd":
             dw = ops.conv3x3_winograd_wrw(transposed, xw, dy, Cout, out=sink, math=math)
-        elif weng == "bf16d":
+        elif weng == "bf16d" and k == 3:
             dw = ops.conv3x3_bf16_wrw(transposed, xw, dy, Cout, out=sink)
+        elif weng == "bf16d":
+            fine, coarse = (dy, xw) if transposed else (xw, dy)
+            dw = ops.conv4x4s2_bf16_wrw(fine, coarse, B, *_s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil), out=sink)
         elif weng == "wino_dil":
             dw = ops.conv4x4_dilated_winograd(2, xw, dy, (B, Cin, H, W), Cout, out=sink, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math)
         elif weng == "one":

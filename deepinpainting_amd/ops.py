@@ -626,6 +626,33 @@ def conv4x4s2_bf16(mode, inp, weight, B, Kc, Cf, nh, nw, out_dtype=torch.bfloat1
     return out
 
 
+def conv4x4s2_bf16_wrw_supported(B, Kc, Cf, nh, nw):
+    return _lib.lib().ipsr_conv4x4s2_bf16_wrw_workspace_bytes(B, Kc, Cf, nh, nw) > 0
+
+
+def conv4x4s2_bf16_wrw(fine, coarse, B, Kc, Cf, nh, nw, out=None):
+    """Weight gradient [Kc,Cf,4,4] (fp32) of a k4 s2 p1 layer from its bf16 fine [B,Cf,2nh,2nw] and coarse [B,Kc,nh,nw] tensors
+    (ipsr_conv4x4s2_bf16_wrw); `out`: optional contiguous fp32 destination (a gradient bucket slice)."""
+    fine, f_bf = _act(fine, "fine tensor")
+    coarse, c_bf = _act(coarse, "coarse tensor")
+    if not (f_bf and c_bf):
+        raise TypeError("conv4x4s2_bf16_wrw reads bf16 tensors")
+    if tuple(fine.shape) != (B, Cf, 2 * nh, 2 * nw) or tuple(coarse.shape) != (B, Kc, nh, nw):
+        raise RuntimeError("conv4x4s2_bf16_wrw: fine %s / coarse %s do not match %s / %s" % (tuple(fine.shape), tuple(coarse.shape), (B, Cf, 2 * nh, 2 * nw), (B, Kc, nh, nw)))
+    shape = (Kc, Cf, 4, 4)
+    if out is not None and (tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != fine.device):
+        raise RuntimeError("conv4x4s2_bf16_wrw: `out` must be a contiguous fp32 %s tensor on %s" % (shape, fine.device))
+    L = _lib.lib()
+    nbytes = L.ipsr_conv4x4s2_bf16_wrw_workspace_bytes(B, Kc, Cf, nh, nw)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv4x4s2_bf16_wrw: %s is not implemented (%s)" % ((B, Kc, Cf, nh, nw), L.ipsr_last_error().decode("utf-8", "replace")))
+    dw = out if out is not None else torch.empty(shape, dtype=torch.float32, device=fine.device)
+    ws = _workspace(nbytes, fine.device)
+    _lib.check(L.ipsr_conv4x4s2_bf16_wrw(fine.data_ptr(), coarse.data_ptr(), dw.data_ptr(), B, Kc, Cf, nh, nw, ws.data_ptr(), ws.numel(), _stream()),
+               "ipsr_conv4x4s2_bf16_wrw")
+    return dw
+
+
 def conv3x3_bf16_wrw_supported(transposed, B, Cin, H, W, Cout):
     return _lib.lib().ipsr_conv3x3_bf16_wrw_workspace_bytes(int(transposed), B, Cin, H, W, Cout) > 0
 

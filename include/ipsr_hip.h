@@ -425,6 +425,11 @@ int ipsr_conv3x3_bf16_packed(int op, const void* in, const float* weight, void* 
 size_t ipsr_conv4x4s2_bf16_workspace_bytes(int mode, int B, int Kc, int Cf, int nh, int nw);
 int ipsr_conv4x4s2_bf16(int mode, const void* in, const float* weight, void* out, int B, int Kc, int Cf, int nh, int nw, int out_bf16,
                         void* ws, size_t ws_bytes, void* stream);
+/* weight gradient of the 4x4 stride-2 layers: fine [B,Cf,2nh,2nw], coarse [B,Kc,nh,nw] bf16 -> dw [Kc][Cf][4][4] fp32 (both modules' layout);
+ * nw in {16, 32, 64}, nh a multiple of 64 / nw.  Partial sums added in a fixed order by a second launch. */
+size_t ipsr_conv4x4s2_bf16_wrw_workspace_bytes(int B, int Kc, int Cf, int nh, int nw);
+int ipsr_conv4x4s2_bf16_wrw(const void* fine, const void* coarse, float* dw, int B, int Kc, int Cf, int nh, int nw,
+                            void* ws, size_t ws_bytes, void* stream);
 /* their weight gradient: x [B,Cin,H,W], dy [B,Cout,H,W] bf16 -> dw fp32 in the module's layout (transposed = 0: Conv2d [Cout][Cin][3][3];
  * 1: ConvTranspose2d [Cin][Cout][3][3]).  The reduction over pixels is cut over workgroups; the partial results are added in a fixed
  * order by a second launch (deterministic).  Same shape limits as above. */

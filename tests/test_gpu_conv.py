@@ -651,6 +651,13 @@ def test_direct_bf16_stride2_family(Kc, Cf, nh, nw, B):
         f32 = ops.conv4x4s2_bf16(ops.S2_COARSE_TO_FINE, coarse, w, B, Kc, Cf, nh, nw, out_dtype=torch.float32)
         f16 = ops.conv4x4s2_bf16(ops.S2_COARSE_TO_FINE, coarse, w, B, Kc, Cf, nh, nw)
         assert f16.dtype == torch.bfloat16 and _relerr(f32, f64) <= 1e-5 and _relerr(f16, f64) <= 2.0 ** -8, (_relerr(f32, f64), _relerr(f16, f64))
+    # weight gradient (reduction over the coarse pixels; the fine windows are every other pixel of a row)
+    if nw <= 64:
+        dw64 = torch.ops.aten.convolution_backward(coarse.double(), fine.double(), wd, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        dw = ops.conv4x4s2_bf16_wrw(fine, coarse, B, Kc, Cf, nh, nw)
+        assert dw.dtype == torch.float32 and dw.shape == w.shape and _relerr(dw, dw64) <= 1e-5, _relerr(dw, dw64)
+        sink = torch.full_like(w, float("nan"))
+        assert ops.conv4x4s2_bf16_wrw(fine, coarse, B, Kc, Cf, nh, nw, out=sink) is sink and torch.equal(sink, dw)
     assert not ops.conv4x4s2_bf16_supported(ops.S2_FINE_TO_COARSE, B, Kc, Cf, nh, 24) and not ops.conv4x4s2_bf16_supported(ops.S2_WEIGHT_GRAD, B, Kc, Cf, nh, nw)
 
 
@@ -663,7 +670,7 @@ def test_direct_bf16_conv_through_the_modules_under_autocast():
     seen = []
     hipconv._check_hook = lambda kind, eng, geom, operands, result: seen.append((kind, eng))
     try:
-        for m, H, W in ((nn.Conv2d(128, 256, 3, 1, 1), 64, 64), (nn.ConvTranspose2d(256, 128, 3, 1, 1), 32, 32), (nn.Conv2d(64, 128, 4, 2, 1), 128, 128),
+        for m, H, W in ((nn.Conv2d(128, 256, 3, 1, 1), 64, 64), (nn.ConvTranspose2d(256, 128, 3, 1, 1), 32, 32), (nn.Conv2d(128, 256, 4, 2, 1), 128, 128),
                         (nn.ConvTranspose2d(256, 64, 4, 2, 1), 64, 64)):
             m = m.cuda()
             x = torch.randn(8, m.in_channels, H, W, device="cuda", requires_grad=True)
@@ -679,7 +686,7 @@ def test_direct_bf16_conv_through_the_modules_under_autocast():
                 assert float((a - b).abs().max() / b.abs().max()) <= 2e-2          # bf16 operands and results: 2^-8 each
     finally:
         hipconv._check_hook = None
-    assert seen.count(("forward", "bf16d")) == 4 and seen.count(("input_grad", "bf16d")) == 4 and seen.count(("weight_grad", "bf16d")) == 2, seen
+    assert seen.count(("forward", "bf16d")) == 4 and seen.count(("input_grad", "bf16d")) == 4 and seen.count(("weight_grad", "bf16d")) == 4, seen
     assert hipconv.select(ops.CONV_FWD, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"          # where split-bf16 Winograd still wins
     assert hipconv.select(ops.CONV_FWD, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d" and hipconv.select_wrw(False, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "winograd"
     assert hipconv.select(ops.CONV_FWD, 16, 128, 128, 128, 128, 3, 1, 1, 1, True) == "bf16d"

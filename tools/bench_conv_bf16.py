@@ -134,6 +134,20 @@ def main():
                 err = float((got - ref).abs().max() / ref.abs().max())
             print("%-5s %4d->%-4d @%-3d k4s2 | %-5s | %10.4f %7.1f | %10.4f %7.1f | %10.4f    | %.2e" %
                   (kind, Cin, Cout, H, name, t_d, flops / t_d / 1e9, t_m, flops / t_m / 1e9, t_w, err), flush=True)
+        if ops.conv4x4s2_bf16_wrw_supported(B, Kc, Cf, nh, nh):
+            t_d = timeit(lambda: ops.conv4x4s2_bf16_wrw(fine, coarse, B, Kc, Cf, nh, nh))
+            t_m = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w.to(torch.bfloat16), None, [2, 2], [1, 1], [1, 1], tr, [0, 0], 1, [False, True, False])[1].float())
+            try:
+                t_w = timeit(lambda: ops.conv4x4s2_winograd(ops.S2_WEIGHT_GRAD, fine, coarse, B, Kc, Cf, nh, nh, math="bf16x3"))
+            except Exception:
+                t_w = float("nan")
+            err = float("nan")
+            if a.check:
+                got = ops.conv4x4s2_bf16_wrw(fine, coarse, B, Kc, Cf, nh, nh).double()
+                ref = torch.ops.aten.convolution_backward(coarse.double(), fine.double(), w.double(), None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+                err = float((got - ref).abs().max() / ref.abs().max())
+            print("%-5s %4d->%-4d @%-3d k4s2 | %-5s | %10.4f %7.1f | %10.4f %7.1f | %10.4f    | %.2e" %
+                  (kind, Cin, Cout, H, "wrw", t_d, flops / t_d / 1e9, t_m, flops / t_m / 1e9, t_w, err), flush=True)
 
 
 if __name__ == "__main__":
