@@ -230,6 +230,8 @@ def _plain_inorm(m):
 
 class FusedSequential(nn.Sequential):
     enabled = True          # class-wide switch (Option.fused_norm_act); False = behave exactly like nn.Sequential
+    skip_source = True      # A/B switch (tests): False = a level's producer does NOT write the skip half of the child's concatenated tensor
+                            # (no _InstNormActSkip / _BiasActSkip nodes: the child concatenates, autograd adds the two input gradients)
 
     def _get_name(self):    # prints like the reference's module tree (train.ipynb cell 1 output)
         return 'Sequential'
@@ -297,7 +299,7 @@ class FusedSequential(nn.Sequential):
                     i += 2
                 else:
                     tail = self._tail_relu_after(mods, i + 2)
-                    c1 = _tail_norm_channels(nxt) if tail else None
+                    c1 = _tail_norm_channels(nxt) if (tail and FusedSequential.skip_source) else None
                     if c1:      # this bias pass also writes the skip half of the child's concatenated tensor
                         xa, buf = _BiasActSkip.apply(y, m.bias, child_act[0], child_act[1], c1)
                         x = nxt(xa, head_act_done=True, tail_relu=tail, cat_buf=buf)
@@ -331,7 +333,7 @@ class FusedSequential(nn.Sequential):
                 a = act or child_act or ("none", 0.0)
                 if act is None and child_act is not None:
                     tail = self._tail_relu_after(mods, j + 1)
-                    c1 = _tail_norm_channels(nxt) if tail else None
+                    c1 = _tail_norm_channels(nxt) if (tail and FusedSequential.skip_source) else None
                     if c1:      # this norm also writes the skip half of the child's concatenated tensor
                         x, buf = _InstNormActSkip.apply(y, bias, norm.weight, norm.bias, norm.eps, a[0], a[1], c1)
                         x = nxt(x, head_act_done=True, tail_relu=tail, cat_buf=buf)

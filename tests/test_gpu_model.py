@@ -285,7 +285,18 @@ GPU_GRAD_TOL = {("P", 0): 2e-3, ("P", 1): 2e-3, ("P", 2): 2e-3, ("G", 2): 2e-3, 
 # G.0 4e-2, D 4e-4..1e-2, F 3e-6..9e-6; the Winograd F(4x4,3x3) engine of this repo (netG, VGG) stays inside the same bands.
 
 
-def test_trainer_step_on_gpu_all_gradients_and_weights_vs_reference(tmp_path):
+@pytest.fixture
+def _deterministic_miopen():
+    """MIOpen's default solvers accumulate atomically, forward included (tools/exp_repeatability.py: two passes from identical weights
+    differ by 14 % of netG's gradient); with its deterministic solvers the whole trainer step is bitwise repeatable, which is what a
+    comparison with a fixed fixture needs."""
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    yield
+    torch.backends.cudnn.deterministic = was
+
+
+def test_trainer_step_on_gpu_all_gradients_and_weights_vs_reference(tmp_path, _deterministic_miopen):
     """Everything tests/golden/trainer_step.npz holds from the reference's own optimize_parameters(), on the MI355X: the
     gradient slices of ALL FOUR nets, the weights after the Adam step and the next iteration's errors.  strict_reference
     = the reference's exact sequence (the fixture's netD / netF gradients are the ones backward_G leaves there, which the
@@ -333,6 +344,57 @@ def test_trainer_step_on_gpu_all_gradients_and_weights_vs_reference(tmp_path):
     np.testing.assert_allclose(e2['G_GAN'], d["errors_iter2"][0], rtol=0.25)
 
 
+def test_skip_source_nodes_are_value_neutral_on_the_trainer_fixture(tmp_path):
+    """The producer of a U-Net level's input writes the skip half of the level's concatenated tensor and receives both consumers'
+    gradients inside its backward kernel (models/fused.py: _InstNormActSkip / _BiasActSkip).  A/B on the reference trainer fixture
+    (same weights, same inputs, MIOpen's deterministic solvers: the whole step is then bitwise repeatable, tools/exp_repeatability.py):
+    with the nodes switched off the concatenation and the gradient sum go back to separate kernels — same values, another summation
+    order.  Iteration 1: errors, images and EVERY gradient of the four nets agree to rounding; iteration 2 (behind one Adam step):
+    the errors agree between the two paths to 1e-4.  So whatever separates iteration-2 `D` from the reference fixture (2.8 % with
+    deterministic solvers, 5.6 % in one run with MIOpen's atomically accumulating ones) is not these nodes."""
+    from deepinpainting_amd.options import Option
+    from deepinpainting_amd.models.models import create_model
+    from deepinpainting_amd.models.fused import FusedSequential
+    img, mask, ref = golden_cases.trainer_inputs()
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    runs = {}
+    try:
+        for on in (True, False, True):
+            FusedSequential.skip_source = on
+            opt = Option(gpu_ids=[0], batchSize=1, use_dropout=False, quiet=True, strict_reference=True, checkpoints_dir=str(tmp_path))
+            m = quiet(create_model, opt)
+            for i, net in enumerate((m.netG, m.netP, m.netD, m.netF, m.vgg)):
+                golden_cases.reinit_deterministic(net, 500 + i)
+            out = []
+            for it in range(2):
+                m.set_input(img.cuda(), mask.cuda(), ref.cuda())
+                m.set_ref_latent()
+                m.set_gt_latent()
+                m.optimize_parameters()
+                e = m.get_current_errors()
+                grads = {t: torch.cat([p.grad.reshape(-1) for p in n.parameters()]).clone() for t, n in (("G", m.netG), ("P", m.netP), ("D", m.netD), ("F", m.netF))}
+                out.append(([e['G_GAN'], e['G_L1'], e['D'], e['F']], m.fake_B.detach().clone(), grads))
+            runs.setdefault(on, []).append(out)
+    finally:
+        FusedSequential.skip_source = True
+        torch.backends.cudnn.deterministic = was
+    a, a2, b = runs[True][0], runs[True][1], runs[False][0]
+    # the same path twice: bitwise (this is what makes the A/B below mean something)
+    assert a[0][0] == a2[0][0] and a[1][0] == a2[1][0] and all(torch.equal(a[1][2][t], a2[1][2][t]) for t in "GPDF")
+    # iteration 1, on vs off (measured on MI355X: every gradient element identical — the two gradients of a level's input are added
+    # in the same order whether the producer's kernel or an add kernel does it; asserted at 1e-6 so that a legitimate reordering
+    # of that sum would not fail the test, a lost or misplaced channel slice would by five orders of magnitude)
+    np.testing.assert_allclose(b[0][0], a[0][0], rtol=1e-6)
+    assert float((a[0][1] - b[0][1]).abs().max()) <= 1e-6 * float(a[0][1].abs().max())
+    rel = {t: float((a[0][2][t] - b[0][2][t]).double().norm() / a[0][2][t].double().norm()) for t in "GPDF"}
+    print("iteration 1, skip-source nodes on vs off: relative L2 distance of the whole gradient", {k: "%.1e" % v for k, v in rel.items()})
+    assert max(rel.values()) <= 1e-6, rel
+    # iteration 2, on vs off (measured: identical — D 0.99269 both ways, reference 1.0214)
+    print("iteration 2 errors [G_GAN, G_L1, D, F]: on %s   off %s" % (a[1][0], b[1][0]))
+    np.testing.assert_allclose(b[1][0], a[1][0], rtol=1e-4)
+
+
 def _bwd_index_words(kk, qq, vv, flag, ints):
     """The reference's truncated kbar as (patch k, position q, value) triples -> one sample's bwd_index in the C-ABI layout
     (include/ipsr_hip.h): offA[N+1] | entA_q[N] | offB[N+1] | entB_q[capB] | entB_w[capB] (fp32 bits)."""
@@ -362,7 +424,7 @@ GPU_GRAD_TOL_REPLAY = dict(GPU_GRAD_TOL)
 GPU_GRAD_TOL_REPLAY.update({("G", 0): 3e-3, ("G", 1): 2e-2})     # G.1: an innermost 512-channel level, |gradient| 2e-4: rounding noise
 
 
-def test_trainer_step_with_the_references_truncation_replayed(tmp_path):
+def test_trainer_step_with_the_references_truncation_replayed(tmp_path, _deterministic_miopen):
     """tests/golden/trainer_step.npz also holds the truncated kbar the reference's forward stored for its backward
     (models/IPSRFunction.py:36,134, captured by oracle/gen_golden.py) in both iterations.  Replaying it removes the one
     discontinuity no restatement can reproduce: every gradient slice of all four nets, the weights after
@@ -422,12 +484,11 @@ def test_trainer_step_with_the_references_truncation_replayed(tmp_path):
             assert rel <= GPU_GRAD_TOL_REPLAY[(tag, j)], "net%s %s: %.2e" % (tag, k, rel)
     e2 = run("kbar2")
     print("iteration 2 errors: here %s   reference %s" % ([e2['G_GAN'], e2['G_L1'], e2['D'], e2['F']], list(d["errors_iter2"])))
-    np.testing.assert_allclose([e2['G_L1'], e2['F']], [d["errors_iter2"][1], d["errors_iter2"][3]], rtol=0.05)
-    np.testing.assert_allclose(e2['D'], d["errors_iter2"][2], rtol=0.10)       # iteration 2 sits behind one Adam sign step: 0.964 with the skip gradients summed inside the producer kernel, within 5 % before that change (reference 1.021)
-    # G_GAN (measured 5.20 vs 4.70 WITH the truncation replayed): Adam's first step is -lr*sign(grad), so every element whose
+    np.testing.assert_allclose([e2['G_L1'], e2['F'], e2['D']], [d["errors_iter2"][1], d["errors_iter2"][3], d["errors_iter2"][2]], rtol=0.05)
+    # G_GAN (measured 5.05-5.20 vs 4.70 WITH the truncation replayed): Adam's first step is -lr*sign(grad), so every element whose
     # gradient is ~0 lands 2*lr away when fp32 noise flips its sign; the relativistic logit difference through the just-updated
-    # netD amplifies that.  The truncation is not the cause — the band stays.
-    np.testing.assert_allclose(e2['G_GAN'], d["errors_iter2"][0], rtol=0.25)
+    # netD amplifies that.  The truncation is not the cause.
+    np.testing.assert_allclose(e2['G_GAN'], d["errors_iter2"][0], rtol=0.15)
 
 
 def test_all_four_nets_gradients_auto_engines_vs_miopen_with_one_truncation(tmp_path):
@@ -491,12 +552,18 @@ def test_all_four_nets_gradients_auto_engines_vs_miopen_with_one_truncation(tmp_
     def record(b):
         tape.append(b.clone())
         return b
-    ga, fa = one("miopen", record)
-    gb, fb = one("auto", lambda b: tape[0])
-    gc, _ = one("miopen", lambda b: tape[0])            # the same engine twice: the run-to-run floor (MIOpen's atomics)
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True           # MIOpen's default solvers accumulate atomically (tools/exp_repeatability.py): not a reference
+    try:
+        ga, fa = one("miopen", record)
+        gb, fb = one("auto", lambda b: tape[0])
+        gc, _ = one("miopen", lambda b: tape[0])        # the same engine twice: the run-to-run floor
+    finally:
+        torch.backends.cudnn.deterministic = was
     assert len(tape) == 1 and len(inds) == 3
     flips = int((inds[0] != inds[1]).sum())
     print("arg-max entries that differ between the MIOpen and the engine run: %d of %d" % (flips, inds[0].numel()))
+    assert flips == 0, "a flipped arg-max swaps a gathered patch (a discontinuity of the layer): pick a seed without one so that netG can be compared"
     assert float((fa - fb).abs().max()) <= 2e-4 * float(fa.abs().max())
     # Per net: the relative L2 distance of the whole gradient (every parameter tensor weighed by its size), against two bounds:
     #   * what two MIOpen-only runs differ by (the floor: netG / netP are not even self-consistent to 1e-3 — InstanceNorm over the 4 / 16
@@ -506,16 +573,17 @@ def test_all_four_nets_gradients_auto_engines_vs_miopen_with_one_truncation(tmp_
     #     slope, i.e. a fraction ~eps of the terms changes by O(1): relative change ~ sqrt(eps) = 0.5 %.  Measured D 0.3 %, F 0.8 %.
     # The bands below are 4x what was measured; a wrong engine (an error of 10 % in one layer's gradient) moves these figures far
     # outside them, and tests/test_gpu_conv.py::test_every_engine_call_of_a_training_step_checked_in_situ pins every call at 1e-4.
-    band = {"G": 8e-2, "P": 3e-2, "D": 2e-2, "F": 3e-2}
+    # round 4: with deterministic solvers and this seed NO arg-max entry differs between the runs (asserted), so netG is compared like
+    # the others; bands = 2x the measured distances (G 2.6e-2 over a MIOpen-vs-MIOpen floor of 1.1e-2 — MIOpen's transposed-convolution
+    # gradients stay non-repeatable even so —, P 6.3e-3 over 4.6e-4, D 2.0e-3 and F 1.0e-3 over an exact 0)
+    band = {"G": 5e-2, "P": 1.3e-2, "D": 4e-3, "F": 2e-3}
     report, bad = {}, []
     for tag, net in nets:
         num = sum(float((a - b).double().pow(2).sum()) for a, b in zip(ga[tag], gb[tag])) ** 0.5
         flo = sum(float((a - c).double().pow(2).sum()) for a, c in zip(ga[tag], gc[tag])) ** 0.5
         den = sum(float(a.double().pow(2).sum()) for a in ga[tag]) ** 0.5
         report[tag] = (num / den, flo / den)
-        if flips and tag == "G":
-            continue                    # a flipped arg-max swaps a gathered patch: a discontinuity of the layer, not an engine error
-        if not num / den <= max(band[tag], 12.0 * flo / den):
+        if not num / den <= band[tag]:
             bad.append("net%s: ||auto - miopen|| / ||miopen|| = %.3e (MIOpen vs MIOpen %.3e, band %.0e)" % (tag, num / den, flo / den, band[tag]))
     print("relative L2 distance of the whole gradient (engines vs MIOpen, MIOpen vs MIOpen):", {k: ("%.2e" % v[0], "%.2e" % v[1]) for k, v in report.items()})
     assert not bad, "\n".join(bad)
