@@ -84,6 +84,7 @@ SIGNATURES = {
     "innercos_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "innercos_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                               c_void_p, c_size_t, c_void_p]),
+    "innercos_loss_fused": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "innercos_loss_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p]),
     "ipsr_profile_enable": (c_int, [c_int]),

@@ -37,8 +37,8 @@ int check_launch(const char* what)
 // ---- opt-in profiling rings ----------------------------------------------------------------------------
 // region 0: the correlation + arg-max kernel; 1: a whole ipsr_forward; 2: a whole ipsr_backward(_patch);
 // 3: every launch of the Winograd GEMM kernel (the convolutions' matrix-core kernel), with the launch's flop count;
-// 4: every launch of the direct bf16 convolution kernels (conv_bf16.hip), likewise
-constexpr int N_REGIONS = 5;
+// 4: every launch of the direct bf16 convolution kernels (conv_bf16.hip), likewise; 5: every launch of the InnerCos loss kernel (bytes)
+constexpr int N_REGIONS = 6;
 struct EvRing {
     hipEvent_t* ev = nullptr;      // 2*capacity events: start0, stop0, start1, ...
     double* work = nullptr;        // per entry: work units the caller attached (flops as EXECUTED, padded sizes), 0 if none
@@ -540,6 +540,15 @@ int innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* m
     if (B < 1 || Cuse < 1 || Cx < Cuse || N < 1) return fail(IPSR_ERR_INVALID, "innercos_loss: bad size B=%d Cx=%d Cuse=%d N=%d", B, Cx, Cuse, N);
     if (!aligned16(x) || !aligned16(target) || !aligned16(mask)) return fail(IPSR_ERR_INVALID, "innercos_loss: x/target/mask must be 16-byte aligned");
     return launch_innercos_loss(x, B, Cx, Cuse, N, mask, target, strength, loss, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int innercos_loss_fused(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,
+                        float strength, float* loss, void* ws, size_t ws_bytes, unsigned* ticket, void* stream)
+{
+    if (!x || !mask || !target || !loss || !ws || !ticket) return fail(IPSR_ERR_INVALID, "innercos_loss_fused: null pointer");
+    if (B < 1 || Cuse < 1 || Cx < Cuse || N < 1) return fail(IPSR_ERR_INVALID, "innercos_loss_fused: bad size B=%d Cx=%d Cuse=%d N=%d", B, Cx, Cuse, N);
+    if (!aligned16(x) || !aligned16(target) || !aligned16(mask)) return fail(IPSR_ERR_INVALID, "innercos_loss_fused: x/target/mask must be 16-byte aligned");
+    return launch_innercos_loss_fused(x, B, Cx, Cuse, N, mask, target, strength, loss, ws, ws_bytes, ticket, static_cast<hipStream_t>(stream));
 }
 
 int innercos_loss_backward(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,

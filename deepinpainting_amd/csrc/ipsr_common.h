@@ -221,6 +221,8 @@ int launch_bias_act_bwd(const void* dy, const void* y, int act, float slope, int
 size_t innercos_ws_bytes(int B, int Cuse, int N);
 int launch_innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target,
                          float strength, float* loss, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_innercos_loss_fused(const float* x, int B, int Cx, int Cuse, int N, const float* mask, const float* target, float strength, float* loss,
+                               void* ws, size_t ws_bytes, unsigned* ticket, hipStream_t st);
 int launch_innercos_backward(const float* x, int B, int Cx, int Cuse, int N, const float* mask,
                              const float* target, float strength, const float* grad_loss, float* grad_x,
                              hipStream_t st);

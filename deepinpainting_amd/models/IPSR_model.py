@@ -48,9 +48,13 @@ class IPSR_model(nn.Module):
         self._mask_src = None           # (tensor, version, layer_to_last, threshold) of the last set_mask: an unchanged mask keeps its index
         # capacity of the device-side index (columns of mask_point_idx handed to the kernels; everything the layer sizes by M —
         # compressed attention, backward CSR, LDS of the compress kernel — is sized by it):
-        #   "auto"  the largest per-sample count, rounded up to 32: ONE host read per NEW mask (set_mask with the same, unmodified
-        #           mask tensor keeps the index and costs nothing);   "full"  N, never a host read;   int  caller-supplied bound
+        #   "auto"  the largest per-sample count, rounded up to 32: ONE host read for the FIRST mask (set_mask with the same, unmodified
+        #           mask tensor keeps the index and costs nothing); from the second DIFFERENT mask on — a training loop that draws a
+        #           mask per iteration, train.ipynb c2:16-19 — the capacity is N and nothing is read back: the read stalls the host
+        #           behind the whole queued step (measured: 331 vs 340 images/s), sizing the buffers by N costs nothing measurable;
+        #   "full"  N, never a host read;   int  caller-supplied bound (checked against the mask: one host read per new mask)
         self.index_capacity = "auto"
+        self._masks_seen = 0
 
     def set_mask(self, mask_global, layer_to_last, threshold, feat_mask=None):
         """reference :30-33.  `feat_mask` (optional, [1,1,h,w] byte) lets the trainer share ONE
@@ -68,6 +72,7 @@ class IPSR_model(nn.Module):
             mask = util.cal_feat_mask(mask_global, layer_to_last, threshold)
         self.mask = mask[:, 0] if mask.size(0) > 1 else mask.squeeze()      # [h,w], or [B,h,w] with per-sample masks
         self.cal_fixed_flag = True
+        self._masks_seen += 1
         self._mask_src = (mask_global, mask_global._version, layer_to_last, threshold) if feat_mask is None else None
         return self.mask
 
@@ -93,8 +98,10 @@ class IPSR_model(nn.Module):
             n_win = (self.h - int(self.shift_sz) + 1) * (self.w - int(self.shift_sz) + 1)
             assert flag32.size(1) == n_win, 'mask %s does not match a %dx%d feature' % (tuple(self.mask.shape), self.h, self.w)
             cap = self.index_capacity
+            if cap == "auto" and self._masks_seen > 1:
+                cap = "full"                        # masks change from step to step: no read-back (see __init__)
             if cap == "auto":
-                cap = int(counts.max().item())      # one host read per new mask, off the per-forward path
+                cap = int(counts.max().item())      # one host read for the first mask, off the per-forward path
             elif cap == "full":
                 cap = n_win
             else:

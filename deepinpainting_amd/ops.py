@@ -915,7 +915,10 @@ def conv3x3_winograd_wrw(transposed, x, dy, Cout, out=None, math=None):
     return dw
 
 
-def innercos_loss(x, cuse, mask_f32, target, strength):
+_IC_TICKETS = {}
+
+
+def innercos_loss(x, cuse, mask_f32, target, strength, one_launch=False):
     """K9.  x [B,Cx,h,w] (only the first `cuse` channels are read), target [B,cuse,h,w] -> loss [] fp32."""
     x = _req(x, torch.float32, "in_data")
     target = _req(target, torch.float32, "target")
@@ -927,6 +930,17 @@ def innercos_loss(x, cuse, mask_f32, target, strength):
     loss = torch.empty((), dtype=torch.float32, device=x.device)
     L = _lib.lib()
     ws = _workspace(L.innercos_workspace_bytes(B, cuse, N), x.device)
+    if one_launch:
+        # the last workgroup folds the block partials.  Its arrival counter is a word of OUR memory, one per (device, stream) — the calls
+        # of a stream are ordered, and every launch leaves the word zero — allocated (zeroed) once.  Measured SLOWER than two launches
+        # (csrc/innercos.hip): kept for the C-ABI's completeness and its test, not used by the modules.
+        key = (x.device.index, _stream())
+        ticket = _IC_TICKETS.get(key)
+        if ticket is None:
+            ticket = _IC_TICKETS[key] = torch.zeros(64, dtype=torch.int32, device=x.device)
+        _lib.check(L.innercos_loss_fused(x.data_ptr(), B, Cx, cuse, N, mask.data_ptr(), target.data_ptr(), float(strength),
+                                         loss.data_ptr(), ws.data_ptr(), ws.numel(), ticket.data_ptr(), _stream()), "innercos_loss_fused")
+        return loss
     _lib.check(L.innercos_loss(x.data_ptr(), B, Cx, cuse, N, mask.data_ptr(), target.data_ptr(), float(strength),
                                loss.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "innercos_loss")
     return loss

@@ -351,6 +351,12 @@ size_t innercos_workspace_bytes(int B, int Cuse, int N);
 int innercos_loss(const float* x, int B, int Cx, int Cuse, int N, const float* mask /*[N] fp32*/,
                   const float* target, float strength, float* loss /*[1]*/,
                   void* ws, size_t ws_bytes, void* stream);
+/* the same in ONE launch: the last workgroup to finish adds the block partials (ascending order) and writes the loss.  `ticket`: one
+ * 32-bit word of caller memory that is zero on entry and left zero (the library keeps no device state); calls sharing a word must
+ * be ordered by their stream. */
+int innercos_loss_fused(const float* x, int B, int Cx, int Cuse, int N, const float* mask /*[N] fp32*/,
+                        const float* target, float strength, float* loss /*[1]*/,
+                        void* ws, size_t ws_bytes, unsigned* ticket, void* stream);
 int innercos_loss_backward(const float* x, int B, int Cx, int Cuse, int N, const float* mask,
                            const float* target, float strength, const float* grad_loss /*[1]*/,
                            float* grad_x /*[B,Cx,N]*/, void* stream);
@@ -364,6 +370,7 @@ int innercos_loss_backward(const float* x, int B, int Cx, int Cuse, int N, const
  *   region 2  every whole ipsr_backward / ipsr_backward_patch call
  *   region 3  every launch of the Winograd GEMM kernel (see ipsr_profile_read_region_work)
  *   region 4  every launch of the direct bf16 convolution kernels (ipsr_conv3x3_bf16 / ipsr_conv4x4s2_bf16 / their weight gradient)
+ *   region 5  every launch of the InnerCos loss kernel (innercos_loss_fused; work = algorithmic bytes)
  * so that a training step can report the layer's time ON ITS REAL INPUTS.  ipsr_profile_read_region synchronises the
  * recorded pairs of one region, writes their elapsed times (ms) to the HOST array `ms` and resets that ring; it returns
  * the number written.  ipsr_profile_read(ms, n) == ipsr_profile_read_region(0, ms, n).  ipsr_profile_enable(capacity)

@@ -543,6 +543,9 @@ def test_innercos_vs_golden(ops, name):
     cuse = d["ic_target"].shape[1]
     mask = dev(d["feat_mask"].astype(np.float32).reshape(-1))
     loss = ops.innercos_loss(dev(d["x"]), cuse, mask, dev(d["ic_target"]), float(d["strength"]))
+    for _ in range(3):              # the one-launch form (caller-owned arrival counter, left zero by every call) agrees to fp64 rounding
+        one = ops.innercos_loss(dev(d["x"]), cuse, mask, dev(d["ic_target"]), float(d["strength"]), one_launch=True)
+        np.testing.assert_allclose(one.item(), loss.item(), rtol=1e-6)
     np.testing.assert_allclose(loss.item(), d["ic_loss"], rtol=1e-5)
     np.testing.assert_allclose(loss.item(), orc.innercos_loss(d["x"], d["feat_mask"], d["ic_target"], float(d["strength"])), rtol=1e-6)
     if "ic_grad" in d:
