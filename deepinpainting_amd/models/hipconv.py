@@ -95,6 +95,8 @@ def _bf16_direct(force, mode, op, B, Cin, H, W, Cout, k, stride, pad, dil):
         return "miopen"
     if k == 3 and stride == 1 and pad == 1 and dil == 1 and H * W >= 1024 and ops.conv3x3_bf16_supported(op, B, Cin, H, W, Cout):
         return "bf16d"
+    # (measured and not kept: the small-map engine on fp32 copies for the innermost levels beyond 32 positions per batch — 708 images/s at
+    # 32, 706 at 64, 696 at 256, 658 at 1024: MIOpen's tiny bf16 convolutions cost 45-60 us per CALL but far less device time)
     g = _s2_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
     if g is not None and ops.conv4x4s2_bf16_supported(_s2_mode(op), B, *g):
         # the 4x4 stride-2 family (profiles/r04_conv_bf16_layers.txt, batch 16): 1.3-2x MIOpen wherever the launch has enough tiles;
