@@ -281,6 +281,17 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
                         }
                     }
                 }
+        } else if (sizeof(TOUT) == 2) {
+            // bf16 output: through LDS (free after the last stage's barrier) as [k][256 pixels], so that the tile leaves as 16-byte rows
+            // instead of 64 two-byte stores per lane
+            unsigned short* L = reinterpret_cast<unsigned short*>(lds);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kl = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    L[kl * CB_P + p] = f2bf(acc[0][i][j][e]);
+                }
         } else {
             const bool live = py < g.Hout && px < g.Wout;      // (lane grid == output grid here)
             TOUT* op = out + (size_t)b * g.K * HWo + (size_t)py * g.Wout + px;
@@ -291,6 +302,20 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
                     const int k = kt * KT + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (live && k < g.K) st1(op, (size_t)k * HWo, acc[0][i][j][e]);
                 }
+        }
+    }
+    if (MODE != CB_C2F && sizeof(TOUT) == 2) {
+        __syncthreads();
+        const uint4* L4 = reinterpret_cast<const uint4*>(lds);
+#pragma unroll
+        for (int it = 0; it < KT * CB_P * 2 / 16 / CB_THREADS; ++it) {
+            const int chunk = tid + CB_THREADS * it;           // 32 chunks of 8 pixels per channel row
+            const int kl = chunk >> 5, p0 = (chunk & 31) * 8;
+            const int k = kt * KT + kl;
+            if (k < g.K) {
+                TOUT* op = out + ((size_t)b * g.K + k) * HWo + (size_t)(y0 + (p0 >> g.wshift)) * g.Wout + (p0 & (g.Wl - 1));
+                *reinterpret_cast<uint4*>(op) = L4[chunk];
+            }
         }
     }
 }
@@ -649,9 +674,10 @@ static int wb_geometry(int B, int Ka, int Cb, int H, int W, WbGeom* g)
     g->ktiles = (Ka + WB_K - 1) / WB_K; g->ctiles = (Cb + WB_C - 1) / WB_C;
     if (g->NSLOT * WB_C * g->pitch * 16 > WB_X_BYTES || RS * WB_C * g->pitch > 5 * WB_THREADS)
         return fail(IPSR_ERR_UNSUPPORTED, "bf16 weight gradient: the row ring of a %d-wide image does not fit the LDS plan", W);
-    // runs: about two rounds of one workgroup per CU
+    // runs: ONE round of one workgroup per CU — every run costs a 295-KB partial slab written and read back (PMC, 128 -> 128 @128x128:
+    // 512 runs = 151 MB each way against 134 MB of operands)
     const int groups = H / RS;                                // stages per image
-    int spw = (int)(((long)g->ktiles * g->ctiles * B * groups + 511) / 512);
+    int spw = (int)(((long)g->ktiles * g->ctiles * B * groups + 255) / 256);
     if (spw < 1) spw = 1;
     if (spw > groups) spw = groups;
     while (groups % spw) --spw;

@@ -123,10 +123,8 @@ def _bf16_wins(eng, Cin, H, W, Cout, wrw=False):
         return True
     if eng == "winograd":
         # round 4: against the DIRECT bf16 kernel (csrc/conv_bf16.hip, profiles/r04_conv_bf16_layers.txt) the split engines keep the 16x16
-        # maps (0.056-0.080 vs 0.079-0.146 ms) and the 512-channel weight gradients at 32x32 (0.084-0.121 vs 0.090-0.133)
-        if H * W <= 256:
-            return max(Cin, Cout) >= 512
-        return wrw and H * W <= 1024 and min(Cin, Cout) >= 256 and max(Cin, Cout) == 512
+        # maps (0.056-0.080 vs 0.079-0.146 ms); at 32x32 the direct weight gradient ties or wins since its runs were halved (0.068-0.131 vs 0.084-0.126)
+        return H * W <= 256 and max(Cin, Cout) >= 512
     if eng == "wino_dil":
         return H * W <= 4096 and min(Cin, Cout) >= 256
     return False
@@ -265,13 +263,11 @@ def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
 
 @functools.lru_cache(maxsize=4096)
 def _bf16_direct_wrw(force, mode, transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
-    """Weight gradient on bf16 activations by the direct kernel (ops.conv3x3_bf16_wrw): 1.3-1.6x MIOpen from two 128 x 64 output tiles
-    up; a single tile (64 -> 128 channels) leaves the chip to the partial-sum traffic and stays on MIOpen."""
+    """Weight gradient on bf16 activations by the direct kernel (ops.conv3x3_bf16_wrw): 1.1-2.0x MIOpen on every map from 32x32 up (one
+    run per CU: the partial-sum slabs are what it costs)."""
     if force == "none" or mode in ("miopen", "winograd", "direct"):
         return "miopen"
-    ka, cb = (Cin, Cout) if transposed else (Cout, Cin)
-    if k == 3 and stride == 1 and pad == 1 and dil == 1 and H * W >= 1024 and ((ka + 127) // 128) * ((cb + 63) // 64) >= 2 \
-            and ops.conv3x3_bf16_wrw_supported(transposed, B, Cin, H, W, Cout):
+    if k == 3 and stride == 1 and pad == 1 and dil == 1 and H * W >= 1024 and ops.conv3x3_bf16_wrw_supported(transposed, B, Cin, H, W, Cout):
         return "bf16d"
     g = _s2_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
     if g is not None and g[3] >= 32 and ((g[0] + 127) // 128) * ((g[1] + 31) // 32) >= 4 and ops.conv4x4s2_bf16_wrw_supported(B, *g):

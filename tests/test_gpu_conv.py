@@ -688,9 +688,9 @@ def test_direct_bf16_conv_through_the_modules_under_autocast():
         hipconv._check_hook = None
     assert seen.count(("forward", "bf16d")) == 4 and seen.count(("input_grad", "bf16d")) == 4 and seen.count(("weight_grad", "bf16d")) == 4, seen
     assert hipconv.select(ops.CONV_FWD, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"          # where split-bf16 Winograd still wins
-    assert hipconv.select(ops.CONV_FWD, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d" and hipconv.select_wrw(False, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "winograd"
+    assert hipconv.select(ops.CONV_FWD, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d" and hipconv.select_wrw(False, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"
     assert hipconv.select(ops.CONV_FWD, 16, 128, 128, 128, 128, 3, 1, 1, 1, True) == "bf16d"
-    assert hipconv.select_wrw(False, 16, 64, 128, 128, 128, 3, 1, 1, 1, True) == "miopen"              # one output tile: partial-sum bound
+    assert hipconv.select_wrw(False, 16, 64, 128, 128, 128, 3, 1, 1, 1, True) == "bf16d" and hipconv.select_wrw(False, 16, 64, 256, 256, 64, 3, 1, 1, 1, True) == "miopen"
     assert hipconv.select(ops.CONV_FWD, 16, 128, 128, 128, 128, 3, 1, 1, 1, False) == "winograd"       # fp32 activations: untouched
 
 
