@@ -528,6 +528,7 @@ def main():
     for i in range(args.steps):
         train_step(model, img, mask, ref)
         step_ev[i + 1].record()
+    host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)      # the host's share: launches queued, nothing waited for
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -676,6 +677,7 @@ def main():
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(statistics.median(step_ms), 3),
+        "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
         "images_per_sec_median_step": round(args.batch * world / (statistics.median(step_ms) * 1e-3), 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: 256x256 synthetic images, 128x128 centre mask (M=256 of N=1024 "

@@ -228,10 +228,12 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
 
     for (int s = 0; s < g.nstage; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
+        // The transposition goes first: hipcc drains every LDS-DMA in flight (s_waitcnt vmcnt(0)) before a ds_read_b64_tr_b16, so a
+        // DMA issued ahead of it would be waited for here instead of behind the multiplications.
+        if (!g.raw1 && s + 1 < g.nstage) transpose(nxt, nxt);  // raw[nxt] (stage s+1) landed before the barrier that ended stage s-1
         if (s + 1 < g.nstage) dma_a(nxt, s + 1);               // A[nxt] was last read in stage s-1
         if (!g.raw1) {
             if (s + 2 < g.nstage) dma_x(cur, s + 2);           // raw[cur] was transposed in stage s-1
-            if (s + 1 < g.nstage) transpose(nxt, nxt);         // raw[nxt] (stage s+1) landed before the barrier that ended stage s-1
         } else if (s + 1 < g.nstage) {
             dma_x(0, s + 1);                                   // the one raw buffer was transposed at the end of stage s-1
         }
@@ -515,6 +517,10 @@ struct WbGeom {
     int ktiles, ctiles;
 };
 
+// LDS reads that run beside an LDS-DMA use ext-vector types: a HIP_vector_type (uint4) load is a struct copy that reaches the back end
+// without alias metadata, and hipcc then drains the DMA queue (s_waitcnt vmcnt(0)) in front of it — the prefetch stops overlapping.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ unsigned alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 
 __global__ void __launch_bounds__(WB_THREADS, 1) conv_bf16_wrw_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ w,
@@ -618,7 +624,7 @@ __global__ void __launch_bounds__(WB_THREADS, 1) conv_bf16_wrw_kernel(const unsi
             for (int dy = 0; dy < 3; ++dy) {
                 int slot = (y0 + rs + dy) % g.NSLOT;          // image row y0 + rs + dy - 1 lives in ring slot (y + 1) mod NSLOT
                 const unsigned char* X = lds + 2 * WB_A_BYTES + slot * ring_row_bytes + (bcol * g.pitch + 1 + (px >> 3)) * 16;
-                const uint4 c4 = *reinterpret_cast<const uint4*>(X);
+                const u32x4 c4 = *reinterpret_cast<const u32x4*>(X);    // ext-vector load (see u32x4)
                 const unsigned prev = *reinterpret_cast<const unsigned*>(X - 4);
                 const unsigned next = *reinterpret_cast<const unsigned*>(X + 16);
                 const unsigned s0 = alignbit16(c4.x, prev), s1 = alignbit16(c4.y, c4.x), s2 = alignbit16(c4.z, c4.y), s3 = alignbit16(c4.w, c4.z),
@@ -844,8 +850,8 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_wrw_s2_kernel(const unsigned
                 const int u = 2 * (y0 + rs) + 2 * rh + ri;    // = fine row + 1
                 const int entry = (u >> 1) % g.NPAIR;
                 const unsigned char* X = lds + 2 * W2_A_BYTES + entry * pair_bytes + (u & 1) * row_bytes + (r * g.pitch + 1 + (ox0 >> 2)) * 16;
-                const uint4 lo4 = *reinterpret_cast<const uint4*>(X);
-                const uint4 hi4 = *reinterpret_cast<const uint4*>(X + 16);
+                const u32x4 lo4 = *reinterpret_cast<const u32x4*>(X);
+                const u32x4 hi4 = *reinterpret_cast<const u32x4*>(X + 16);
                 const unsigned prev = *reinterpret_cast<const unsigned*>(X - 4);
                 const unsigned next = *reinterpret_cast<const unsigned*>(X + 32);
                 const unsigned d0 = lo4.x, d1 = lo4.y, d2 = lo4.z, d3 = lo4.w, d4 = hi4.x, d5 = hi4.y, d6 = hi4.z, d7 = hi4.w;
