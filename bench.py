@@ -31,6 +31,9 @@ Rank 0 prints ONE JSON line.  `value` = images/s of the whole job (all ranks).  
                 layer alone on synthetic non-negative features (median of 50).
   strict_reference  the same step with opt.strict_reference=True (the reference's exact sequence incl. the work whose
                 results it never reads, 414.9 GFLOP/image), timed after the headline loop.
+  step_graph    whether the timed steps were replayed from one HIP graph (deepinpainting_amd/stepgraph.py; --graph): default for
+                --dtype bf16 on one GPU, where queueing the step's ~1400 kernels from Python takes as long as running them
+                (`host_enqueue_ms_per_step`); the per-kernel event timings are then taken in eager steps right after the loop.
 `value` = batch * world * K / wall time of the K timed steps (the driver's contract); `ms_per_step_median` and
 `images_per_sec_median_step` (SURVEY §8d's definition) come from HIP events recorded at every step boundary.
 """
@@ -457,6 +460,11 @@ def main():
                     help="nccl = RCCL over xGMI (the measurement); gloo = DRY MODE on the CPU: launcher + argument plumbing + the "
                          "gradient exchange on stand-in nets, no kernels (tests/test_bench_launcher.py)")
     ap.add_argument("--ddp-bucket-mb", type=int, default=64, help="gradient bucket size of the all-reduce (dist.GradBucketReducer)")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="replay the training step from one HIP graph (deepinpainting_amd/stepgraph.py) instead of queueing its ~1100-1400 "
+                         "kernels from Python every step; auto = on where the host is the bound (--dtype bf16 on one GPU: 21.9 ms of queueing "
+                         "for 21.3 ms of GPU work), off for the fp32 headline (GPU-bound: 23.7 ms with either form, and the roofline events stay "
+                         "inside the timed steps) and for N > 1 (the gradient exchange is not recorded)")
     args = ap.parse_args()
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
@@ -517,7 +525,34 @@ def main():
     for red in reducers.values():
         if red is not None:
             red.exposed_ms()                      # drop the warm-up steps' records
-    lib.ipsr_profile_enable(max(args.steps, 1))
+    # One GPU: the step is replayed from a HIP graph recorded here (the recording's own warm-up steps are undone, see StepGraph._record);
+    # if the recording fails the loop below queues the kernels from Python as before, and the JSON line says so.
+    graph_info = {"used": False, "reason": "--graph off" if args.graph == "off" else
+                  ("N > 1: the gradient exchange is not recorded" if world > 1 else "--graph auto: the fp32 step is GPU-bound (see host_enqueue_ms_per_step)")}
+    sgraph = None
+    if world == 1 and (args.graph == "on" or (args.graph == "auto" and args.dtype == "bf16")):
+        from deepinpainting_amd.stepgraph import StepGraph
+        try:
+            sgraph = StepGraph(model)
+            sgraph.step(img, mask, ref)
+            torch.cuda.synchronize()
+            graph_info = {"used": True, "recordings": sgraph.recordings,
+                          "note": "timed steps = hipGraphLaunch of the recorded step (same kernels, same order); the per-kernel HIP-event "
+                                  "timings of this line are taken in eager steps right after the timed loop (events are not recorded into a graph)"}
+        except Exception as e:                                      # noqa: BLE001 — report and measure the eager step instead
+            sgraph = None
+            graph_info = {"used": False, "reason": "recording failed: %s: %s" % (type(e).__name__, str(e)[:300])}
+            torch.cuda.synchronize()
+        if rank == 0:
+            print("[bench] step graph: %s (%.1f s since start)" % (graph_info, time.perf_counter() - T_START), file=sys.stderr, flush=True)
+
+    def one_step():
+        if sgraph is not None:
+            sgraph.step(img, mask, ref)
+        else:
+            train_step(model, img, mask, ref)
+    if sgraph is None:
+        lib.ipsr_profile_enable(max(args.steps, 1))
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     if world > 1:
@@ -526,7 +561,7 @@ def main():
     t0 = time.perf_counter()
     step_ev[0].record()
     for i in range(args.steps):
-        train_step(model, img, mask, ref)
+        one_step()
         step_ev[i + 1].record()
     host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)      # the host's share: launches queued, nothing waited for
     torch.cuda.synchronize()
@@ -544,16 +579,19 @@ def main():
         buf = (ctypes.c_float * max(args.steps, 1))()
         n = lib.ipsr_profile_read_region(region, ctypes.cast(buf, ctypes.c_void_p), args.steps)
         return [buf[i] for i in range(n)]
-    kern_ms, fwd_in_step, bwd_in_step = read_region(0), read_region(1), read_region(2)
+    if sgraph is None:
+        kern_ms, fwd_in_step, bwd_in_step = read_region(0), read_region(1), read_region(2)
     lib.ipsr_profile_enable(0)
     # region 3: every launch of the convolutions' matrix-core kernel (Winograd GEMM), with its flops — in a few EXTRA steps
     # after the timed loop (~100 more event records per step would perturb the headline number)
     gsteps = 3
     ncap = 256 * gsteps
-    lib.ipsr_profile_enable_mask(gsteps, 0x38)
+    lib.ipsr_profile_enable_mask(gsteps, 0x38 if sgraph is None else 0x3F)
     for _ in range(gsteps):
         train_step(model, img, mask, ref)
     torch.cuda.synchronize()
+    if sgraph is not None:                                # the layer's regions too: the timed loop replayed a graph, which carries no events
+        kern_ms, fwd_in_step, bwd_in_step = read_region(0), read_region(1), read_region(2)
 
     def read_work(region):
         ms, work, use = (ctypes.c_float * ncap)(), (ctypes.c_double * ncap)(), (ctypes.c_double * ncap)()
@@ -677,7 +715,7 @@ def main():
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(statistics.median(step_ms), 3),
-        "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
+        "host_enqueue_ms_per_step": round(host_enqueue_ms, 3), "step_graph": graph_info,
         "images_per_sec_median_step": round(args.batch * world / (statistics.median(step_ms) * 1e-3), 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: 256x256 synthetic images, 128x128 centre mask (M=256 of N=1024 "
@@ -696,8 +734,10 @@ def main():
                                       "total": round(statistics.median(fwd_in_step) + statistics.median(bwd_in_step), 4)
                                       if fwd_in_step and bwd_in_step else None,
                                       "calls_timed": [len(fwd_in_step), len(bwd_in_step)],
-                                      "inputs": "HIP events around ipsr_forward / ipsr_backward inside the timed training steps "
-                                                "(real signed conv features, batch %d)" % args.batch}},
+                                      "inputs": ("HIP events around ipsr_forward / ipsr_backward inside the timed training steps "
+                                                 "(real signed conv features, batch %d)" % args.batch) if sgraph is None else
+                                                ("HIP events around ipsr_forward / ipsr_backward in %d eager training steps right after the timed "
+                                                 "loop, which replayed a HIP graph (real signed conv features, batch %d)" % (gsteps, args.batch))}},
         "ipsr_layer_ms_bf16corr": layer_timing_bf16corr(device),
         "ipsr_layer_ms_other_configs": layer_timing_other_configs(device),
         "roofline": {"kernel": "ipsr::corr_argmax_kernel (fp32 MFMA correlation + arg-max)" if args.dtype == "f32" else

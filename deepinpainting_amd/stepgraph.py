@@ -65,6 +65,25 @@ class StepGraph(object):
     def _adam_state(o):
         return [v for st in o.state.values() for v in st.values() if torch.is_tensor(v)]
 
+    def _drop_autograd_graph(self):
+        """The trainer keeps the last step's results (fake_B, the predictions, the losses, the InnerCos taps' `loss`), and through them
+        that step's autograd graph with its AccumulateGrad nodes.  Those nodes remember the stream they were created on and every later
+        forward reuses them while they live: after eager steps on the default stream the recorded backward would hop to the default
+        stream in the middle of the capture (torch warns; hipStreamEndCapture then faults).  Detaching the kept results frees the graph,
+        and the warm-up on the capture stream creates the nodes anew."""
+        seen, objs = set(), [self.model]
+        for v in vars(self.model).values():
+            for mod in (v if isinstance(v, (list, tuple)) else [v]):
+                if isinstance(mod, torch.nn.Module):
+                    objs += list(mod.modules())
+        for o in objs:
+            if id(o) in seen:
+                continue
+            seen.add(id(o))
+            for k, v in list(vars(o).items()):
+                if torch.is_tensor(v) and v.grad_fn is not None:
+                    setattr(o, k, v.detach())
+
     def _record(self, img, mask, ref):
         """Warm-up steps on the capture stream (MIOpen's solver look-ups, the per-stream workspaces, the Adam state's first
         allocation), undone afterwards: parameters, buffers, optimizer state and the generator go back to their values before the
@@ -76,6 +95,7 @@ class StepGraph(object):
                 g['capturable'] = True                  # fused Adam keeps `step` on the device either way; this lifts torch's capture check
         self._img, self._ref, self._mask = img.clone(), ref.clone(), mask
         _lib.lib().ipsr_profile_enable(0)               # region timing records HIP events on the launch stream: not inside a capture
+        self._drop_autograd_graph()
         cur = torch.cuda.current_stream(m.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):

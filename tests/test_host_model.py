@@ -101,6 +101,15 @@ def test_trainer_refuses_a_silently_random_vgg(monkeypatch):
         quiet(create_model, Option(gpu_ids=[], quiet=True))
 
 
+def test_step_graph_needs_the_gpu():
+    """A HIP graph is recorded from a HIP stream: on a CPU model the recorder says so instead of stepping eagerly behind the caller's back."""
+    from types import SimpleNamespace
+    import torch
+    from deepinpainting_amd.stepgraph import StepGraph
+    with pytest.raises(RuntimeError, match="MI355X"):
+        StepGraph(SimpleNamespace(device=torch.device("cpu")))
+
+
 def test_scheduler_lambda_rule():
     opt = Option(niter=2, niter_decay=3, epoch_count=1)
     p = torch.nn.Parameter(torch.zeros(1))
