@@ -31,9 +31,9 @@ Rank 0 prints ONE JSON line.  `value` = images/s of the whole job (all ranks).  
                 layer alone on synthetic non-negative features (median of 50).
   strict_reference  the same step with opt.strict_reference=True (the reference's exact sequence incl. the work whose
                 results it never reads, 414.9 GFLOP/image), timed after the headline loop.
-  step_graph    whether the timed steps were replayed from one HIP graph (deepinpainting_amd/stepgraph.py; --graph): default for
-                --dtype bf16 on one GPU, where queueing the step's ~1400 kernels from Python takes as long as running them
-                (`host_enqueue_ms_per_step`); the per-kernel event timings are then taken in eager steps right after the loop.
+  step_graph    whether the timed steps were replayed from one HIP graph (deepinpainting_amd/stepgraph.py; --graph on, off by
+                default: the replay is no faster than the eager step here); the per-kernel event timings are then taken in eager
+                steps right after the loop.  `host_enqueue_ms_per_step` = the host's share of a step (kernels queued, nothing waited for).
 `value` = batch * world * K / wall time of the K timed steps (the driver's contract); `ms_per_step_median` and
 `images_per_sec_median_step` (SURVEY §8d's definition) come from HIP events recorded at every step boundary.
 """
@@ -460,11 +460,11 @@ def main():
                     help="nccl = RCCL over xGMI (the measurement); gloo = DRY MODE on the CPU: launcher + argument plumbing + the "
                          "gradient exchange on stand-in nets, no kernels (tests/test_bench_launcher.py)")
     ap.add_argument("--ddp-bucket-mb", type=int, default=64, help="gradient bucket size of the all-reduce (dist.GradBucketReducer)")
-    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="replay the training step from one HIP graph (deepinpainting_amd/stepgraph.py) instead of queueing its ~1100-1400 "
-                         "kernels from Python every step; auto = on where the host is the bound (--dtype bf16 on one GPU: 21.9 ms of queueing "
-                         "for 21.3 ms of GPU work), off for the fp32 headline (GPU-bound: 23.7 ms with either form, and the roofline events stay "
-                         "inside the timed steps) and for N > 1 (the gradient exchange is not recorded)")
+    ap.add_argument("--graph", choices=("on", "off"), default="off",
+                    help="on: replay the training step from one HIP graph (deepinpainting_amd/stepgraph.py, one GPU only) instead of queueing its "
+                         "~1100-1400 kernels from Python every step.  Off by default: measured at --dtype bf16 --batch 16 the replay takes 22.5 ms "
+                         "against 21.7 ms for the eager step (hipGraphLaunch orders its ~1400 nodes one by one), although it frees the host "
+                         "(0.4 ms instead of 21.9 ms of queueing per step)")
     args = ap.parse_args()
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
@@ -527,10 +527,9 @@ def main():
             red.exposed_ms()                      # drop the warm-up steps' records
     # One GPU: the step is replayed from a HIP graph recorded here (the recording's own warm-up steps are undone, see StepGraph._record);
     # if the recording fails the loop below queues the kernels from Python as before, and the JSON line says so.
-    graph_info = {"used": False, "reason": "--graph off" if args.graph == "off" else
-                  ("N > 1: the gradient exchange is not recorded" if world > 1 else "--graph auto: the fp32 step is GPU-bound (see host_enqueue_ms_per_step)")}
+    graph_info = {"used": False, "reason": "--graph off (the default)" if args.graph == "off" else "N > 1: the gradient exchange is not recorded"}
     sgraph = None
-    if world == 1 and (args.graph == "on" or (args.graph == "auto" and args.dtype == "bf16")):
+    if world == 1 and args.graph == "on":
         from deepinpainting_amd.stepgraph import StepGraph
         try:
             sgraph = StepGraph(model)
@@ -570,6 +569,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+    # a step that went wrong must not produce a throughput number: the losses of the last timed step are finite, or the run stops here
+    timed_losses = {k: float(v) for k, v in model.get_current_errors().items()}
+    if not all(v == v and abs(v) != float("inf") for v in timed_losses.values()):
+        raise SystemExit("bench.py: non-finite losses after the timed steps: %s" % timed_losses)
     ddp = ddp_report(args, world, rank, device, elapsed, step_ms, reducers, "nccl") if world > 1 else None
     for red in reducers.values():
         if red is not None:
@@ -767,6 +770,7 @@ def main():
         "strict_reference": strict,
         "ddp": ddp,
         "losses_last_step": {k: round(v, 4) for k, v in errs.items()},
+        "losses_last_timed_step": {k: round(v, 4) for k, v in timed_losses.items()},
     }
     if world == 1 and not args.no_cpu_baseline:
         print("[bench] GPU part done: %.2f images/s; timing the CPU twin ..." % value, file=sys.stderr, flush=True)

@@ -25,16 +25,26 @@ __device__ __forceinline__ float thin_relu(float v) { return v < 0.0f ? 0.0f : v
 // few -> many.  One thread = TWO adjacent pixels x 16 output channels: the I x 3 x 4 window values live in registers, the 16*I*9 weights in
 // LDS (uniform reads: broadcast) — every weight read feeds two multiply-adds (with one pixel per thread the kernel was bound by its 432
 // ds_reads per thread, 2 TB/s of output).  grid (ceil(W/512), H, B * O/16); W even.
-template <int I>
-__global__ void __launch_bounds__(256) thin_f2m_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, int relu,
-                                                       float* __restrict__ out, int B, int O, int H, int W, long so, long si, int flip)
+// TIN / TOUT = float or bf16_t.  With a bf16 side (BASELINE config 5) the kernel is the autocast convolution: weights and an fp32 input are
+// rounded to bf16 on the way in (what autocast's casts do), products accumulate in fp32, bias / ReLU in fp32, one rounding on the way out.
+template <typename T> struct thin_is_bf16 { static constexpr bool value = false; };
+template <> struct thin_is_bf16<bf16_t> { static constexpr bool value = true; };
+__device__ __forceinline__ float thin_rb(float v) { return bf2f(f2bf(v)); }
+__device__ __forceinline__ void thin_st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+__device__ __forceinline__ void thin_st2(bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+
+template <int I, typename TIN, typename TOUT>
+__global__ void __launch_bounds__(256) thin_f2m_kernel(const TIN* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, int relu,
+                                                       TOUT* __restrict__ out, int B, int O, int H, int W, long so, long si, int flip)
 {
+    constexpr bool RB = thin_is_bf16<TIN>::value || thin_is_bf16<TOUT>::value;
     __shared__ float wl[THIN_OC][I * 9];
     const int nchunk = O / THIN_OC;
     const int b = blockIdx.z / nchunk, o0 = (blockIdx.z - b * nchunk) * THIN_OC;
     for (int idx = threadIdx.x; idx < THIN_OC * I * 9; idx += 256) {
         const int o = idx / (I * 9), rem = idx - o * (I * 9), i = rem / 9, t = rem - i * 9;
-        wl[o][rem] = w[(long)(o0 + o) * so + (long)i * si + (flip ? 8 - t : t)];
+        const float wv = w[(long)(o0 + o) * so + (long)i * si + (flip ? 8 - t : t)];
+        wl[o][rem] = RB ? thin_rb(wv) : wv;
     }
     __syncthreads();
     const int x = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
@@ -42,7 +52,7 @@ __global__ void __launch_bounds__(256) thin_f2m_kernel(const float* __restrict__
     float win[I][3][4];                                   // columns x-1 .. x+2
 #pragma unroll
     for (int i = 0; i < I; ++i) {
-        const float* ip = in + ((size_t)b * I + i) * H * W;
+        const TIN* ip = in + ((size_t)b * I + i) * H * W;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int yy = y + r - 1;
@@ -50,11 +60,12 @@ __global__ void __launch_bounds__(256) thin_f2m_kernel(const float* __restrict__
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int xx = x + c - 1;
-                win[i][r][c] = (yok && (unsigned)xx < (unsigned)W) ? ip[(size_t)yy * W + xx] : 0.0f;
+                const float v = (yok && (unsigned)xx < (unsigned)W) ? ld1(ip, (size_t)yy * W + xx) : 0.0f;
+                win[i][r][c] = (RB && !thin_is_bf16<TIN>::value) ? thin_rb(v) : v;
             }
         }
     }
-    float* op = out + (((size_t)b * O + o0) * H + y) * W + x;
+    TOUT* op = out + (((size_t)b * O + o0) * H + y) * W + x;
 #pragma unroll 4
     for (int o = 0; o < THIN_OC; ++o) {
         float a0 = bias ? bias[o0 + o] : 0.0f, a1 = a0;
@@ -69,20 +80,22 @@ __global__ void __launch_bounds__(256) thin_f2m_kernel(const float* __restrict__
                     a1 = __builtin_fmaf(wv, win[i][r][q + 1], a1);
                 }
         if (relu) { a0 = thin_relu(a0); a1 = thin_relu(a1); }
-        *reinterpret_cast<float2*>(op + (size_t)o * H * W) = make_float2(a0, a1);
+        thin_st2(op + (size_t)o * H * W, a0, a1);
     }
 }
 
 // many -> few.  One thread = 4 adjacent pixels x all O outputs; per input channel three float4 rows (+ the two halo columns),
 // the O*9 weights of the channel from LDS.  grid (ceil(W/1024 * 4 rows) ...): block = 4 rows x 64 lanes x 4 pixels.
-template <int O>
-__global__ void __launch_bounds__(256) thin_m2f_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+template <int O, typename TIN, typename TOUT>
+__global__ void __launch_bounds__(256) thin_m2f_kernel(const TIN* __restrict__ in, const float* __restrict__ w, TOUT* __restrict__ out,
                                                        int B, int I, int H, int W, long so, long si, int flip)
 {
+    constexpr bool RB = thin_is_bf16<TIN>::value || thin_is_bf16<TOUT>::value;
     extern __shared__ float wl[];                 // [I][O*9]
     for (int idx = threadIdx.x; idx < I * O * 9; idx += 256) {
         const int i = idx / (O * 9), rem = idx - i * (O * 9), o = rem / 9, t = rem - o * 9;
-        wl[idx] = w[(long)o * so + (long)i * si + (flip ? 8 - t : t)];
+        const float wv = w[(long)o * so + (long)i * si + (flip ? 8 - t : t)];
+        wl[idx] = RB ? thin_rb(wv) : wv;
     }
     __syncthreads();
     const int b = blockIdx.z;
@@ -94,20 +107,24 @@ __global__ void __launch_bounds__(256) thin_m2f_kernel(const float* __restrict__
     for (int o = 0; o < O; ++o)
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[o][p] = 0.0f;
-    const float* ib = in + (size_t)b * I * H * W;
+    const TIN* ib = in + (size_t)b * I * H * W;
     for (int i = 0; i < I; ++i) {
-        const float* ip = ib + (size_t)i * H * W;
+        const TIN* ip = ib + (size_t)i * H * W;
         const float* wi = wl + i * (O * 9);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int yy = y + r - 1;
             float v[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             if ((unsigned)yy < (unsigned)H) {
-                const float* rp = ip + (size_t)yy * W + x0;
-                const float4 c = *reinterpret_cast<const float4*>(rp);
+                const size_t e = (size_t)yy * W + x0;                // a multiple of 4 (W % 4 == 0): ld4 indexes 4-element vectors
+                const float4 c = ld4(ip, e >> 2);
                 v[1] = c.x; v[2] = c.y; v[3] = c.z; v[4] = c.w;
-                if (x0 > 0) v[0] = rp[-1];
-                if (x0 + 4 < W) v[5] = rp[4];
+                if (x0 > 0) v[0] = ld1(ip, e - 1);
+                if (x0 + 4 < W) v[5] = ld1(ip, e + 4);
+                if (RB && !thin_is_bf16<TIN>::value) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) v[q] = thin_rb(v[q]);
+                }
             }
 #pragma unroll
             for (int o = 0; o < O; ++o)
@@ -121,14 +138,14 @@ __global__ void __launch_bounds__(256) thin_m2f_kernel(const float* __restrict__
     }
 #pragma unroll
     for (int o = 0; o < O; ++o)
-        *reinterpret_cast<float4*>(out + (((size_t)b * O + o) * H + y) * W + x0) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+        st4(out, ((((size_t)b * O + o) * H + y) * W + x0) >> 2, make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]));
 }
 
 // weight gradient, pass 1.  One workgroup = THIN_CB wide channels x THIN_ROWS rows of one sample; a thread walks its 4 pixels of each
 // row (4 rows at a time), keeps THIN_CB*CS*9 partial sums, the workgroup reduces them through LDS (fixed order) and writes one
 // partial vector.  grid (ceil(W/256), ceil(H/THIN_ROWS), B * Cb/THIN_CB).
-template <int CS>
-__global__ void __launch_bounds__(256) thin_wrw_kernel(const float* __restrict__ big, const float* __restrict__ small, float* __restrict__ part,
+template <int CS, typename TB, typename TS>
+__global__ void __launch_bounds__(256) thin_wrw_kernel(const TB* __restrict__ big, const TS* __restrict__ small, float* __restrict__ part,
                                                        int B, int Cb, int H, int W)
 {
     constexpr int NV = THIN_CB * CS * 9;
@@ -151,22 +168,30 @@ __global__ void __launch_bounds__(256) thin_wrw_kernel(const float* __restrict__
             float g[THIN_CB][4];
 #pragma unroll
             for (int c = 0; c < THIN_CB; ++c) {
-                const float4 v = *reinterpret_cast<const float4*>(big + (((size_t)b * Cb + cb0 + c) * H + y) * W + x0);
+                const float4 v = ld4(big, ((((size_t)b * Cb + cb0 + c) * H + y) * W + x0) >> 2);
                 g[c][0] = v.x; g[c][1] = v.y; g[c][2] = v.z; g[c][3] = v.w;
+                if (thin_is_bf16<TS>::value && !thin_is_bf16<TB>::value) {       // mixed operands: the fp32 one is rounded as autocast's cast would
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) g[c][p] = thin_rb(g[c][p]);
+                }
             }
 #pragma unroll
             for (int k = 0; k < CS; ++k) {
-                const float* sp = small + ((size_t)b * CS + k) * H * W;
+                const TS* sp = small + ((size_t)b * CS + k) * H * W;
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
                     const int yy = y + u - 1;
                     float v[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     if ((unsigned)yy < (unsigned)H) {
-                        const float* rp = sp + (size_t)yy * W + x0;
-                        const float4 c4 = *reinterpret_cast<const float4*>(rp);
+                        const size_t e = (size_t)yy * W + x0;
+                        const float4 c4 = ld4(sp, e >> 2);
                         v[1] = c4.x; v[2] = c4.y; v[3] = c4.z; v[4] = c4.w;
-                        if (x0 > 0) v[0] = rp[-1];
-                        if (x0 + 4 < W) v[5] = rp[4];
+                        if (x0 > 0) v[0] = ld1(sp, e - 1);
+                        if (x0 + 4 < W) v[5] = ld1(sp, e + 4);
+                        if (thin_is_bf16<TB>::value && !thin_is_bf16<TS>::value) {
+#pragma unroll
+                            for (int q = 0; q < 6; ++q) v[q] = thin_rb(v[q]);
+                        }
                     }
 #pragma unroll
                     for (int c = 0; c < THIN_CB; ++c)
@@ -358,33 +383,48 @@ using namespace ipsr;
 
 extern "C" {
 
-int ipsr_conv3x3_thin(int op, const float* in, const float* w, const float* bias, int relu, float* out, int B, int I, int O, int H, int W,
-                      long so, long si, int flip, void* stream)
+// io: bit 0 = `in` is bf16, bit 1 = `out` is bf16 (as in ipsr_conv3x3_winograd_mp); 0 = the fp32 kernels of round 2.
+int ipsr_conv3x3_thin_io(int op, const void* in, const float* w, const float* bias, int relu, void* out, int B, int I, int O, int H, int W,
+                         long so, long si, int flip, int io, void* stream)
 {
     if (!in || !w || !out) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: null pointer");
-    if (B < 1 || I < 1 || O < 1 || H < 1 || W < 1) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: bad argument");
+    if (B < 1 || I < 1 || O < 1 || H < 1 || W < 1 || (io & ~3)) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool ib = io & 1, ob = io & 2;
     if (op == 0) {          // few -> many
         if (O % THIN_OC != 0 || (I != 3 && I != 6)) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: few->many needs 3 or 6 inputs and outputs %% 16 == 0 (got %d -> %d)", I, O);
         if ((size_t)B * (O / THIN_OC) > 65535 || H > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: grid too large");
-        if ((W & 1) || (reinterpret_cast<uintptr_t>(out) & 7u)) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: few->many needs an even width and an 8-byte aligned output (W=%d)", W);
+        if ((W & 1) || (reinterpret_cast<uintptr_t>(out) & (ob ? 3u : 7u))) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: few->many needs an even width and an aligned output (W=%d)", W);
         const dim3 grid(cdiv(W, 512), H, B * (O / THIN_OC));
-        if (I == 3) thin_f2m_kernel<3><<<grid, 256, 0, st>>>(in, w, bias, relu, out, B, O, H, W, so, si, flip);
-        else thin_f2m_kernel<6><<<grid, 256, 0, st>>>(in, w, bias, relu, out, B, O, H, W, so, si, flip);
+#define THIN_F2M(II, TI, TO) thin_f2m_kernel<II, TI, TO><<<grid, 256, 0, st>>>(static_cast<const TI*>(in), w, bias, relu, static_cast<TO*>(out), B, O, H, W, so, si, flip)
+#define THIN_F2M_IO(II) do { if (ib && ob) THIN_F2M(II, bf16_t, bf16_t); else if (ib) THIN_F2M(II, bf16_t, float); else if (ob) THIN_F2M(II, float, bf16_t); else THIN_F2M(II, float, float); } while (0)
+        if (I == 3) THIN_F2M_IO(3); else THIN_F2M_IO(6);
+#undef THIN_F2M_IO
+#undef THIN_F2M
         return check_launch("thin_f2m_kernel");
     }
     if (op == 1) {          // many -> few
         if (bias || relu) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: many->few has no epilogue");
         if ((O != 3 && O != 6) || W % 4 != 0) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: many->few needs 3 or 6 outputs and W %% 4 == 0 (got %d -> %d, W=%d)", I, O, W);
-        if ((reinterpret_cast<uintptr_t>(in) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: tensors must be 16-byte aligned");
+        if ((reinterpret_cast<uintptr_t>(in) & (ib ? 7u : 15u)) || (reinterpret_cast<uintptr_t>(out) & (ob ? 7u : 15u)))
+            return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: tensors must be aligned to four elements");
         const size_t lds = (size_t)I * O * 9 * sizeof(float);
         if (lds > 48 * 1024) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin: %d input channels exceed the LDS weight buffer", I);
         const dim3 grid(cdiv(W, 256), cdiv(H, 4), B);
-        if (O == 3) thin_m2f_kernel<3><<<grid, 256, lds, st>>>(in, w, out, B, I, H, W, so, si, flip);
-        else thin_m2f_kernel<6><<<grid, 256, lds, st>>>(in, w, out, B, I, H, W, so, si, flip);
+#define THIN_M2F(OO, TI, TO) thin_m2f_kernel<OO, TI, TO><<<grid, 256, lds, st>>>(static_cast<const TI*>(in), w, static_cast<TO*>(out), B, I, H, W, so, si, flip)
+#define THIN_M2F_IO(OO) do { if (ib && ob) THIN_M2F(OO, bf16_t, bf16_t); else if (ib) THIN_M2F(OO, bf16_t, float); else if (ob) THIN_M2F(OO, float, bf16_t); else THIN_M2F(OO, float, float); } while (0)
+        if (O == 3) THIN_M2F_IO(3); else THIN_M2F_IO(6);
+#undef THIN_M2F_IO
+#undef THIN_M2F
         return check_launch("thin_m2f_kernel");
     }
     return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin: op %d", op);
+}
+
+int ipsr_conv3x3_thin(int op, const float* in, const float* w, const float* bias, int relu, float* out, int B, int I, int O, int H, int W,
+                      long so, long si, int flip, void* stream)
+{
+    return ipsr_conv3x3_thin_io(op, in, w, bias, relu, out, B, I, O, H, W, so, si, flip, 0, stream);
 }
 
 size_t ipsr_conv3x3_thin_wrw_workspace_bytes(int B, int Cb, int Cs, int H, int W)
@@ -394,23 +434,33 @@ size_t ipsr_conv3x3_thin_wrw_workspace_bytes(int B, int Cb, int Cs, int H, int W
     return align_up(nblk * THIN_CB * Cs * 9 * sizeof(float), 256) + 256;
 }
 
-int ipsr_conv3x3_thin_wrw(const float* big, const float* small, float* g, int B, int Cb, int Cs, int H, int W, void* ws, size_t ws_bytes, void* stream)
+// io: bit 0 = `big` is bf16, bit 1 = `small` is bf16; the gradient is fp32 either way.
+int ipsr_conv3x3_thin_wrw_io(const void* big, const void* small, float* g, int B, int Cb, int Cs, int H, int W, int io, void* ws, size_t ws_bytes, void* stream)
 {
-    if (!big || !small || !g || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin_wrw: null pointer");
+    if (!big || !small || !g || !ws || (io & ~3)) return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin_wrw: null pointer / bad io code");
     const size_t need = ipsr_conv3x3_thin_wrw_workspace_bytes(B, Cb, Cs, H, W);
     if (need == 0) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin_wrw: Cb=%d Cs=%d %dx%d is not implemented", Cb, Cs, H, W);
     if (ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "ipsr_conv3x3_thin_wrw: workspace %zu < %zu", ws_bytes, need);
-    if ((reinterpret_cast<uintptr_t>(big) & 15u) || (reinterpret_cast<uintptr_t>(small) & 15u) || (reinterpret_cast<uintptr_t>(ws) & 15u))
-        return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin_wrw: tensors / workspace must be 16-byte aligned");
+    const bool bb = io & 1, sb = io & 2;
+    if ((reinterpret_cast<uintptr_t>(big) & (bb ? 7u : 15u)) || (reinterpret_cast<uintptr_t>(small) & (sb ? 7u : 15u)) || (reinterpret_cast<uintptr_t>(ws) & 15u))
+        return fail(IPSR_ERR_INVALID, "ipsr_conv3x3_thin_wrw: tensors must be aligned to four elements, the workspace to 16 bytes");
     if ((size_t)B * (Cb / THIN_CB) > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv3x3_thin_wrw: grid too large");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
     const dim3 grid(cdiv(W, 256), cdiv(H, THIN_ROWS), B * (Cb / THIN_CB));
-    if (Cs == 3) thin_wrw_kernel<3><<<grid, 256, 0, st>>>(big, small, part, B, Cb, H, W);
-    else thin_wrw_kernel<6><<<grid, 256, 0, st>>>(big, small, part, B, Cb, H, W);
+#define THIN_WRW(CC, TBG, TSM) thin_wrw_kernel<CC, TBG, TSM><<<grid, 256, 0, st>>>(static_cast<const TBG*>(big), static_cast<const TSM*>(small), part, B, Cb, H, W)
+#define THIN_WRW_IO(CC) do { if (bb && sb) THIN_WRW(CC, bf16_t, bf16_t); else if (bb) THIN_WRW(CC, bf16_t, float); else if (sb) THIN_WRW(CC, float, bf16_t); else THIN_WRW(CC, float, float); } while (0)
+    if (Cs == 3) THIN_WRW_IO(3); else THIN_WRW_IO(6);
+#undef THIN_WRW_IO
+#undef THIN_WRW
     if (int rc = check_launch("thin_wrw_kernel")) return rc;
     thin_wrw_reduce_kernel<<<cdiv(Cb * Cs * 9, 256), 256, 0, st>>>(part, g, B, Cb, Cs, (int)(grid.x * grid.y));
     return check_launch("thin_wrw_reduce_kernel");
+}
+
+int ipsr_conv3x3_thin_wrw(const float* big, const float* small, float* g, int B, int Cb, int Cs, int H, int W, void* ws, size_t ws_bytes, void* stream)
+{
+    return ipsr_conv3x3_thin_wrw_io(big, small, g, B, Cb, Cs, H, W, 0, ws, ws_bytes, stream);
 }
 
 size_t ipsr_conv_to_one_workspace_bytes(int B, int C, int H, int W, int K, int pad)

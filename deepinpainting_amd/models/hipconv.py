@@ -82,6 +82,8 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
         return eng
     if _bf16_wins(eng, Cin, H, W, Cout) or eng in _CAST_ENGINES:
         return eng
+    if _mode() == "auto" and _thin_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil, True):
+        return "thin"            # the vector-ALU stream kernels read / write bf16 tensors themselves (ipsr_conv3x3_thin_io)
     return _bf16_direct(os.environ.get("IPSR_BF16_ENGINES", ""), _mode(), op, B, Cin, H, W, Cout, k, stride, pad, dil)
 
 
@@ -209,17 +211,21 @@ def _smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
     return B, Cout, Cin, Hy, Wy, H, W, k, stride, pad, dil
 
 
-def _thin_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
+def _thin_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     """3x3 stride-1 layers with a 3- or 6-channel side on maps of >= 64x64 (profiles/r02_thin.txt, device time at 256x256, batch 8):
     many -> few (VGG conv1_1 input gradient 185 -> 61 us, netG's last ConvTranspose2d forward 217 -> 130 us) and 3 -> many
     (VGG conv1_1 forward 70 -> 52 us, and the bias + ReLU pass goes into the kernel); 6 -> 64 forward and the weight gradients
-    stay on MIOpen (87 vs 99 us; 134 vs 296 us)."""
+    stay on MIOpen (87 vs 99 us; 134 vs 296 us).  bf16 activations (batch 16, profiles/r04_thin_bf16.txt): 3 -> many wins by 2x and
+    1.5x (VGG conv1_1 forward 90 vs 182 us, bias + ReLU included; the last ConvTranspose2d's input gradient 172 vs 261 us); 6 -> 64 stays
+    on MIOpen (175 vs 156 us) and many -> 3 on the direct MFMA kernel (252 vs 300 us)."""
     if os.environ.get("IPSR_NO_THIN", "0") == "1":           # A/B switch
         return False
     if not (k == 3 and stride == 1 and pad == 1 and dil == 1) or H * W < 4096 or not ops.thin_supported(op, Cin, H, W, Cout):
         return False
     fwd = op in (ops.CONV_FWD, ops.CONVT_FWD)
     i, o = (Cin, Cout) if fwd else (Cout, Cin)
+    if bf16:
+        return i == 3
     return o in (3, 6) or i == 3
 
 
@@ -342,7 +348,7 @@ class _HipConv(torch.autograd.Function):
         elif eng_fwd == "wino_dil":
             y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=act)
         elif eng_fwd == "thin":
-            y = ops.conv3x3_thin(op, xc, w, (B, Cin, H, W), Cout)
+            y = ops.conv3x3_thin(op, xc, w, (B, Cin, H, W), Cout, out_dtype=act)
         elif eng_fwd == "one":
             y = ops.conv_to_one(xc.float(), w, pad).to(act)
         elif eng_fwd == "smallmap":
@@ -380,7 +386,7 @@ class _HipConv(torch.autograd.Function):
             elif eng == "wino_dil":
                 dx = ops.conv4x4_dilated_winograd(1, dy, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=x.dtype)
             elif eng == "thin":
-                dx = ops.conv3x3_thin(op, dy, w, (B, Cin, H, W), Cout)
+                dx = ops.conv3x3_thin(op, dy, w, (B, Cin, H, W), Cout, out_dtype=x.dtype)
             elif eng == "smallmap":
                 dx = ops.conv_smallmap(_smallmap_op(op), dy.float(), w, *_smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)).to(x.dtype)
             elif eng == "wino_s2":
@@ -486,7 +492,7 @@ def conv_nobias(m, x, weight=None):
             return ops.conv4x4_dilated_winograd(0, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil),
                                                 math=math, out_dtype=act)
         elif eng == "thin":
-            return ops.conv3x3_thin(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout)
+            return ops.conv3x3_thin(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, out_dtype=act)
         elif eng == "one":
             return ops.conv_to_one(x.contiguous().float(), w.detach(), pad).to(act)
         elif eng == "smallmap":

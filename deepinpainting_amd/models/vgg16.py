@@ -111,9 +111,10 @@ class Vgg16(torch.nn.Module):
                                              math=math, out_dtype=torch.bfloat16 if bf16 else torch.float32)
                     i += 3 if pool else 2
                     continue
-                if x.dtype == torch.float32 and not torch.is_autocast_enabled() and not pool and \
-                        hipconv.select(ops.CONV_FWD, B, Cin, H, W, m.out_channels, 3, 1, 1, 1) == "thin":
-                    x = ops.conv3x3_thin(ops.CONV_FWD, x.contiguous(), m.weight, (B, Cin, H, W), m.out_channels, bias=m.bias, relu=True)   # conv1_1
+                if (bf16 or (x.dtype == torch.float32 and not torch.is_autocast_enabled())) and not pool and \
+                        hipconv.select(ops.CONV_FWD, B, Cin, H, W, m.out_channels, 3, 1, 1, 1, bf16) == "thin":
+                    x = ops.conv3x3_thin(ops.CONV_FWD, x.contiguous(), m.weight, (B, Cin, H, W), m.out_channels, bias=m.bias, relu=True,
+                                         out_dtype=torch.bfloat16 if bf16 else torch.float32)                                        # conv1_1
                     i += 2
                     continue
                 y = hipconv.conv_nobias(m, x)

@@ -813,12 +813,15 @@ def conv_to_one_wrw(x, dy, K, pad, out=None):
     return dw
 
 
-def conv3x3_thin(op, inp, weight, in_shape, Cout, bias=None, relu=False, out=None):
-    """k3 s1 p1 Conv2d / ConvTranspose2d forward or backward-data with a 3- or 6-channel side (ipsr_conv3x3_thin).  `in_shape` =
-    the module's input (B, Cin, H, W); `inp` is x for the forward ops and dy for the backward-data ops; bias / ReLU only few -> many."""
+def conv3x3_thin(op, inp, weight, in_shape, Cout, bias=None, relu=False, out=None, out_dtype=None):
+    """k3 s1 p1 Conv2d / ConvTranspose2d forward or backward-data with a 3- or 6-channel side (ipsr_conv3x3_thin_io).  `in_shape` =
+    the module's input (B, Cin, H, W); `inp` is x for the forward ops and dy for the backward-data ops; bias / ReLU only few -> many.
+    fp32 or bf16 activation tensors on either side (`out_dtype`, default = the input's); with a bf16 side the arithmetic is autocast's
+    (bf16 operands, fp32 accumulation)."""
     B, Cin, H, W = in_shape
-    inp = _req(inp, torch.float32, "input")
+    inp, _ = _act(inp, "input")
     weight = _req(weight, torch.float32, "weight")
+    out_dtype = out_dtype or (out.dtype if out is not None else inp.dtype)
     fwd = op in (CONV_FWD, CONVT_FWD)
     I, O = (Cin, Cout) if fwd else (Cout, Cin)
     if tuple(inp.shape) != (B, I, H, W):
@@ -829,20 +832,22 @@ def conv3x3_thin(op, inp, weight, in_shape, Cout, bias=None, relu=False, out=Non
     if not thin_supported(op, Cin, H, W, Cout):
         raise NotImplementedError("conv3x3_thin op %d: Cin=%d Cout=%d %dx%d is not a thin-layer shape" % (op, Cin, Cout, H, W))
     so, si, flip = {CONV_FWD: (Cin * 9, 9, 0), CONV_BWD_DATA: (9, Cin * 9, 1), CONVT_FWD: (9, Cout * 9, 1), CONVT_BWD_DATA: (Cout * 9, 9, 0)}[op]
+    io = _io_code(inp.dtype == torch.bfloat16, out_dtype)
     if out is None:
-        out = torch.empty((B, O, H, W), dtype=torch.float32, device=inp.device)
-    elif tuple(out.shape) != (B, O, H, W) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != inp.device:
-        raise RuntimeError("conv3x3_thin: `out` must be a contiguous fp32 %s tensor on %s" % ((B, O, H, W), inp.device))
+        out = torch.empty((B, O, H, W), dtype=out_dtype, device=inp.device)
+    elif tuple(out.shape) != (B, O, H, W) or out.dtype != out_dtype or not out.is_contiguous() or out.device != inp.device:
+        raise RuntimeError("conv3x3_thin: `out` must be a contiguous %s %s tensor on %s" % (out_dtype, (B, O, H, W), inp.device))
     few2many = I in (3, 6) and O % 16 == 0
-    _lib.check(_lib.lib().ipsr_conv3x3_thin(0 if few2many else 1, inp.data_ptr(), weight.data_ptr(), _ptr(_f32(bias)) if bias is not None else None,
-                                            int(bool(relu)), out.data_ptr(), B, I, O, H, W, so, si, flip, _stream()), "ipsr_conv3x3_thin")
+    _lib.check(_lib.lib().ipsr_conv3x3_thin_io(0 if few2many else 1, inp.data_ptr(), weight.data_ptr(), _ptr(_f32(bias)) if bias is not None else None,
+                                               int(bool(relu)), out.data_ptr(), B, I, O, H, W, so, si, flip, io, _stream()), "ipsr_conv3x3_thin_io")
     return out
 
 
 def conv3x3_thin_wrw(transposed, x, dy, out=None):
-    """Weight gradient of a k3 s1 p1 Conv2d ([Cout,Cin,3,3]) / ConvTranspose2d ([Cin,Cout,3,3]) with a 3- or 6-channel side."""
-    x = _req(x, torch.float32, "x")
-    dy = _req(dy, torch.float32, "dy")
+    """Weight gradient (fp32) of a k3 s1 p1 Conv2d ([Cout,Cin,3,3]) / ConvTranspose2d ([Cin,Cout,3,3]) with a 3- or 6-channel side; x and dy
+    each fp32 or bf16."""
+    x, _ = _act(x, "x")
+    dy, _ = _act(dy, "dy")
     B, Cin, H, W = x.shape
     Cout = dy.shape[1]
     wshape = (Cin, Cout, 3, 3) if transposed else (Cout, Cin, 3, 3)
@@ -855,8 +860,9 @@ def conv3x3_thin_wrw(transposed, x, dy, out=None):
         if nbytes == 0:
             raise NotImplementedError("ipsr_conv3x3_thin_wrw: Cb=%d Cs=%d %dx%d is not implemented" % (Cb, Cs, H, W))
         ws = _workspace(nbytes, x.device)
-        _lib.check(L.ipsr_conv3x3_thin_wrw(big.data_ptr(), small.data_ptr(), g.data_ptr(), B, Cb, Cs, H, W, ws.data_ptr(), ws.numel(), _stream()),
-                   "ipsr_conv3x3_thin_wrw")
+        io = int(big.dtype == torch.bfloat16) | (2 if small.dtype == torch.bfloat16 else 0)
+        _lib.check(L.ipsr_conv3x3_thin_wrw_io(big.data_ptr(), small.data_ptr(), g.data_ptr(), B, Cb, Cs, H, W, io, ws.data_ptr(), ws.numel(), _stream()),
+                   "ipsr_conv3x3_thin_wrw_io")
         return g
     raise NotImplementedError("conv3x3_thin_wrw: the weight's first channel dimension must be the wide one (got %s)" % (wshape,))
 

@@ -131,11 +131,20 @@ class StepGraph(object):
         module text) records first."""
         if self._key != self._state_key(img, mask, ref):
             self._record(img, mask, ref)
-        self._img.copy_(img, non_blocking=True)
-        self._ref.copy_(ref, non_blocking=True)
-        if self.capture:
-            self.graph.replay()
-        else:
+        if not self.capture:
+            self._img.copy_(img, non_blocking=True)
+            self._ref.copy_(ref, non_blocking=True)
             self._eager(mask)
+            return
+        # The replay runs on the stream it was recorded on, fenced by events on both sides: a hipGraphLaunch queued on the default stream was
+        # not always ordered against the work queued after it there (the next replay's input copies, a host read of the losses), and two
+        # overlapping replays of one recording share every intermediate buffer.
+        cur = torch.cuda.current_stream(self.model.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._img.copy_(img, non_blocking=True)
+            self._ref.copy_(ref, non_blocking=True)
+            self.graph.replay()
+        cur.wait_stream(self.stream)
 
     __call__ = step

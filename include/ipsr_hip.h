@@ -329,6 +329,14 @@ int ipsr_conv_smallmap(int op, const float* a, const float* b, float* out, int B
 int ipsr_conv3x3_thin(int op, const float* in, const float* w, const float* bias, int relu, float* out, int B, int I, int O, int H, int W,
                       long so, long si, int flip, void* stream);
 size_t ipsr_conv3x3_thin_wrw_workspace_bytes(int B, int Cb, int Cs, int H, int W);
+/* The same kernels on bf16 activation tensors (BASELINE config 5, the modules under torch.autocast(bfloat16)).  `io`: bit 0 = the first
+ * tensor is bf16, bit 1 = the second (_io: in / out; _wrw_io: big / small); 0 = the fp32 entry points above.  With a bf16 side the
+ * arithmetic is autocast's: weights and an fp32 operand are rounded to bf16 on the way in, products accumulate in fp32, bias / ReLU in
+ * fp32, one rounding on the way out; the weight gradient stays fp32.  Alignment: four elements (few -> many output: two). */
+int ipsr_conv3x3_thin_io(int op, const void* in, const float* w, const float* bias, int relu, void* out, int B, int I, int O, int H, int W,
+                         long so, long si, int flip, int io, void* stream);
+int ipsr_conv3x3_thin_wrw_io(const void* big, const void* small, float* g, int B, int Cb, int Cs, int H, int W, int io,
+                             void* ws, size_t ws_bytes, void* stream);
 /* ipsr_conv_to_one: nn.Conv2d(C, 1, K, stride 1, padding pad) — netD's last layer (models/networks.py:489-495, 512 -> 1, k4 p1 on
  * 31x31) — as one pass over the input (252 MFLOP against 31.5 MB: a stream).  x [B,C,H,W] fp32, K in {3, 4}.
  *   op 0 forward:          other = w [1,C,K,K],    out = y [B,1,Ho,Wo],  Ho = H + 2 pad - K + 1

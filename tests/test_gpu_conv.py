@@ -298,6 +298,43 @@ def test_thin_3x3_layers_vs_fp64(kind, Ci, Co, H, W, B):
         assert tuple(dw.shape) == tuple(w.shape) and _rel(dw, dw64) <= 2e-5
 
 
+@pytest.mark.parametrize("kind,Ci,Co,H,W,B", [("conv", 3, 64, 32, 48, 2), ("conv", 6, 64, 20, 36, 3), ("convT", 128, 3, 24, 32, 2), ("convT", 64, 3, 64, 256, 1)])
+@pytest.mark.parametrize("in_bf16,out_bf16", [(True, True), (False, True), (True, False)])
+def test_thin_3x3_layers_on_bf16_tensors(kind, Ci, Co, H, W, B, in_bf16, out_bf16):
+    """ipsr_conv3x3_thin_io / _wrw_io with bf16 tensors on either side (BASELINE config 5): the arithmetic is autocast's — operands
+    rounded to bf16 (weights and an fp32 input on the way in), fp32 accumulation, ONE rounding on the way out.  Against an fp64
+    convolution of the rounded operands: fp32 results within 2e-5, bf16 results within half a bf16 ulp of the result's scale (2^-8)
+    plus that."""
+    from deepinpainting_amd import ops
+    g = torch.Generator().manual_seed(Ci * 13 + H)
+    tr = kind == "convT"
+    bf = torch.bfloat16
+    x = torch.randn(B, Ci, H, W, generator=g).cuda()
+    w = (torch.randn((Ci, Co, 3, 3) if tr else (Co, Ci, 3, 3), generator=g) * 0.1).cuda()
+    bias = torch.randn(Co, generator=g).cuda()
+    xin = x.to(bf) if in_bf16 else x
+    xd, wd = x.to(bf).double().cpu().requires_grad_(True), w.to(bf).double().cpu().requires_grad_(True)
+    y64 = F.conv_transpose2d(xd, wd, None, 1, 1) if tr else F.conv2d(xd, wd, None, 1, 1)
+    dy = torch.randn(y64.shape, generator=g).cuda()
+    dyin = dy.to(bf) if in_bf16 else dy
+    dx64, dw64 = torch.autograd.grad(y64, (xd, wd), dy.to(bf).double().cpu())
+    tol = 2e-5 + (2.0 ** -8 if out_bf16 else 0.0)
+    odt = bf if out_bf16 else torch.float32
+    fop, bop = (ops.CONVT_FWD, ops.CONVT_BWD_DATA) if tr else (ops.CONV_FWD, ops.CONV_BWD_DATA)
+    y = ops.conv3x3_thin(fop, xin, w, (B, Ci, H, W), Co, out_dtype=odt)
+    assert y.dtype == odt and _rel(y.float(), y64.detach()) <= tol
+    if not tr:
+        yb = ops.conv3x3_thin(fop, xin, w, (B, Ci, H, W), Co, bias=bias, relu=True, out_dtype=odt)
+        assert _rel(yb.float(), torch.relu(y64.detach() + bias.double().cpu().view(1, -1, 1, 1))) <= tol
+    dx = ops.conv3x3_thin(bop, dyin, w, (B, Ci, H, W), Co, out_dtype=odt)
+    assert dx.dtype == odt and _rel(dx.float(), dx64) <= tol
+    # weight gradient: fp32 result; operands (x, dy) = (first flag, second flag) bf16 or fp32-rounded-inside
+    dw = ops.conv3x3_thin_wrw(tr, xin, dy.to(bf) if out_bf16 else dy)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == tuple(w.shape)
+    if in_bf16 or out_bf16:                       # with both operands fp32 the kernel is the fp32 one (no rounding): covered above
+        assert _rel(dw, dw64) <= 2e-5
+
+
 # ---- the training step's OWN shapes (BASELINE config 2: batch 8, 256x256) ------------------------------------------------------
 # (module, input H=W): the layers the step spends its time in, every Winograd family, all three passes.  References: the same
 # module in fp64 on the GPU (torch's native convolution) AND MIOpen fp32 on the same tensors.

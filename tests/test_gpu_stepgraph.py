@@ -84,6 +84,34 @@ def test_replayed_steps_equal_eager_steps_bit_for_bit(tmp_path, deterministic_mi
         assert torch.equal(got[other][2], got["eager"][2]), other
 
 
+def test_queued_replays_do_not_overlap(tmp_path, deterministic_miopen):
+    """Twelve steps queued back to back with no host read in between (bench.py's timed loop): the replays must execute one after the
+    other — they share every intermediate buffer.  (Launched on the default stream they did not always: losses read as leftovers of
+    other tensors, then NaN weights; StepGraph.step fences the replay on its own stream.)  Same weights as twelve eager steps."""
+    from deepinpainting_amd.stepgraph import StepGraph
+    mask = torch.zeros(1, 1, 256, 256, dtype=torch.bool, device="cuda")
+    mask[:, :, 64:192, 64:192] = 1
+    got = {}
+    for mode in ("eager", "graph"):
+        m = _model(tmp_path / mode, True)
+        torch.cuda.manual_seed(99)
+        img, ref = _data(0)
+        for _ in range(2):                               # eager steps on the default stream first, as bench.py's warm-up
+            m.set_input(img, mask, ref); m.set_ref_latent(); m.set_gt_latent(); m.optimize_parameters()
+        sg = StepGraph(m) if mode == "graph" else None
+        for i in range(12):
+            if sg is None:
+                m.set_input(img, mask, ref); m.set_ref_latent(); m.set_gt_latent(); m.optimize_parameters()
+            else:
+                sg.step(img, mask, ref)
+        e = m.get_current_errors()
+        got[mode] = ([e[k] for k in ("G_GAN", "G_L1", "D", "F")], _weights(m))
+        del m, sg
+        torch.cuda.empty_cache()
+    assert np.isfinite(got["graph"][0]).all() and got["graph"][0] == got["eager"][0]
+    assert torch.equal(got["graph"][1], got["eager"][1])
+
+
 def test_recording_trains_nothing_and_follows_the_learning_rate(tmp_path, deterministic_miopen):
     """`_record` runs warm-up steps and undoes them: weights, Adam moments and step counts are what they were.  A learning-rate change
     (the reference's per-epoch scheduler, models/base_model.py update_learning_rate) and a new mask tensor each record again; the

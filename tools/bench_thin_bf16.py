@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""The 3x3 layers with a 3- or 6-channel side on bf16 activations (BASELINE config 5, batch 16): the vector-ALU stream kernels
+(csrc/thin_conv.hip, ipsr_conv3x3_thin_io) against MIOpen under autocast (NHWC transposes and weight casts included) and, where it
+applies, the direct bf16 MFMA kernel.  Prints ms per call (HIP events over `--iters` back-to-back calls) and the error against an
+fp64 convolution of the bf16-rounded operands.
+
+    python tools/bench_thin_bf16.py > profiles/r04_thin_bf16.txt
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepinpainting_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=30)
+    a = ap.parse_args()
+    B, S = a.batch, 256
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(3)
+    cases = [  # name, transposed, Cin, Cout, input dtype, passes
+        ("VGG conv1_1   conv  3 -> 64 (+bias, ReLU)", False, 3, 64, torch.float32, ("fwd",)),
+        ("netG first    conv  6 -> 64", False, 6, 64, torch.float32, ("fwd",)),
+        ("netG last     convT 128 -> 3", True, 128, 3, torch.bfloat16, ("fwd", "bwd")),
+    ]
+    print("layer (batch %d, 256x256)                     | pass | thin bf16 ms | MIOpen autocast ms | direct MFMA ms | max err / max |ref|" % B)
+    for name, tr, Cin, Cout, xdt, passes in cases:
+        w = (torch.randn((Cin, Cout, 3, 3) if tr else (Cout, Cin, 3, 3), device=dev, generator=g) * 0.1)
+        bias = torch.randn(Cout, device=dev, generator=g) * 0.1
+        x = (torch.rand(B, Cin, S, S, device=dev, generator=g) * 2 - 1).to(xdt)
+        dy = (torch.rand(B, Cout, S, S, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        wr = w.to(torch.bfloat16).double()
+        for ps in passes:
+            fused = name.startswith("VGG")
+            if ps == "fwd":
+                op = ops.CONVT_FWD if tr else ops.CONV_FWD
+                inp = x
+
+                def thin():
+                    return ops.conv3x3_thin(op, inp, w, (B, Cin, S, S), Cout, bias=bias if fused else None, relu=fused, out_dtype=torch.bfloat16)
+
+                def miopen():
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        y = F.conv_transpose2d(inp, w, None, 1, 1) if tr else F.conv2d(inp, w, None, 1, 1)
+                    if fused:
+                        y = ops.bias_act_(y, bias, "relu")
+                    return y
+                xr = inp.to(torch.bfloat16).double()[:2]
+                ref = F.conv_transpose2d(xr, wr, None, 1, 1) if tr else F.conv2d(xr, wr, None, 1, 1)
+                if fused:
+                    ref = torch.relu(ref + bias.double()[None, :, None, None])
+            else:
+                op = ops.CONVT_BWD_DATA if tr else ops.CONV_BWD_DATA
+                inp = dy
+
+                def thin():
+                    return ops.conv3x3_thin(op, inp, w, (B, Cin, S, S), Cout, out_dtype=torch.bfloat16)
+                wb = w.to(torch.bfloat16)
+                xb = x.to(torch.bfloat16)
+
+                def miopen():
+                    return torch.ops.aten.convolution_backward(inp, xb, wb, None, [1, 1], [1, 1], [1, 1], tr, [0, 0], 1, [True, False, False])[0]
+                dr = inp.double()[:2]
+                ref = F.conv2d(dr, wr, None, 1, 1) if tr else F.conv_transpose2d(dr, wr, None, 1, 1)
+            t_thin = timeit(thin, a.iters)
+            t_mi = timeit(miopen, a.iters)
+            t_dir = None
+            if not fused and ops.conv3x3_bf16_supported(op, B, Cin, S, S, Cout):
+                xin = inp.to(torch.bfloat16)
+                t_dir = timeit(lambda: ops.conv3x3_bf16(op, xin, w, (B, Cin, S, S), Cout), a.iters)
+            got = thin()[:2].double()
+            err = float((got - ref).abs().max() / ref.abs().max())
+            print("%-45s | %-4s | %12.4f | %18.4f | %14s | %.2e" % (name, ps, t_thin, t_mi, "%.4f" % t_dir if t_dir else "-", err), flush=True)
+
+
+if __name__ == "__main__":
+    main()
