@@ -240,16 +240,33 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
         const unsigned char* A = lds + cur * g.a_bytes + a_off;
         const unsigned char* T = lds + t_base + cur * g.t_bytes;
         const int* toff = g.tapoff[MODE == CB_F2C ? (s & 1) : (MODE == CB_C2F ? phase : 0)];
+        // software pipeline over the taps: the fragments of tap t + 1 are read while tap t multiplies (two register sets); the
+        // sched_group_barriers pin that order — left alone the compiler issues a tap's reads right before its own multiplications and
+        // every tap waits out the LDS latency (s_waitcnt lgkmcnt(0) in front of 4 MFMAs)
+        bf16x8 fa[2][2], fb[2][NJ];
+        auto load_tap = [&](int t, int set) {
+            fa[set][0] = *reinterpret_cast<const bf16x8*>(A + (t * 2 * KT) * 16);
+            fa[set][1] = *reinterpret_cast<const bf16x8*>(A + (t * 2 * KT + 32) * 16);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(T + b_off[j] + toff[t] * 16);
+        };
+        load_tap(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);                              // tap 0's reads: the pipeline's fill
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
-            const int q = t / TPSET;
-            const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + (t * 2 * KT) * 16);
-            const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + (t * 2 * KT + 32) * 16);
+            const int q = t / TPSET, set = t & 1;
+            if (t + 1 < NTAP) load_tap(t + 1, set ^ 1);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(T + b_off[j] + toff[t] * 16);
-                acc[q][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[q][0][j], 0, 0, 0);
-                acc[q][1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[q][1][j], 0, 0, 0);
+                acc[q][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][0], fb[set][j], acc[q][0][j], 0, 0, 0);
+                acc[q][1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][1], fb[set][j], acc[q][1][j], 0, 0, 0);
+            }
+            if (t + 1 < NTAP) {
+                // (with an LDS-DMA in flight hipcc only ever waits lgkmcnt(0), never a counted value: the reads must all be OLD when the next
+                // tap's first multiplication asks for them, so they go right behind this tap's first one, not one per multiplication)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           // this tap's first MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);                      // the next tap's reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 1, 0);                  // the rest of this tap
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this stage's DMAs are the next stage's operands

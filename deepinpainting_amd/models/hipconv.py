@@ -69,22 +69,51 @@ def _amp_bf16():
 _check_hook = None     # test hook: callable(kind, engine, geometry, operands, result) after every engine call of _HipConv
 
 
+# The A/B switches (IPSR_CONV_ENGINE, IPSR_NO_SMALLMAP, IPSR_NO_THIN, IPSR_BF16_ENGINES) are read from the environment ONCE, at first use:
+# a training step asks `select` ~250 times, and each os.environ.get costs ~0.8 us of a host that is the step's bound under bf16
+# (tools/profile_host.py: 2000 look-ups, 1.6 ms per step).  `reload_env()` re-reads them (a tool that flips one in-process).
+_ENV = {}
+_SEL = {}
+
+
+def _env(name, default):
+    v = _ENV.get(name)
+    if v is None:
+        v = _ENV[name] = os.environ.get(name, default)
+    return v
+
+
+def reload_env():
+    _ENV.clear()
+    _SEL.clear()
+    for f in (_select, _select_wrw, _bf16_direct, _bf16_direct_wrw):
+        f.cache_clear()
+
+
 def _mode():
-    return _FORCE or os.environ.get("IPSR_CONV_ENGINE", "auto")
+    return _FORCE or _env("IPSR_CONV_ENGINE", "auto")
 
 
 def select(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     """-> the engine for one convolution call.  (Cin, H, W) = the module's input, as in ipsr_conv2d.  Memoised per (mode, shape):
     the rules query the library (workspace probes), ~150 convolution calls per training step ask.
     bf16: the activations are bf16 tensors — only the Winograd engines read / write those; every other shape takes MIOpen."""
-    eng = _select(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0") + os.environ.get("IPSR_NO_THIN", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
+    key = (0, _FORCE, op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16)
+    eng = _SEL.get(key)
+    if eng is None:
+        eng = _SEL[key] = _select_any(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16)
+    return eng
+
+
+def _select_any(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16):
+    eng = _select(_mode(), _env("IPSR_NO_SMALLMAP", "0") + _env("IPSR_NO_THIN", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
     if not bf16:
         return eng
     if _bf16_wins(eng, Cin, H, W, Cout) or eng in _CAST_ENGINES:
         return eng
     if _mode() == "auto" and _thin_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil, True):
         return "thin"            # the vector-ALU stream kernels read / write bf16 tensors themselves (ipsr_conv3x3_thin_io)
-    return _bf16_direct(os.environ.get("IPSR_BF16_ENGINES", ""), _mode(), op, B, Cin, H, W, Cout, k, stride, pad, dil)
+    return _bf16_direct(_env("IPSR_BF16_ENGINES", ""), _mode(), op, B, Cin, H, W, Cout, k, stride, pad, dil)
 
 
 @functools.lru_cache(maxsize=4096)
@@ -118,7 +147,7 @@ def _bf16_wins(eng, Cin, H, W, Cout, wrw=False):
     <= 32x32 (0.72-0.79x), the dilated 4x4 layers with >= 256 channels at <= 64x64 (0.70-0.90x), netD's 4x4 stride-1 layer (0.95x);
     they lose on larger maps and on the whole 4x4 stride-2 family (1.1-1.7x) — those stay on MIOpen.  IPSR_BF16_ENGINES=all|none
     overrides (A/B timing)."""
-    force = os.environ.get("IPSR_BF16_ENGINES", "")
+    force = _env("IPSR_BF16_ENGINES", "")
     if eng not in _BF16_ENGINES or force == "none":
         return False
     if force == "all":
@@ -218,7 +247,7 @@ def _thin_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     stay on MIOpen (87 vs 99 us; 134 vs 296 us).  bf16 activations (batch 16, profiles/r04_thin_bf16.txt): 3 -> many wins by 2x and
     1.5x (VGG conv1_1 forward 90 vs 182 us, bias + ReLU included; the last ConvTranspose2d's input gradient 172 vs 261 us); 6 -> 64 stays
     on MIOpen (175 vs 156 us) and many -> 3 on the direct MFMA kernel (252 vs 300 us)."""
-    if os.environ.get("IPSR_NO_THIN", "0") == "1":           # A/B switch
+    if _env("IPSR_NO_THIN", "0") == "1":           # A/B switch
         return False
     if not (k == 3 and stride == 1 and pad == 1 and dil == 1) or H * W < 4096 or not ops.thin_supported(op, Cin, H, W, Cout):
         return False
@@ -237,7 +266,7 @@ def _smallmap_op(op):
 def _smallmap_data_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
     """Forward / input gradient on grids of <= 32 positions per batch (2x2 and 1x1 at batch 8): 15-20 us on the device against
     MIOpen's 40-50 (profiles/r02_hipconv_small.txt); from 128 positions up the op is a real GEMM and MIOpen ties."""
-    if os.environ.get("IPSR_NO_SMALLMAP", "0") == "1" or k not in (3, 4) or min(Cin, Cout) < 256:
+    if _env("IPSR_NO_SMALLMAP", "0") == "1" or k not in (3, 4) or min(Cin, Cout) < 256:
         return False
     g = _smallmap_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
     return g[3] >= 1 and g[4] >= 1 and g[0] * g[3] * g[4] <= 32 and ops.smallmap_supported(_smallmap_op(op), *g)
@@ -246,7 +275,7 @@ def _smallmap_data_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
 def _smallmap_wrw_wins(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
     """Weight gradients of the 4x4 layers on grids of <= 256 positions per batch (the four innermost levels at batch 8): the GEMM
     writes dW in place, 27-39 us against MIOpen's 41-57 (profiles/r02_hipconv_small.txt)."""
-    if k != 4 or stride != 2 or os.environ.get("IPSR_NO_SMALLMAP", "0") == "1":        # the switch is for A/B timing
+    if k != 4 or stride != 2 or _env("IPSR_NO_SMALLMAP", "0") == "1":        # the switch is for A/B timing
         return False
     g = _smallmap_geometry(transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
     return g[3] >= 1 and g[4] >= 1 and g[0] * g[3] * g[4] <= 256 and min(Cin, Cout) >= 256 and ops.smallmap_supported(ops.SM_WRW, *g)
@@ -259,12 +288,20 @@ def _is_k4s1(k, stride, pad, dil):
 def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
     """-> the engine for the weight gradient of one layer (profiles/r02_hipconv_k3_wrw.txt: F(3x3,4x4) is 2.0-2.4x
     MIOpen from 256 channels up on maps of 16x16..64x64; on larger maps its tile-major transforms lose to MIOpen)."""
-    eng = _select_wrw(_mode(), os.environ.get("IPSR_NO_SMALLMAP", "0"), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+    key = (1, _FORCE, transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16)
+    eng = _SEL.get(key)
+    if eng is None:
+        eng = _SEL[key] = _select_wrw_any(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16)
+    return eng
+
+
+def _select_wrw_any(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16):
+    eng = _select_wrw(_mode(), _env("IPSR_NO_SMALLMAP", "0"), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
     if not bf16:
         return eng
     if _bf16_wins(eng, Cin, H, W, Cout, True) or eng in _CAST_ENGINES:
         return eng
-    return _bf16_direct_wrw(os.environ.get("IPSR_BF16_ENGINES", ""), _mode(), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+    return _bf16_direct_wrw(_env("IPSR_BF16_ENGINES", ""), _mode(), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
 
 
 @functools.lru_cache(maxsize=4096)

@@ -15,7 +15,8 @@ _ws_cache = {}
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """The raw hipStream_t of torch's current stream on the current device (the C getter: no Stream object per launch)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _workspace(nbytes, device):
@@ -30,7 +31,7 @@ def _workspace(nbytes, device):
 
 def _on_current_device(t, name):
     # the kernels are launched on the CURRENT device's stream with raw pointers: a tensor living on another GPU would fault
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != torch._C._cuda_getDevice():        # (the C getter: this check runs ~700 times per training step)
         raise RuntimeError("%s is on %s but the current device is cuda:%d — wrap the call in torch.cuda.device(...) "
                            "(one process per GPU sets it once)" % (name, t.device, torch.cuda.current_device()))
 
