@@ -38,7 +38,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
 
 constexpr int CB_K = 128, CB_P = 256, CB_C = 16, CB_THREADS = 512, CB_MAXTAP = 9;
-constexpr int CB_TR_MAX = 6;                                // transposition blocks (4 channels x 16 pixels) per 16-lane group and stage
+// per-thread loop bounds of a stage, by pixels per tile (256 / 512): transposition blocks (4 channels x 16 pixels) per 16-lane group, and
+// 16-byte raw-tile chunks per thread
+constexpr int cb_tr_max(int ptile) { return ptile == 256 ? 6 : 10; }
+constexpr int cb_xj(int ptile) { return ptile == 256 ? 3 : 5; }
 constexpr int CB_LDS_MAX = 160 * 1024;
 // LDS plan (per geometry, cb_finish): A[2] | T[2] | raw[2 or 1].  A stage = ntap x 4 KB ([tap][c group][128 k][8 c] bf16), raw = [16 c][raw
 // rows][input width] bf16, T = [planes][2 c groups][positions][8 c].  k3 at W <= 128: 2 x (36 + 16 + 16.3) KB; stride 2: 2 x (32 + 20 + 20.4);
@@ -60,14 +63,14 @@ struct CbGeom {
     int Hin, Win;               // the tensor the kernel reads
     int Hl, Wl, wshift;         // lane grid (rows, width = power of two), log2 Wl
     int Hout, Wout;             // the tensor written
-    int R, NR, PW, NPOS;        // lane-grid rows per tile (256 / Wl), raw rows, padded width, positions NR * PW per (plane, c group)
+    int R, NR, PW, NPOS;        // lane-grid rows per tile (ptile / Wl), raw rows, padded width, positions NR * PW per (plane, c group)
     int ymul, rowstep, yoff[2]; // input row of raw row i of sub-stage e: ymul * y0 + yoff[e] + rowstep * i
     int nsub, nphase;           // stages per channel block (F2C: 2), output row phases = workgroups per (k tile, pixel tile) (C2F: 2)
     int ntap;
     int tapoff[2][CB_MAXTAP];   // per sub-stage (F2C) / row phase (C2F): plane * 2 * NPOS + drow * PW + dcol
     int ktiles, ptiles, nstage; // ceil(K / 128), B * Hl / R, (C / 16) * nsub
     int a_bytes, t_bytes, raw_bytes, raw1;      // LDS plan: stage sizes, one raw buffer instead of two
-    int kt;                     // produced channels per workgroup tile: 128, or 64 when K <= 64
+    int kt, ptile;              // produced channels per workgroup tile: 128, or 64 when K <= 64; pixels per tile: 256, or 512 (64-row kernel)
 };
 
 // packed weights: Wp[kt][phase][cb][sub][t][cg][k & 127][c & 7] bf16 (zero for k >= K); source element (k, c, tap) at w[c * sc + k * sk + srctap]
@@ -100,14 +103,18 @@ __global__ void __launch_bounds__(256) cb_pack_weights_kernel(const float* __res
 
 // KT = produced channels per workgroup tile: 128 (waves 2 x 4, a wave 64 x 64), or 64 for layers that produce <= 64 channels (waves 1 x 8, a
 // wave 64 x 32) — a 128-row tile on a 64-channel layer multiplies zeros half of the time (VGG conv1_2, the outermost U-Net levels).
-template <int MODE, int KT, typename TOUT>
+template <int MODE, int KT, int P, typename TOUT>
 __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned short* __restrict__ in, const uint4* __restrict__ Wp,
                                                                   const uint4* __restrict__ zero_page, CbGeom g, TOUT* __restrict__ out)
 {
     constexpr int NTAP = MODE == CB_S1 ? 9 : 8;
     constexpr int NSET = MODE == CB_C2F ? 2 : 1;               // accumulator sets (C2F: the two column phases of the fine output)
     constexpr int TPSET = NTAP / NSET;
-    constexpr int WN = KT == 128 ? 4 : 8, NJ = 8 / WN;         // wave columns; 32-pixel MFMA tiles per wave
+    // P = pixels per tile: 256 under 128 produced channels; under 64 it is 512 where the map has the rows for it — a wave owns 64 x 64
+    // either way (4 fragment reads per 4 MFMAs; on a 64 x 256 tile it is 64 x 32: 3 reads per 2 MFMAs = 192 B/clk/CU of the LDS's 256)
+    static_assert((KT == 128 && P == 256) || (KT == 64 && (P == 256 || P == 512)), "tile");
+    constexpr int WN = KT == 128 ? 4 : 8, NJ = P / 32 / WN;    // wave columns; 32-pixel MFMA tiles per wave
+    constexpr int CB_TR_MAX = cb_tr_max(P);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];          // 2 x (A | raw | T)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,7 +132,7 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
     // ---- stage-invariant addresses ------------------------------------------------------------------------------------------
     // raw tile DMA: chunk q (16 bytes = 8 pixels) = (c, row, seg), LDS image linear in q; per sub-stage its own row set
     const int segs = g.Win >> 3, nchunk = CB_C * g.NR * segs;
-    constexpr int XJ = 3;                                  // 16-byte chunks per thread: up to 1280 (stride 2, 64-wide coarse grid)
+    constexpr int XJ = cb_xj(P);
     const unsigned short* gx[XJ][MODE == CB_F2C ? 2 : 1];
     bool xlive[XJ];
 #pragma unroll
@@ -301,7 +308,7 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
                     }
                 }
         } else if (sizeof(TOUT) == 2) {
-            // bf16 output: through LDS (free after the last stage's barrier) as [k][256 pixels], so that the tile leaves as 16-byte rows
+            // bf16 output: through LDS (free after the last stage's barrier) as [k][P pixels], so that the tile leaves as 16-byte rows
             // instead of 64 two-byte stores per lane
             unsigned short* L = reinterpret_cast<unsigned short*>(lds);
 #pragma unroll
@@ -309,7 +316,7 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int kl = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    L[kl * CB_P + p] = f2bf(acc[0][i][j][e]);
+                    L[kl * P + p] = f2bf(acc[0][i][j][e]);
                 }
         } else {
             const bool live = py < g.Hout && px < g.Wout;      // (lane grid == output grid here)
@@ -327,9 +334,9 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
         __syncthreads();
         const uint4* L4 = reinterpret_cast<const uint4*>(lds);
 #pragma unroll
-        for (int it = 0; it < KT * CB_P * 2 / 16 / CB_THREADS; ++it) {
-            const int chunk = tid + CB_THREADS * it;           // 32 chunks of 8 pixels per channel row
-            const int kl = chunk >> 5, p0 = (chunk & 31) * 8;
+        for (int it = 0; it < KT * P * 2 / 16 / CB_THREADS; ++it) {
+            const int chunk = tid + CB_THREADS * it;           // P / 8 chunks of 8 pixels per channel row
+            const int kl = chunk / (P / 8), p0 = (chunk % (P / 8)) * 8;
             const int k = kt * KT + kl;
             if (k < g.K) {
                 TOUT* op = out + ((size_t)b * g.K + k) * HWo + (size_t)(y0 + (p0 >> g.wshift)) * g.Wout + (p0 & (g.Wl - 1));
@@ -339,10 +346,11 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
     }
 }
 
-static int cb_lane_grid(int Hl, int Wl, CbGeom* g, const char* who)
+static int cb_lane_grid(int Hl, int Wl, int ptile, CbGeom* g, const char* who)
 {
     if (Wl != 16 && Wl != 32 && Wl != 64 && Wl != 128 && Wl != 256) return fail(IPSR_ERR_UNSUPPORTED, "%s: grid width %d (16 .. 256, a power of two)", who, Wl);
-    const int R = CB_P / Wl;
+    const int R = ptile / Wl;
+    g->ptile = ptile;
     if (Hl % R != 0) return fail(IPSR_ERR_UNSUPPORTED, "%s: %d rows are not a multiple of the %d rows of a tile", who, Hl, R);
     g->Hl = Hl; g->Wl = Wl; g->R = R;
     g->wshift = Wl == 16 ? 4 : (Wl == 32 ? 5 : (Wl == 64 ? 6 : (Wl == 128 ? 7 : 8)));
@@ -361,17 +369,17 @@ static int cb_finish(CbGeom* g, const char* who)
     g->t_bytes = (int)align_up((size_t)planes * 2 * g->NPOS * 16, 256);
     g->raw_bytes = (int)align_up((size_t)CB_C * g->NR * g->Win * 2, 1024);
     g->raw1 = 2 * (g->a_bytes + g->t_bytes + g->raw_bytes) > CB_LDS_MAX;
-    if (2 * (g->a_bytes + g->t_bytes) + (g->raw1 ? 1 : 2) * g->raw_bytes > CB_LDS_MAX || 4 * g->NR * (g->Win / 16) > 32 * CB_TR_MAX ||
-        CB_C * g->NR * (g->Win / 8) > 3 * CB_THREADS)
+    if (2 * (g->a_bytes + g->t_bytes) + (g->raw1 ? 1 : 2) * g->raw_bytes > CB_LDS_MAX || 4 * g->NR * (g->Win / 16) > 32 * cb_tr_max(g->ptile) ||
+        CB_C * g->NR * (g->Win / 8) > cb_xj(g->ptile) * CB_THREADS)
         return fail(IPSR_ERR_UNSUPPORTED, "%s: a tile of %d rows x %d does not fit the LDS plan", who, g->NR, g->Win);
     return IPSR_OK;
 }
 
 // k3 s1 p1
-static int cb_geometry(int B, int C, int K, int H, int W, CbGeom* g)
+static int cb_geometry_p(int B, int C, int K, int H, int W, int ptile, CbGeom* g)
 {
     if (C % CB_C != 0) return fail(IPSR_ERR_UNSUPPORTED, "bf16 direct conv: %d reduction channels are not a multiple of %d", C, CB_C);
-    if (int rc = cb_lane_grid(H, W, g, "bf16 direct conv")) return rc;
+    if (int rc = cb_lane_grid(H, W, ptile, g, "bf16 direct conv")) return rc;
     g->B = B; g->C = C; g->K = K; g->Hin = H; g->Win = W; g->Hout = H; g->Wout = W;
     g->NR = g->R + 2; g->PW = W + 2;
     g->ymul = 1; g->rowstep = 1; g->yoff[0] = -1; g->yoff[1] = -1;
@@ -380,11 +388,25 @@ static int cb_geometry(int B, int C, int K, int H, int W, CbGeom* g)
     return cb_finish(g, "bf16 direct conv");
 }
 
+// <= 64 produced channels: the 512-pixel tile where the map and the LDS plan allow it, else 256
+static int cb_geometry(int B, int C, int K, int H, int W, CbGeom* g)
+{
+    if (K <= 64 && cb_geometry_p(B, C, K, H, W, 2 * CB_P, g) == IPSR_OK) return IPSR_OK;
+    return cb_geometry_p(B, C, K, H, W, CB_P, g);
+}
+
+static int cb_geometry_s2_p(int form, int B, int C, int K, int nh, int nw, int ptile, CbGeom* g);
 // k4 s2 p1: fine [.,Cf,2nh,2nw], coarse [.,Kc,nh,nw].  form 0: fine -> coarse (C = Cf reduced, K = Kc produced); 1: coarse -> fine
 static int cb_geometry_s2(int form, int B, int C, int K, int nh, int nw, CbGeom* g)
 {
+    if (K <= 64 && cb_geometry_s2_p(form, B, C, K, nh, nw, 2 * CB_P, g) == IPSR_OK) return IPSR_OK;
+    return cb_geometry_s2_p(form, B, C, K, nh, nw, CB_P, g);
+}
+
+static int cb_geometry_s2_p(int form, int B, int C, int K, int nh, int nw, int ptile, CbGeom* g)
+{
     if (C % CB_C != 0) return fail(IPSR_ERR_UNSUPPORTED, "bf16 direct 4x4 stride-2 conv: %d reduction channels are not a multiple of %d", C, CB_C);
-    if (int rc = cb_lane_grid(nh, nw, g, "bf16 direct 4x4 stride-2 conv")) return rc;
+    if (int rc = cb_lane_grid(nh, nw, ptile, g, "bf16 direct 4x4 stride-2 conv")) return rc;
     g->B = B; g->C = C; g->K = K;
     if (form == 0) {
         g->Hin = 2 * nh; g->Win = 2 * nw; g->Hout = nh; g->Wout = nw;
@@ -430,12 +452,12 @@ size_t conv_bf16_s2_ws_bytes(int form, int B, int C, int K, int nh, int nw)
     return 256 + (size_t)g.ktiles * g.nphase * g.nstage * 8 * 2 * g.kt * 16;
 }
 
-template <int MODE, int KT, typename TOUT>
+template <int MODE, int KT, int P, typename TOUT>
 static void cb_launch_kernel(const CbGeom& g, const void* in, const uint4* Wp, const uint4* zero_page, void* out, unsigned grid, size_t smem, hipStream_t st)
 {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, KT, TOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_MAX); attr = true; }
-    conv_bf16_kernel<MODE, KT, TOUT><<<grid, CB_THREADS, smem, st>>>(static_cast<const unsigned short*>(in), Wp, zero_page, g, static_cast<TOUT*>(out));
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, KT, P, TOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS_MAX); attr = true; }
+    conv_bf16_kernel<MODE, KT, P, TOUT><<<grid, CB_THREADS, smem, st>>>(static_cast<const unsigned short*>(in), Wp, zero_page, g, static_cast<TOUT*>(out));
 }
 
 template <int MODE>
@@ -452,12 +474,15 @@ static int cb_launch(const CbGeom& g, CbPack pk, const void* in, const float* w,
     const unsigned grid = (unsigned)(g.ktiles * g.nphase * g.ptiles);
     const size_t smem = 2 * (size_t)(g.a_bytes + g.t_bytes) + (size_t)(g.raw1 ? 1 : 2) * g.raw_bytes;
     profile_mark_start(st, 4);
-    if (g.kt == 64) {
-        if (out_bf16) cb_launch_kernel<MODE, 64, bf16_t>(g, in, Wp, zero_page, out, grid, smem, st);
-        else cb_launch_kernel<MODE, 64, float>(g, in, Wp, zero_page, out, grid, smem, st);
+    if (g.kt == 64 && g.ptile == 2 * CB_P) {
+        if (out_bf16) cb_launch_kernel<MODE, 64, 2 * CB_P, bf16_t>(g, in, Wp, zero_page, out, grid, smem, st);
+        else cb_launch_kernel<MODE, 64, 2 * CB_P, float>(g, in, Wp, zero_page, out, grid, smem, st);
+    } else if (g.kt == 64) {
+        if (out_bf16) cb_launch_kernel<MODE, 64, CB_P, bf16_t>(g, in, Wp, zero_page, out, grid, smem, st);
+        else cb_launch_kernel<MODE, 64, CB_P, float>(g, in, Wp, zero_page, out, grid, smem, st);
     } else {
-        if (out_bf16) cb_launch_kernel<MODE, 128, bf16_t>(g, in, Wp, zero_page, out, grid, smem, st);
-        else cb_launch_kernel<MODE, 128, float>(g, in, Wp, zero_page, out, grid, smem, st);
+        if (out_bf16) cb_launch_kernel<MODE, 128, CB_P, bf16_t>(g, in, Wp, zero_page, out, grid, smem, st);
+        else cb_launch_kernel<MODE, 128, CB_P, float>(g, in, Wp, zero_page, out, grid, smem, st);
     }
     const double outs = (double)g.B * g.Hout * g.Wout;
     profile_mark_stop(st, 4, 2.0 * taps_per_out * g.C * (double)(g.ktiles * g.kt) * outs, 2.0 * taps_per_out * g.C * (double)g.K * outs);
