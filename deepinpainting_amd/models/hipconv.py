@@ -106,7 +106,7 @@ def select(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
 
 
 def _select_any(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16):
-    eng = _select(_mode(), _env("IPSR_NO_SMALLMAP", "0") + _env("IPSR_NO_THIN", "0"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
+    eng = _select(_mode(), _env("IPSR_NO_SMALLMAP", "0") + _env("IPSR_NO_THIN", "0") + _env("IPSR_SMALLMAP_MAX_POS", "32"), op, B, Cin, H, W, Cout, k, stride, pad, dil)
     if not bf16:
         return eng
     if _bf16_wins(eng, Cin, H, W, Cout) or eng in _CAST_ENGINES:
@@ -269,7 +269,7 @@ def _smallmap_data_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil):
     if _env("IPSR_NO_SMALLMAP", "0") == "1" or k not in (3, 4) or min(Cin, Cout) < 256:
         return False
     g = _smallmap_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
-    return g[3] >= 1 and g[4] >= 1 and g[0] * g[3] * g[4] <= 32 and ops.smallmap_supported(_smallmap_op(op), *g)
+    return g[3] >= 1 and g[4] >= 1 and g[0] * g[3] * g[4] <= int(_env("IPSR_SMALLMAP_MAX_POS", "32")) and ops.smallmap_supported(_smallmap_op(op), *g)
 
 
 def _smallmap_wrw_wins(transposed, B, Cin, H, W, Cout, k, stride, pad, dil):
