@@ -110,3 +110,30 @@ def test_conv_dispatcher_rules_on_the_host():
     assert ops.s2_winograd_supported(ops.S2_FINE_TO_COARSE, 8, 128, 64, 64, 64) and not ops.s2_winograd_supported(ops.S2_FINE_TO_COARSE, 8, 128, 3, 64, 64)
     assert ops.smallmap_supported(ops.SM_WRW, 8, 512, 512, 4, 4, 8, 8, 4, 2, 1, 1) and not ops.smallmap_supported(ops.SM_WRW, 8, 512, 500, 4, 4, 8, 8, 4, 2, 1, 1)
     assert not ops.smallmap_supported(ops.SM_DATA, 8, 512, 512, 4, 4, 11, 11, 4, 2, 1, 1)         # 11x11 does not map to a 4x4 output
+    # bf16 activations (BASELINE config 5, batch 16): the direct kernels from 32x32 up, split-bf16 Winograd on 16x16 maps with >= 512
+    # channels, the 3-channel ends on the stream kernels, MIOpen for what nothing here expresses
+    assert sel(ops.CONV_FWD, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d" and wrw(False, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d"
+    assert sel(ops.CONV_FWD, 16, 64, 256, 256, 64, 3, 1, 1, 1, True) == "bf16d"           # VGG conv1_2: the 64-row kernel, 512-pixel tile
+    assert sel(ops.CONV_FWD, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"
+    assert sel(ops.CONVT_FWD, 16, 512, 32, 32, 128, 4, 2, 1, 1, True) == "bf16d" and wrw(True, 16, 512, 32, 32, 128, 4, 2, 1, 1, True) == "bf16d"
+    assert sel(ops.CONV_FWD, 16, 3, 256, 256, 64, 3, 1, 1, 1, True) == "thin"              # VGG conv1_1
+    assert sel(ops.CONVT_BWD_DATA, 16, 128, 256, 256, 3, 3, 1, 1, 1, True) == "thin"       # the last ConvTranspose2d's input gradient (3 -> 128)
+    assert sel(ops.CONVT_FWD, 16, 128, 256, 256, 3, 3, 1, 1, 1, True) == "bf16d"           # its forward: the direct kernel beats the stream kernel
+    assert sel(ops.CONV_FWD, 16, 6, 256, 256, 64, 3, 1, 1, 1, True) == "miopen"            # 6 -> 64: MIOpen is ahead under bf16
+    assert sel(ops.CONV_FWD, 16, 64, 256, 256, 64, 4, 2, 3, 2, True) == "miopen"           # the dilated family on large maps
+    assert ops.conv3x3_bf16_supported(ops.CONV_FWD, 2, 32, 16, 16, 48)                     # <= 64 produced channels on a map too small for 512-pixel tiles
+    # the selection is memoised per shape and per forced mode; the A/B switches are read from the environment once (reload_env re-reads)
+    was = hipconv._FORCE
+    try:
+        hipconv._FORCE = "miopen"
+        assert sel(ops.CONV_FWD, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "miopen" and sel(ops.CONV_FWD, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "miopen"
+        hipconv._FORCE = None
+        assert sel(ops.CONV_FWD, 8, 512, 32, 32, 512, 3, 1, 1, 1) == "winograd"
+        os.environ["IPSR_NO_THIN"] = "1"
+        assert sel(ops.CONV_FWD, 16, 3, 256, 256, 64, 3, 1, 1, 1, True) == "thin"          # cached: the environment is not re-read per call
+        hipconv.reload_env()
+        assert sel(ops.CONV_FWD, 16, 3, 256, 256, 64, 3, 1, 1, 1, True) == "miopen"
+    finally:
+        hipconv._FORCE = was
+        os.environ.pop("IPSR_NO_THIN", None)
+        hipconv.reload_env()
