@@ -242,6 +242,177 @@ __global__ void __launch_bounds__(256) thin_wrw_reduce_kernel(const float* __res
 
 
 // ---------------------------------------------------------------------------------------------------
+// Weight gradient of the thin layers on the bf16 matrix cores (BASELINE config 5; bf16 wide tensor):
+//      G[kb][cs][r][s] = sum_{b, y, x}  big[b][kb][y][x] * small[b][cs][y*st + r - pad][x*st + s - pad]
+// Conv2d: big = dy, small = x;  ConvTranspose2d: big = x, small = dy — the same formula with `big` on the coarse grid — and G is the
+// module's weight layout [dim0 = wide][dim1 = narrow][k][k] either way.  k3 s1 p1 and k4 s2 p1, 3 or 6 narrow channels.
+// As a GEMM the reduction runs over PIXELS: D[kb][R] += A[kb][16 px] * B[16 px][R], R = cs * k*k + tap (27 / 54 / 48 / 96 -> one to three
+// 32-column tiles).  A fragments are aligned 16-byte loads of the wide tensor (8 consecutive pixels of one channel: NCHW has them contiguous),
+// B fragments are gathered from the narrow tensor, which lives in L1 / L2 (786 KB per sample): 8 scalar loads per lane and 32 columns,
+// zero outside the image, rounded to bf16 like autocast's cast.  No LDS.  A wave owns whole rows of `big` and the full [kb tile][R]
+// accumulator; the workgroup's four waves are added in order through LDS into one partial slab, a second launch adds the slabs in order
+// (deterministic).
+// The vector-ALU form above takes 0.14-0.30 ms per layer at batch 16 (VALU-bound); this one reads the wide tensor once at HBM rate.
+typedef __bf16 thin_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float thin_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned thin_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT, int RT, typename TS>
+__global__ void __launch_bounds__(256) thin_wrw_mfma_kernel(const bf16_t* __restrict__ big, const TS* __restrict__ small, float* __restrict__ slabs,
+                                                            int B, int Kb, int Cs, int Hb, int Wb, int Hs, int Ws, int k, int st, int pad, int rows_per_wg)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, k0 = blockIdx.z * (32 * MT);
+    const int y_lo = blockIdx.x * rows_per_wg;
+    const int T = k * k, R_real = Cs * T;
+    // the lane's column of each 32-column tile: (narrow channel, tap row, tap column), or nothing beyond the real width
+    int c_cs[RT], c_rr[RT], c_ss[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int r = n + 32 * rt;
+        const bool live = r < R_real;
+        const int cs = live ? r / T : 0, t = live ? r - cs * T : 0;
+        c_cs[rt] = live ? cs : -1; c_rr[rt] = t / k; c_ss[rt] = t - (t / k) * k;
+    }
+    thin_f32x16 acc[MT][RT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][rt][e] = 0.0f;
+
+    const size_t plane_b = (size_t)Hb * Wb, plane_s = (size_t)Hs * Ws;
+    // The wave's steps: its rows (y_lo + wave, + 4, ...) x the row's 16-pixel segments, as one sequence, software-pipelined: the loads of
+    // step i + 1 (2-4 wide-tensor vectors from HBM, 8-24 narrow-tensor values from L2) are issued before step i is converted and multiplied
+    // — one memory latency per step would otherwise be the whole kernel (16 steps per wave).
+    const int xsteps = Wb >> 4;
+    int nrows = 0;
+    for (int y = y_lo + wave; y < y_lo + rows_per_wg && y < Hb; y += 4) ++nrows;
+    const int nsteps = nrows * xsteps;
+    thin_u32x4 la[2][MT];
+    float lg[2][RT][8];
+    auto issue = [&](int i, int buf) {
+        const int y = y_lo + wave + 4 * (i / xsteps), x0 = (i % xsteps) << 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int kb = min(k0 + 32 * mt + n, Kb - 1);                  // rows beyond Kb are masked when consumed
+            la[buf][mt] = *reinterpret_cast<const thin_u32x4*>(big + ((size_t)b * Kb + kb) * plane_b + (size_t)y * Wb + x0 + 8 * h);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int sy = min(max(y * st + c_rr[rt] - pad, 0), Hs - 1);
+            const TS* sp = small + ((size_t)b * Cs + max(c_cs[rt], 0)) * plane_s + (size_t)sy * Ws;
+            // every load is issued, from a clamped address, and masked when consumed: a load under a per-element condition makes hipcc
+            // branch around it and wait for it alone
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int sx = (x0 + 8 * h + j) * st + c_ss[rt] - pad;
+                lg[buf][rt][j] = ld1(sp, (size_t)min(max(sx, 0), Ws - 1));
+            }
+        }
+    };
+    auto consume = [&](int i, int buf) {
+        const int y = y_lo + wave + 4 * (i / xsteps), x0 = (i % xsteps) << 4;
+        thin_bf16x8 fa[MT], fb[RT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const thin_u32x4 z = {0u, 0u, 0u, 0u};
+            fa[mt] = __builtin_bit_cast(thin_bf16x8, (k0 + 32 * mt + n < Kb) ? la[buf][mt] : z);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int sy = y * st + c_rr[rt] - pad;
+            const bool rowok = c_cs[rt] >= 0 && (unsigned)sy < (unsigned)Hs;
+            unsigned short q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int sx = (x0 + 8 * h + j) * st + c_ss[rt] - pad;
+                q[j] = f2bf((rowok && (unsigned)sx < (unsigned)Ws) ? lg[buf][rt][j] : 0.0f);      // (exact for a bf16 narrow tensor)
+            }
+            const thin_u32x4 pk = {(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16),
+                                   (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
+            fb[rt] = __builtin_bit_cast(thin_bf16x8, pk);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[rt], acc[mt][rt], 0, 0, 0);
+    };
+    if (nsteps > 0) issue(0, 0);
+    for (int i = 0; i < nsteps; i += 2) {                      // two steps per trip: the buffer index is a compile-time constant
+        if (i + 1 < nsteps) issue(i + 1, 1);
+        consume(i, 0);
+        if (i + 1 < nsteps) {
+            if (i + 2 < nsteps) issue(i + 2, 0);
+            consume(i + 1, 1);
+        }
+    }
+    // the four waves' accumulators are added in wave order through LDS (one wave's worth at a time), wave 0 writes the workgroup's slab
+    // [kb tile row][32 RT columns]
+    __shared__ float red[MT * RT * 16 * 64];
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[((mt * RT + rt) * 16 + e) * 64 + lane] = acc[mt][rt][e];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mt][rt][e] += red[((mt * RT + rt) * 16 + e) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    const size_t slab = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* out = slabs + slab * (32 * MT) * (32 * RT);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * h;
+                out[(size_t)row * (32 * RT) + 32 * rt + n] = acc[mt][rt][e];
+            }
+}
+
+// G[kb][r] = sum over the slabs of one kb tile, ascending (r < R_real).  One workgroup per kb row: thread = (r, slab group of four).
+__global__ void __launch_bounds__(256) thin_wrw_mfma_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ G, int Kb, int R_real, int rows_tile,
+                                                                   int cols, int slabs_per_tile)
+{
+    __shared__ float part[4][64];
+    const int kb = blockIdx.x, tile = kb / rows_tile, row = kb - tile * rows_tile;
+    const int grp = threadIdx.x >> 6;
+    const size_t sstride = (size_t)rows_tile * cols;
+    for (int r0 = 0; r0 < cols; r0 += 64) {
+        const int r = r0 + (threadIdx.x & 63);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;      // four independent chains per thread (a fixed order all the same): the loads overlap
+        if (r < cols) {
+            const float* p = slabs + (size_t)tile * slabs_per_tile * sstride + (size_t)row * cols + r;
+            int sI = grp;
+            for (; sI + 12 < slabs_per_tile; sI += 16) {
+                a0 += p[(size_t)sI * sstride]; a1 += p[(size_t)(sI + 4) * sstride]; a2 += p[(size_t)(sI + 8) * sstride]; a3 += p[(size_t)(sI + 12) * sstride];
+            }
+            for (; sI < slabs_per_tile; sI += 4) a0 += p[(size_t)sI * sstride];
+        }
+        part[grp][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (grp == 0 && r < R_real) G[(size_t)kb * R_real + r] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Conv2d with ONE output channel, stride 1 (netD's last layer, 512 -> 1, k4 p1 on 31x31: models/networks.py:489-495; batch 16 in
 // backward_D, 8 in backward_G).  252 MFLOP against 31.5 MB of input: a stream, which MIOpen's generic paths take 80-145 us
 // (forward) and 75-127 us (weight gradient) for.  Both passes here walk input planes through LDS (zero halo of `pad`, so the taps
@@ -461,6 +632,64 @@ int ipsr_conv3x3_thin_wrw_io(const void* big, const void* small, float* g, int B
 int ipsr_conv3x3_thin_wrw(const float* big, const float* small, float* g, int B, int Cb, int Cs, int H, int W, void* ws, size_t ws_bytes, void* stream)
 {
     return ipsr_conv3x3_thin_wrw_io(big, small, g, B, Cb, Cs, H, W, 0, ws, ws_bytes, stream);
+}
+
+// ---- thin weight gradients on the matrix cores (bf16 wide tensor) ---------------------------------------------------------------
+static int thin_wrw_mfma_plan(int B, int Kb, int Cs, int Hb, int Wb, int k, int stride, int* MT, int* RT, int* rows_per_wg, int* gx)
+{
+    const bool k3 = k == 3 && stride == 1, k4 = k == 4 && stride == 2;
+    if (B < 1 || Kb < 1 || Hb < 1 || (Cs != 3 && Cs != 6) || !(k3 || k4) || Wb % 16 != 0 || Wb < 16) return 0;
+    const int R = Cs * k * k;                                 // 27, 54, 48, 96
+    *RT = (R + 31) / 32;
+    *MT = Kb >= 128 && *RT <= 2 ? 4 : 2;                      // accumulator tiles per wave: at most 8
+    if (Kb % 8 != 0) return 0;
+    // rows per workgroup: two to four workgroups per CU
+    const int ktiles = (Kb + 32 * *MT - 1) / (32 * *MT);
+    int rows = 4;
+    const long wgs = *RT >= 2 ? 512 : 1024;                   // (measured: two gather tiles per step like longer runs, one tile more workgroups)
+    while ((long)B * ktiles * ((Hb + rows - 1) / rows) > wgs && rows < Hb) rows *= 2;
+    *rows_per_wg = rows;
+    *gx = (Hb + rows - 1) / rows;
+    return ktiles;
+}
+
+size_t ipsr_conv_thin_wrw_mfma_workspace_bytes(int B, int Kb, int Cs, int Hb, int Wb, int k, int stride)
+{
+    int MT, RT, rows, gx;
+    const int ktiles = thin_wrw_mfma_plan(B, Kb, Cs, Hb, Wb, k, stride, &MT, &RT, &rows, &gx);
+    if (!ktiles) return 0;
+    return align_up((size_t)ktiles * B * gx * (32 * MT) * (32 * RT) * sizeof(float), 256) + 256;
+}
+
+// big [B,Kb,Hb,Wb] bf16; small [B,Cs,Hs,Ws] fp32 (small_bf16 = 0) or bf16, Hs = Hb (k3 s1 p1) or 2 Hb (k4 s2 p1); g [Kb][Cs][k][k] fp32.
+int ipsr_conv_thin_wrw_mfma(const void* big, const void* small, float* g, int B, int Kb, int Cs, int Hb, int Wb, int k, int stride, int small_bf16,
+                            void* ws, size_t ws_bytes, void* stream)
+{
+    if (!big || !small || !g || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv_thin_wrw_mfma: null pointer");
+    int MT, RT, rows, gx;
+    const int ktiles = thin_wrw_mfma_plan(B, Kb, Cs, Hb, Wb, k, stride, &MT, &RT, &rows, &gx);
+    if (!ktiles) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_thin_wrw_mfma: Kb=%d Cs=%d %dx%d k%d s%d is not implemented", Kb, Cs, Hb, Wb, k, stride);
+    const size_t need = ipsr_conv_thin_wrw_mfma_workspace_bytes(B, Kb, Cs, Hb, Wb, k, stride);
+    if (ws_bytes < need) return fail(IPSR_ERR_WORKSPACE, "ipsr_conv_thin_wrw_mfma: workspace %zu < %zu", ws_bytes, need);
+    if ((reinterpret_cast<uintptr_t>(big) & 15u) || (reinterpret_cast<uintptr_t>(ws) & 15u)) return fail(IPSR_ERR_INVALID, "ipsr_conv_thin_wrw_mfma: `big` / workspace must be 16-byte aligned");
+    if (B > 65535 || ktiles > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_thin_wrw_mfma: grid too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* slabs = static_cast<float*>(ws);
+    const int Hs = Hb * stride, Ws = Wb * stride, pad = 1;
+    const dim3 grid(gx, B, ktiles);
+#define THIN_WM(MTT, RTT, TSM) thin_wrw_mfma_kernel<MTT, RTT, TSM><<<grid, 256, 0, st>>>(static_cast<const bf16_t*>(big), static_cast<const TSM*>(small), slabs, \
+                                                                                  B, Kb, Cs, Hb, Wb, Hs, Ws, k, stride, pad, rows)
+#define THIN_WM_TS(MTT, RTT) do { if (small_bf16) THIN_WM(MTT, RTT, bf16_t); else THIN_WM(MTT, RTT, float); } while (0)
+    if (MT == 4 && RT == 1) THIN_WM_TS(4, 1);
+    else if (MT == 4 && RT == 2) THIN_WM_TS(4, 2);
+    else if (RT == 1) THIN_WM_TS(2, 1);
+    else if (RT == 2) THIN_WM_TS(2, 2);
+    else THIN_WM_TS(2, 3);
+#undef THIN_WM_TS
+#undef THIN_WM
+    if (int rc = check_launch("thin_wrw_mfma_kernel")) return rc;
+    thin_wrw_mfma_reduce_kernel<<<ktiles * 32 * MT > Kb ? Kb : ktiles * 32 * MT, 256, 0, st>>>(slabs, g, Kb, Cs * k * k, 32 * MT, 32 * RT, B * gx);
+    return check_launch("thin_wrw_mfma_reduce_kernel");
 }
 
 size_t ipsr_conv_to_one_workspace_bytes(int B, int C, int H, int W, int K, int pad)

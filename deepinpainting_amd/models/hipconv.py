@@ -14,6 +14,8 @@ Three engines per (operation, geometry), chosen by `select()` from measurements 
                                   >= 128 / 64 channels on coarse grids of 16..64
   "thin"      csrc/thin_conv.hip  3x3 stride-1 layers with a 3- or 6-channel side at full resolution (VGG conv1_1, netG's last ConvTranspose2d):
                                   one pass over the wide tensor on the vector ALUs, 1.3-3x MIOpen
+  "thin_mfma" csrc/thin_conv.hip  weight gradient of the layers with 3 or 6 channels on the narrow side (k3 s1 p1, k4 s2 p1) under bf16
+                                  activations: the pixel reduction on the bf16 matrix cores straight from NCHW, two launches
   "smallmap"  csrc/winograd.hip   the innermost levels: the weight tensor streamed once, 16 bytes per lane straight into MFMA operands —
                                   weight gradients of the 4x4 stride-2 layers up to 256 positions per batch (dW written in its native
                                   layout), forward and input gradient of the 3x3 / 4x4 layers up to 32 positions
@@ -301,6 +303,12 @@ def _select_wrw_any(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16):
         return eng
     if _bf16_wins(eng, Cin, H, W, Cout, True) or eng in _CAST_ENGINES:
         return eng
+    if _mode() == "auto" and _env("IPSR_NO_THIN", "0") != "1" and pad == 1 and dil == 1 and (k, stride) in ((3, 1), (4, 2)) and H * W >= 4096 \
+            and ops.thin_wrw_mfma_supported(transposed, B, Cin, H, W, Cout, k, stride):
+        # 3 / 6 channels on the narrow side: the pixel reduction on the bf16 matrix cores straight from NCHW (profiles/r04_thin_bf16.txt, batch 16:
+        # 3 -> 64 k4 s2 0.033 vs MIOpen's 0.057 ms, ConvT 128 -> 3 k3 0.152 vs 0.202, k4 s2 0.052 vs 0.063, 6 -> 64 0.118 vs 0.125 — and 2
+        # launches instead of MIOpen's 5-6)
+        return "thin_mfma"
     return _bf16_direct_wrw(_env("IPSR_BF16_ENGINES", ""), _mode(), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
 
 
@@ -436,10 +444,12 @@ class _HipConv(torch.autograd.Function):
                 _check_hook("input_grad", eng, ctx.geom, (dy, x, w), dx)
         weng = select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16) if ctx.needs_input_grad[1] else None
         # data parallel: write the weight gradient straight into its slice of the armed gradient bucket (dist.py)
-        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2", "smallmap", "one", "bf16d") else None
-        xw = x if (x.dtype == dy.dtype or weng in (None, "miopen")) else x.to(dy.dtype)      # a weight gradient reads both operands in one dtype
+        sink = ipsr_dist.grad_sink_for(w.data_ptr(), w.shape) if weng in ("winograd", "wino_dil", "wino_s2", "smallmap", "one", "bf16d", "thin_mfma") else None
+        xw = x if (x.dtype == dy.dtype or weng in (None, "miopen", "thin_mfma")) else x.to(dy.dtype)      # a weight gradient reads both operands in one dtype
         if weng == "winograd":
             dw = ops.conv3x3_winograd_wrw(transposed, xw, dy, Cout, out=sink, math=math)
+        elif weng == "thin_mfma":
+            dw = ops.conv_thin_wrw_mfma(transposed, (x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)) if transposed else x, dy, k, stride, out=sink)
         elif weng == "bf16d" and k == 3:
             dw = ops.conv3x3_bf16_wrw(transposed, xw, dy, Cout, out=sink)
         elif weng == "bf16d":

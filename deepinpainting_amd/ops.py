@@ -868,6 +868,43 @@ def conv3x3_thin_wrw(transposed, x, dy, out=None):
     raise NotImplementedError("conv3x3_thin_wrw: the weight's first channel dimension must be the wide one (got %s)" % (wshape,))
 
 
+def thin_wrw_mfma_supported(transposed, B, Cin, H, W, Cout, k, stride):
+    """Weight gradient of a k3 s1 p1 / k4 s2 p1 layer with 3 or 6 channels on its NARROW side on the bf16 matrix cores: the wide side
+    must be the weight's first dimension (Conv2d: Cout wide; ConvTranspose2d: Cin wide) and live on the coarse grid."""
+    if transposed:
+        Kb, Cs, Hb, Wb = Cin, Cout, H, W                   # big = x on the module's input grid (the coarse one)
+    else:
+        if H % stride or W % stride:
+            return False
+        Kb, Cs, Hb, Wb = Cout, Cin, H // stride, W // stride
+    return _lib.lib().ipsr_conv_thin_wrw_mfma_workspace_bytes(B, Kb, Cs, Hb, Wb, k, stride) > 0
+
+
+def conv_thin_wrw_mfma(transposed, x, dy, k, stride, out=None):
+    """-> dW (fp32, the module's layout) of a thin Conv2d / ConvTranspose2d under bf16 activations (ipsr_conv_thin_wrw_mfma).  The wide
+    tensor of (x, dy) must be bf16; the narrow one may be fp32 (it is rounded to bf16 inside, as autocast's cast would)."""
+    x, _ = _act(x, "x")
+    dy, _ = _act(dy, "dy")
+    big, small = (x, dy) if transposed else (dy, x)
+    if big.dtype != torch.bfloat16:
+        raise TypeError("conv_thin_wrw_mfma reads the wide tensor as bf16, got %s" % big.dtype)
+    B, Kb, Hb, Wb = big.shape
+    Cs = small.shape[1]
+    if tuple(small.shape) != (B, Cs, Hb * stride, Wb * stride):
+        raise RuntimeError("conv_thin_wrw_mfma: narrow tensor %s does not match wide %s at stride %d" % (tuple(small.shape), tuple(big.shape), stride))
+    L = _lib.lib()
+    nbytes = L.ipsr_conv_thin_wrw_mfma_workspace_bytes(B, Kb, Cs, Hb, Wb, k, stride)
+    if nbytes == 0:
+        raise NotImplementedError("ipsr_conv_thin_wrw_mfma: Kb=%d Cs=%d %dx%d k%d s%d is not implemented" % (Kb, Cs, Hb, Wb, k, stride))
+    g = out if out is not None else torch.empty((Kb, Cs, k, k), dtype=torch.float32, device=x.device)
+    if tuple(g.shape) != (Kb, Cs, k, k) or g.dtype != torch.float32 or not g.is_contiguous():
+        raise RuntimeError("conv_thin_wrw_mfma: `out` must be a contiguous fp32 %s tensor" % ((Kb, Cs, k, k),))
+    ws = _workspace(nbytes, x.device)
+    _lib.check(L.ipsr_conv_thin_wrw_mfma(big.data_ptr(), small.data_ptr(), g.data_ptr(), B, Kb, Cs, Hb, Wb, k, stride, int(small.dtype == torch.bfloat16),
+                                         ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv_thin_wrw_mfma")
+    return g
+
+
 SM_DATA, SM_WRW, SM_FWD = 0, 1, 2
 
 

@@ -93,5 +93,36 @@ def main():
             print("%-45s | %-4s | %12.4f | %18.4f | %14s | %.2e" % (name, ps, t_thin, t_mi, "%.4f" % t_dir if t_dir else "-", err), flush=True)
 
 
+def wrw_table(B, iters):
+    """Weight gradients of the thin layers: the MFMA kernel (ipsr_conv_thin_wrw_mfma) against aten.convolution_backward on bf16 operands
+    (MIOpen, incl. its transposes; + the fp32 cast of dW)."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(5)
+    print("\nweight gradient (batch %d)                          | MFMA thin ms | MIOpen bf16 ms | vector-ALU thin ms | max err / max |ref|" % B)
+    cases = [("netG first    conv  6 -> 64   k3 s1 @256", False, 6, 64, 256, 3, 1), ("netG last     convT 128 -> 3  k3 s1 @256", True, 128, 3, 256, 3, 1),
+             ("netD / netP   conv  3 -> 64   k4 s2 @256", False, 3, 64, 256, 4, 2), ("netP last     convT 128 -> 3  k4 s2 @128", True, 128, 3, 128, 4, 2)]
+    for name, tr, Cin, Cout, S, k, st in cases:
+        x = (torch.rand(B, Cin, S, S, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        w = torch.randn((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device=dev, generator=g) * 0.1
+        So = (S - 1) * st - 2 + k if tr else (S + 2 - k) // st + 1
+        dy = (torch.rand(B, Cout, So, So, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        wb = w.to(torch.bfloat16)
+
+        def mfma():
+            return ops.conv_thin_wrw_mfma(tr, x, dy, k, st)
+
+        def miopen():
+            return torch.ops.aten.convolution_backward(dy, x, wb, None, [st, st], [1, 1], [1, 1], tr, [0, 0], 1, [False, True, False])[1].float()
+        t_m = timeit(mfma, iters)
+        t_mi = timeit(miopen, iters)
+        t_v = timeit(lambda: ops.conv3x3_thin_wrw(tr, x, dy), iters) if k == 3 else None
+        xd, wd = x[:2].double().cpu(), w.double().cpu().requires_grad_(True)
+        y64 = F.conv_transpose2d(xd, wd, None, st, 1) if tr else F.conv2d(xd, wd, None, st, 1)
+        (ref,) = torch.autograd.grad(y64, (wd,), dy[:2].double().cpu())
+        got = ops.conv_thin_wrw_mfma(tr, x[:2].contiguous(), dy[:2].contiguous(), k, st).double().cpu()
+        print("%-48s | %12.4f | %14.4f | %18s | %.2e" % (name, t_m, t_mi, "%.4f" % t_v if t_v else "-", float((got - ref).abs().max() / ref.abs().max())), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    wrw_table(16, 30)
