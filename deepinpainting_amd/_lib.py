@@ -69,6 +69,8 @@ SIGNATURES = {
     "ipsr_conv3x3_thin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_long, ctypes.c_long, c_int, c_void_p]),
     "ipsr_conv3x3_thin_io": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_long, ctypes.c_long, c_int, c_int, c_void_p]),
     "ipsr_conv3x3_thin_wrw_io": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ipsr_conv_thin_f2m_mfma_supported": (c_int, [c_int] * 7),
+    "ipsr_conv_thin_f2m_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_long, ctypes.c_long, c_int, c_int, c_void_p]),
     "ipsr_conv_thin_wrw_mfma_workspace_bytes": (c_size_t, [c_int] * 7),
     "ipsr_conv_thin_wrw_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ipsr_conv3x3_thin_wrw_workspace_bytes": (c_size_t, [c_int] * 5),

@@ -325,14 +325,13 @@ __global__ void __launch_bounds__(256) thin_wrw_mfma_kernel(const bf16_t* __rest
         for (int rt = 0; rt < RT; ++rt) {
             const int sy = y * st + c_rr[rt] - pad;
             const bool rowok = c_cs[rt] >= 0 && (unsigned)sy < (unsigned)Hs;
-            unsigned short q[8];
+            float q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int sx = (x0 + 8 * h + j) * st + c_ss[rt] - pad;
-                q[j] = f2bf((rowok && (unsigned)sx < (unsigned)Ws) ? lg[buf][rt][j] : 0.0f);      // (exact for a bf16 narrow tensor)
+                q[j] = (rowok && (unsigned)sx < (unsigned)Ws) ? lg[buf][rt][j] : 0.0f;
             }
-            const thin_u32x4 pk = {(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16),
-                                   (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
+            const thin_u32x4 pk = {f2bf2(q[0], q[1]), f2bf2(q[2], q[3]), f2bf2(q[4], q[5]), f2bf2(q[6], q[7])};      // (exact for a bf16 narrow tensor)
             fb[rt] = __builtin_bit_cast(thin_bf16x8, pk);
         }
 #pragma unroll
@@ -409,6 +408,159 @@ __global__ void __launch_bounds__(256) thin_wrw_mfma_reduce_kernel(const float* 
         __syncthreads();
         if (grp == 0 && r < R_real) G[(size_t)kb * R_real + r] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// few -> many on the bf16 matrix cores (BASELINE config 5):
+//      out[b][o][y][x] = sum_{cs < Cs, t < k*k}  Wg(o, cs, t) * in[b][cs][y*st + r - pad][x*st + s - pad]       (+ bias, ReLU)
+// Cs in {3, 6}, (k, st) = (3, 1) or (4, 2), pad 1: VGG conv1_1, netG's first Conv2d, the first Conv2d of netP / netD, and the input
+// gradient of netG's last ConvTranspose2d (Wg = W[o*so + cs*si + (flip ? T-1-t : t)] as in the vector-ALU kernels above, which are VALU-bound
+// at ~40 TF: 90-180 us per layer at batch 16).  GEMM D[o][32 px] = A[o][R] * B[R][32 px] with the reduction R = Cs*k*k (27 / 54 / 48 / 96)
+// padded to KS steps of 16: the A fragments (the whole weight matrix of the workgroup's o tile) live in registers for the workgroup's
+// lifetime, a B fragment is the lane's pixel's window gathered from the narrow tensor (L1 / L2 resident; every load issued from a
+// clamped address and masked afterwards), software-pipelined one tile ahead.  The 32 x 32MT result tile leaves through a per-wave LDS
+// staging area as 16-byte row pieces.  A wave owns a 32-pixel row segment at a time; workgroup = 4 waves = 4 rows.
+template <int MT, int KS, typename TIN, typename TOUT>
+__global__ void __launch_bounds__(256) thin_f2m_mfma_kernel(const TIN* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, int relu,
+                                                            TOUT* __restrict__ out, int B, int Cs, int O, int Hs, int Ws, int Ho, int Wo, int k, int st, int pad,
+                                                            long so, long si, int flip, int rows_per_wg)
+{
+    constexpr int EPW = 32 * MT * 32;                          // result elements per wave tile
+    __shared__ __attribute__((aligned(16))) TOUT stage[4][EPW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, o0 = blockIdx.z * (32 * MT);
+    const int T = k * k, R_real = Cs * T;
+    // A: row o0 + 32 mt + n, reduction entries 16 ks + 8 h + j
+    thin_bf16x8 fa[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            unsigned short q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 16 * ks + 8 * h + j, o = o0 + 32 * mt + n;
+                const int cs = r / T, t = r - cs * T;
+                const bool live = r < R_real && o < O;
+                const float v = w[live ? (long)o * so + (long)cs * si + (flip ? T - 1 - t : t) : 0];
+                q[j] = f2bf(live ? v : 0.0f);
+            }
+            const thin_u32x4 pk = {(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16),
+                                   (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
+            fa[mt][ks] = __builtin_bit_cast(thin_bf16x8, pk);
+        }
+    // B: the lane's window entries of step ks, element j, packed as (narrow channel | tap row << 4 | tap column << 8 | live << 12) once — the
+    // divisions by the runtime tap count do not belong in the tile loop
+    int code[KS][8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 16 * ks + 8 * h + j;
+            const bool live = r < R_real;
+            const int cs = live ? r / T : 0, t = live ? r - cs * T : 0, rr = t / k, ss = t - rr * k;
+            code[ks][j] = cs | (rr << 4) | (ss << 8) | ((live ? 1 : 0) << 12);
+        }
+    const size_t plane_s = (size_t)Hs * Ws, plane_o = (size_t)Ho * Wo;
+    int off[KS][8];                                            // the same entries as address offsets from the pixel's own position (interior tiles)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cd = code[ks][j];
+            off[ks][j] = (cd & 15) * (int)plane_s + (((cd >> 4) & 15) - pad) * Ws + (((cd >> 8) & 15) - pad);
+        }
+    float bv[MT][16];                                          // bias of the lane's result rows
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int o = o0 + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * h;
+            bv[mt][e] = (bias && o < O) ? bias[o] : 0.0f;
+        }
+    const int xsegs = Wo >> 5;
+    int nrows = 0;
+    const int y_lo = blockIdx.x * rows_per_wg;
+    for (int y = y_lo + wave; y < y_lo + rows_per_wg && y < Ho; y += 4) ++nrows;
+    const int ntiles = nrows * xsegs;
+    float lg[2][KS][8];
+    // a tile whose windows all lie inside the image (wave-uniform): plain base + offset loads and no masks
+    auto interior = [&](int y, int x0) {
+        return y * st - pad >= 0 && y * st + (k - 1) - pad < Hs && x0 * st - pad >= 0 && (x0 + 31) * st + (k - 1) - pad < Ws;
+    };
+    auto issue = [&](int i, int buf) {
+        const int y = y_lo + wave + 4 * (i / xsegs), x0 = (i % xsegs) << 5, x = x0 + n;
+        if (interior(y, x0)) {
+            const TIN* base = in + (size_t)b * Cs * plane_s + (size_t)(y * st) * Ws + x * st;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) lg[buf][ks][j] = ld1(base + off[ks][j], 0);
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cd = code[ks][j], cs = cd & 15, rr = (cd >> 4) & 15, ss = (cd >> 8) & 15;
+                const int sy = min(max(y * st + rr - pad, 0), Hs - 1), sx = min(max(x * st + ss - pad, 0), Ws - 1);
+                lg[buf][ks][j] = ld1(in + ((size_t)b * Cs + cs) * plane_s, (size_t)sy * Ws + sx);
+            }
+    };
+    auto consume = [&](int i, int buf) {
+        const int y = y_lo + wave + 4 * (i / xsegs), x0 = (i % xsegs) << 5, x = x0 + n;
+        thin_f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][e] = bv[mt][e];
+        const bool inner = interior(y, x0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cd = code[ks][j], rr = (cd >> 4) & 15, ss = (cd >> 8) & 15;
+                const int sy = y * st + rr - pad, sx = x * st + ss - pad;
+                // (entries beyond the real reduction length meet zero weights; interior tiles need no mask at all)
+                const bool ok = inner || ((unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws);
+                q[j] = ok ? lg[buf][ks][j] : 0.0f;
+            }
+            const thin_u32x4 pk = {f2bf2(q[0], q[1]), f2bf2(q[2], q[3]), f2bf2(q[4], q[5]), f2bf2(q[6], q[7])};
+            const thin_bf16x8 fb = __builtin_bit_cast(thin_bf16x8, pk);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][ks], fb, acc[mt], 0, 0, 0);
+        }
+        // result tile [row o][32 px] through the wave's staging area, out as 16-byte pieces of rows
+        TOUT* L = stage[wave];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[mt][e];
+                if (relu) v = thin_relu(v);
+                st1(L, (size_t)(32 * mt + (e & 3) + 8 * (e >> 2) + 4 * h) * 32 + n, v);
+            }
+        constexpr int PER = 16 / sizeof(TOUT);                 // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
+        constexpr int PPR = 32 / PER;                          // pieces per row
+#pragma unroll
+        for (int c0 = 0; c0 < 32 * MT * PPR; c0 += 64) {
+            const int c = c0 + lane, row = c / PPR, seg = c - row * PPR;
+            const int o = o0 + row;
+            const uint4 v = *reinterpret_cast<const uint4*>(L + (size_t)row * 32 + seg * PER);
+            if (o < O) *reinterpret_cast<uint4*>(out + ((size_t)b * O + o) * plane_o + (size_t)y * Wo + x0 + seg * PER) = v;
+        }
+    };
+    if (ntiles > 0) issue(0, 0);
+    for (int i = 0; i < ntiles; i += 2) {
+        if (i + 1 < ntiles) issue(i + 1, 1);
+        consume(i, 0);
+        if (i + 1 < ntiles) {
+            if (i + 2 < ntiles) issue(i + 2, 0);
+            consume(i + 1, 1);
+        }
     }
 }
 
@@ -632,6 +784,55 @@ int ipsr_conv3x3_thin_wrw_io(const void* big, const void* small, float* g, int B
 int ipsr_conv3x3_thin_wrw(const float* big, const float* small, float* g, int B, int Cb, int Cs, int H, int W, void* ws, size_t ws_bytes, void* stream)
 {
     return ipsr_conv3x3_thin_wrw_io(big, small, g, B, Cb, Cs, H, W, 0, ws, ws_bytes, stream);
+}
+
+// ---- few -> many on the matrix cores --------------------------------------------------------------------------------------------
+static int thin_f2m_mfma_plan(int B, int Cs, int O, int Ho, int Wo, int k, int stride, int* MT, int* KS, int* rows)
+{
+    const bool k3 = k == 3 && stride == 1, k4 = k == 4 && stride == 2;
+    if (B < 1 || O < 1 || Ho < 1 || (Cs != 3 && Cs != 6) || !(k3 || k4) || Wo % 32 != 0 || O % 8 != 0) return 0;
+    *KS = (Cs * k * k + 15) / 16;                             // 2, 4, 3, 6
+    *MT = O >= 128 && *KS <= 4 ? 4 : 2;
+    const int otiles = (O + 32 * *MT - 1) / (32 * *MT);
+    int r = 4;
+    while ((long)B * otiles * ((Ho + r - 1) / r) > 2048 && r < Ho) r *= 2;
+    *rows = r;
+    return otiles;
+}
+
+int ipsr_conv_thin_f2m_mfma_supported(int B, int Cs, int O, int Ho, int Wo, int k, int stride)
+{
+    int MT, KS, rows;
+    return thin_f2m_mfma_plan(B, Cs, O, Ho, Wo, k, stride, &MT, &KS, &rows) > 0;
+}
+
+// in [B,Cs,Ho*stride,Wo*stride] (io bit 0: bf16, else fp32), out [B,O,Ho,Wo] (io bit 1: bf16, else fp32); weight element (o, cs, t) at
+// w[o*so + cs*si + (flip ? k*k-1-t : t)]; bias [O] or NULL, relu 0/1.
+int ipsr_conv_thin_f2m_mfma(const void* in, const float* w, const float* bias, int relu, void* out, int B, int Cs, int O, int Ho, int Wo, int k, int stride,
+                            long so, long si, int flip, int io, void* stream)
+{
+    if (!in || !w || !out || (io & ~3)) return fail(IPSR_ERR_INVALID, "ipsr_conv_thin_f2m_mfma: null pointer / bad io code");
+    int MT, KS, rows;
+    const int otiles = thin_f2m_mfma_plan(B, Cs, O, Ho, Wo, k, stride, &MT, &KS, &rows);
+    if (!otiles) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_thin_f2m_mfma: Cs=%d O=%d %dx%d k%d s%d is not implemented", Cs, O, Ho, Wo, k, stride);
+    if (reinterpret_cast<uintptr_t>(out) & 15u) return fail(IPSR_ERR_INVALID, "ipsr_conv_thin_f2m_mfma: `out` must be 16-byte aligned");
+    if (B > 65535 || otiles > 65535) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_thin_f2m_mfma: grid too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((Ho + rows - 1) / rows, B, otiles);
+    const int Hs = Ho * stride, Ws = Wo * stride;
+    const bool ib = io & 1, ob = io & 2;
+#define THIN_FM(MTT, KSS, TI, TO) thin_f2m_mfma_kernel<MTT, KSS, TI, TO><<<grid, 256, 0, st>>>(static_cast<const TI*>(in), w, bias, relu, static_cast<TO*>(out), \
+                                                                                       B, Cs, O, Hs, Ws, Ho, Wo, k, stride, 1, so, si, flip, rows)
+#define THIN_FM_IO(MTT, KSS) do { if (ib && ob) THIN_FM(MTT, KSS, bf16_t, bf16_t); else if (ib) THIN_FM(MTT, KSS, bf16_t, float); \
+                                  else if (ob) THIN_FM(MTT, KSS, float, bf16_t); else THIN_FM(MTT, KSS, float, float); } while (0)
+    if (MT == 4) {
+        if (KS == 2) THIN_FM_IO(4, 2); else if (KS == 3) THIN_FM_IO(4, 3); else THIN_FM_IO(4, 4);
+    } else {
+        if (KS == 2) THIN_FM_IO(2, 2); else if (KS == 3) THIN_FM_IO(2, 3); else if (KS == 4) THIN_FM_IO(2, 4); else THIN_FM_IO(2, 6);
+    }
+#undef THIN_FM_IO
+#undef THIN_FM
+    return check_launch("thin_f2m_mfma_kernel");
 }
 
 // ---- thin weight gradients on the matrix cores (bf16 wide tensor) ---------------------------------------------------------------

@@ -14,6 +14,7 @@ Three engines per (operation, geometry), chosen by `select()` from measurements 
                                   >= 128 / 64 channels on coarse grids of 16..64
   "thin"      csrc/thin_conv.hip  3x3 stride-1 layers with a 3- or 6-channel side at full resolution (VGG conv1_1, netG's last ConvTranspose2d):
                                   one pass over the wide tensor on the vector ALUs, 1.3-3x MIOpen
+  "thin_f2m"  csrc/thin_conv.hip  Conv2d 3 -> K, k4 s2 p1, forward under bf16 activations: the window gather on the bf16 matrix cores, one launch
   "thin_mfma" csrc/thin_conv.hip  weight gradient of the layers with 3 or 6 channels on the narrow side (k3 s1 p1, k4 s2 p1) under bf16
                                   activations: the pixel reduction on the bf16 matrix cores straight from NCHW, two launches
   "smallmap"  csrc/winograd.hip   the innermost levels: the weight tensor streamed once, 16 bytes per lane straight into MFMA operands —
@@ -115,6 +116,11 @@ def _select_any(op, B, Cin, H, W, Cout, k, stride, pad, dil, bf16):
         return eng
     if _mode() == "auto" and _thin_wins(op, B, Cin, H, W, Cout, k, stride, pad, dil, True):
         return "thin"            # the vector-ALU stream kernels read / write bf16 tensors themselves (ipsr_conv3x3_thin_io)
+    if _mode() == "auto" and _env("IPSR_NO_THIN", "0") != "1" and op == ops.CONV_FWD and Cin == 3 and (k, stride, pad, dil) == (4, 2, 1, 1) and H * W >= 4096 \
+            and ops.thin_f2m_mfma_supported(op, B, Cin, H, W, Cout, k, stride):
+        # the first Conv2d of netP / netD (3 -> 64, k4 s2): the window gather on the matrix cores, 0.041-0.045 vs MIOpen's 0.059 ms and one
+        # launch instead of four (profiles/r04_thin_bf16.txt; for the 3x3 thin layers the vector-ALU kernels and MIOpen stay ahead or level)
+        return "thin_f2m"
     return _bf16_direct(_env("IPSR_BF16_ENGINES", ""), _mode(), op, B, Cin, H, W, Cout, k, stride, pad, dil)
 
 
@@ -394,6 +400,8 @@ class _HipConv(torch.autograd.Function):
             y = ops.conv4x4_dilated_winograd(0, xc, w, (B, Cin, H, W), Cout, geom=ops.conv4x4_geometry(k, stride, pad, dil), math=math, out_dtype=act)
         elif eng_fwd == "thin":
             y = ops.conv3x3_thin(op, xc, w, (B, Cin, H, W), Cout, out_dtype=act)
+        elif eng_fwd == "thin_f2m":
+            y = ops.conv_thin_f2m_mfma(op, xc, w, (B, Cin, H, W), Cout, k, stride, out_dtype=act)
         elif eng_fwd == "one":
             y = ops.conv_to_one(xc.float(), w, pad).to(act)
         elif eng_fwd == "smallmap":
@@ -540,6 +548,8 @@ def conv_nobias(m, x, weight=None):
                                                 math=math, out_dtype=act)
         elif eng == "thin":
             return ops.conv3x3_thin(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, out_dtype=act)
+        elif eng == "thin_f2m":
+            return ops.conv_thin_f2m_mfma(op, x.contiguous(), w.detach(), (B, Cin, H, W), Cout, k, stride, out_dtype=act)
         elif eng == "one":
             return ops.conv_to_one(x.contiguous().float(), w.detach(), pad).to(act)
         elif eng == "smallmap":

@@ -868,6 +868,46 @@ def conv3x3_thin_wrw(transposed, x, dy, out=None):
     raise NotImplementedError("conv3x3_thin_wrw: the weight's first channel dimension must be the wide one (got %s)" % (wshape,))
 
 
+def _thin_f2m_geometry(op, B, Cin, H, W, Cout, k, stride):
+    """(Cs, O, Ho, Wo, so, si, flip) of a few -> many pass in the terms of ipsr_conv_thin_f2m_mfma, or None: Conv2d forward (narrow input
+    -> wide output on the strided grid) and ConvTranspose2d input gradient (narrow dy on the fine grid -> wide dx on the coarse one)."""
+    T = k * k
+    if op == CONV_FWD:
+        if H % stride or W % stride:
+            return None
+        return Cin, Cout, H // stride, W // stride, Cin * T, T, 0
+    if op == CONVT_BWD_DATA:                                   # dx[ci][iy][ix] = sum_{co,t} W[ci][co][t] dy[co][iy*st + r - pad][ix*st + s - pad]
+        return Cout, Cin, H, W, Cout * T, T, 0
+    return None
+
+
+def thin_f2m_mfma_supported(op, B, Cin, H, W, Cout, k, stride):
+    g = _thin_f2m_geometry(op, B, Cin, H, W, Cout, k, stride)
+    return g is not None and bool(_lib.lib().ipsr_conv_thin_f2m_mfma_supported(B, g[0], g[1], g[2], g[3], k, stride))
+
+
+def conv_thin_f2m_mfma(op, inp, weight, in_shape, Cout, k, stride, bias=None, relu=False, out_dtype=torch.bfloat16):
+    """Conv2d forward / ConvTranspose2d input gradient with 3 or 6 channels on the narrow (read) side on the bf16 matrix cores
+    (ipsr_conv_thin_f2m_mfma): k3 s1 p1 or k4 s2 p1.  `in_shape` = the module's input (B, Cin, H, W); `inp` = x (forward) or dy (input
+    gradient), fp32 or bf16 (rounded to bf16 inside); bias / ReLU in fp32; bf16 or fp32 out."""
+    B, Cin, H, W = in_shape
+    inp, in_bf = _act(inp, "input")
+    weight = _req(weight, torch.float32, "weight")
+    g = _thin_f2m_geometry(op, B, Cin, H, W, Cout, k, stride)
+    if g is None or not _lib.lib().ipsr_conv_thin_f2m_mfma_supported(B, g[0], g[1], g[2], g[3], k, stride):
+        raise NotImplementedError("conv_thin_f2m_mfma op %d: Cin=%d Cout=%d %dx%d k%d s%d is not implemented" % (op, Cin, Cout, H, W, k, stride))
+    Cs, O, Ho, Wo, so, si, flip = g
+    want_in = (B, Cs, Ho * stride, Wo * stride)
+    want_w = (Cout, Cin, k, k) if op == CONV_FWD else (Cin, Cout, k, k)
+    if tuple(inp.shape) != want_in or tuple(weight.shape) != want_w:
+        raise RuntimeError("conv_thin_f2m_mfma op %d: input %s / weight %s do not match %s / %s" % (op, tuple(inp.shape), tuple(weight.shape), want_in, want_w))
+    out = torch.empty((B, O, Ho, Wo), dtype=out_dtype, device=inp.device)
+    _lib.check(_lib.lib().ipsr_conv_thin_f2m_mfma(inp.data_ptr(), weight.data_ptr(), _ptr(_f32(bias)) if bias is not None else None, int(bool(relu)),
+                                                  out.data_ptr(), B, Cs, O, Ho, Wo, k, stride, so, si, flip, _io_code(in_bf, out_dtype), _stream()),
+               "ipsr_conv_thin_f2m_mfma")
+    return out
+
+
 def thin_wrw_mfma_supported(transposed, B, Cin, H, W, Cout, k, stride):
     """Weight gradient of a k3 s1 p1 / k4 s2 p1 layer with 3 or 6 channels on its NARROW side on the bf16 matrix cores: the wide side
     must be the weight's first dimension (Conv2d: Cout wide; ConvTranspose2d: Cin wide) and live on the coarse grid."""

@@ -337,6 +337,14 @@ int ipsr_conv3x3_thin_io(int op, const void* in, const float* w, const float* bi
                          long so, long si, int flip, int io, void* stream);
 int ipsr_conv3x3_thin_wrw_io(const void* big, const void* small, float* g, int B, int Cb, int Cs, int H, int W, int io,
                              void* ws, size_t ws_bytes, void* stream);
+/* few -> many on the bf16 matrix cores (BASELINE config 5): out[b][o][y][x] = sum_{cs,t} W[o*so + cs*si + (flip ? k*k-1-t : t)] *
+ * in[b][cs][y*stride + r - 1][x*stride + s - 1] (+ bias, ReLU) — VGG16 conv1_1 (models/vgg16.py:9), netG's first Conv2d and the input
+ * gradient of its last ConvTranspose2d (models/networks.py:255-259,300-312), the first Conv2d of netP / netD (:404-410,470-476).
+ * Cs in {3, 6}; (k, stride) = (3, 1) or (4, 2), padding 1; Wo % 32 == 0, O % 8 == 0.  `io`: bit 0 = `in` bf16 (else fp32), bit 1 = `out`
+ * bf16 (else fp32); operands are rounded to bf16, accumulation / bias / ReLU in fp32.  so / si / flip as in ipsr_conv3x3_thin. */
+int ipsr_conv_thin_f2m_mfma_supported(int B, int Cs, int O, int Ho, int Wo, int k, int stride);
+int ipsr_conv_thin_f2m_mfma(const void* in, const float* w, const float* bias, int relu, void* out, int B, int Cs, int O, int Ho, int Wo, int k, int stride,
+                            long so, long si, int flip, int io, void* stream);
 /* Weight gradient of the thin layers on the bf16 matrix cores (BASELINE config 5):
  *   g[kb][cs][r][s] = sum_{b,y,x} big[b][kb][y][x] * small[b][cs][y*stride + r - 1][x*stride + s - 1]
  * big [B,Kb,Hb,Wb] bf16 = the wide tensor of the pair (x, dy) — dy of a Conv2d, x of a ConvTranspose2d — small [B,Cs,Hb*stride,Wb*stride]

@@ -120,6 +120,7 @@ def test_conv_dispatcher_rules_on_the_host():
     assert sel(ops.CONVT_BWD_DATA, 16, 128, 256, 256, 3, 3, 1, 1, 1, True) == "thin"       # the last ConvTranspose2d's input gradient (3 -> 128)
     assert sel(ops.CONVT_FWD, 16, 128, 256, 256, 3, 3, 1, 1, 1, True) == "bf16d"           # its forward: the direct kernel beats the stream kernel
     assert sel(ops.CONV_FWD, 16, 6, 256, 256, 64, 3, 1, 1, 1, True) == "miopen"            # 6 -> 64: MIOpen is ahead under bf16
+    assert sel(ops.CONV_FWD, 16, 3, 256, 256, 64, 4, 2, 1, 1, True) == "thin_f2m"          # the first Conv2d of netP / netD
     assert sel(ops.CONV_FWD, 16, 64, 256, 256, 64, 4, 2, 3, 2, True) == "miopen"           # the dilated family on large maps
     assert wrw(False, 16, 3, 256, 256, 64, 4, 2, 1, 1, True) == "thin_mfma" and wrw(True, 16, 128, 256, 256, 3, 3, 1, 1, 1, True) == "thin_mfma"   # thin weight gradients
     assert wrw(False, 16, 6, 256, 256, 64, 3, 1, 1, 1, True) == "thin_mfma" and wrw(False, 16, 3, 256, 256, 64, 4, 2, 1, 1) == "miopen"            # (bf16 only)

@@ -363,6 +363,38 @@ def test_thin_weight_gradient_on_the_matrix_cores(kind, Ci, Co, H, W, B, k, st, 
     assert torch.equal(dw, ops.conv_thin_wrw_mfma(tr, xin, dyin, k, st))
 
 
+@pytest.mark.parametrize("kind,Ci,Co,H,W,B,k,st", [("conv", 3, 64, 20, 64, 2, 3, 1), ("conv", 6, 64, 12, 32, 3, 3, 1), ("conv", 3, 64, 32, 64, 2, 4, 2),
+                                                   ("convT", 128, 3, 24, 32, 2, 3, 1), ("convT", 72, 6, 8, 32, 2, 4, 2), ("conv", 3, 24, 8, 32, 1, 3, 1),
+                                                   ("conv", 3, 64, 256, 256, 2, 3, 1), ("conv", 3, 64, 256, 256, 1, 4, 2)])
+@pytest.mark.parametrize("in_bf16,out_bf16", [(False, True), (True, True), (True, False)])
+def test_thin_few_to_many_on_the_matrix_cores(kind, Ci, Co, H, W, B, k, st, in_bf16, out_bf16):
+    """ipsr_conv_thin_f2m_mfma: Conv2d forward (+ bias + ReLU) and ConvTranspose2d input gradient with 3 / 6 channels on the side that is
+    read, k3 s1 p1 and k4 s2 p1, on v_mfma_f32_32x32x16_bf16 — against fp64 on the same bf16-rounded operands: fp32 results within 2e-5
+    of the result's scale, bf16 results within that plus half a bf16 ulp (2^-8)."""
+    from deepinpainting_amd import ops
+    g = torch.Generator().manual_seed(Ci * 5 + H + k)
+    tr = kind == "convT"
+    bf = torch.bfloat16
+    x = torch.randn(B, Ci, H, W, generator=g).cuda()
+    w = (torch.randn((Ci, Co, k, k) if tr else (Co, Ci, k, k), generator=g) * 0.1).cuda()
+    bias = torch.randn(Ci if tr else Co, generator=g).cuda()
+    xd, wd = x.to(bf).double().cpu().requires_grad_(True), w.to(bf).double().cpu()
+    y64 = F.conv_transpose2d(xd, wd, None, st, 1) if tr else F.conv2d(xd, wd, None, st, 1)
+    tol = 2e-5 + (2.0 ** -8 if out_bf16 else 0.0)
+    odt = bf if out_bf16 else torch.float32
+    if tr:
+        dy = torch.randn(y64.shape, generator=g).cuda()
+        (ref,) = torch.autograd.grad(y64, (xd,), dy.to(bf).double().cpu())
+        op, inp = ops.CONVT_BWD_DATA, (dy.to(bf) if in_bf16 else dy)
+    else:
+        ref, op, inp = y64.detach(), ops.CONV_FWD, (x.to(bf) if in_bf16 else x)
+    assert ops.thin_f2m_mfma_supported(op, B, Ci, H, W, Co, k, st)
+    y = ops.conv_thin_f2m_mfma(op, inp, w, (B, Ci, H, W), Co, k, st, out_dtype=odt)
+    assert y.dtype == odt and tuple(y.shape) == tuple(ref.shape) and _rel(y.float(), ref) <= tol
+    yb = ops.conv_thin_f2m_mfma(op, inp, w, (B, Ci, H, W), Co, k, st, bias=bias, relu=True, out_dtype=odt)
+    assert _rel(yb.float(), torch.relu(ref + bias.double().cpu().view(1, -1, 1, 1))) <= tol
+
+
 # ---- the training step's OWN shapes (BASELINE config 2: batch 8, 256x256) ------------------------------------------------------
 # (module, input H=W): the layers the step spends its time in, every Winograd family, all three passes.  References: the same
 # module in fp64 on the GPU (torch's native convolution) AND MIOpen fp32 on the same tensors.

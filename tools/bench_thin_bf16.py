@@ -123,6 +123,42 @@ def wrw_table(B, iters):
         print("%-48s | %12.4f | %14.4f | %18s | %.2e" % (name, t_m, t_mi, "%.4f" % t_v if t_v else "-", float((got - ref).abs().max() / ref.abs().max())), flush=True)
 
 
+def f2m_table(B, iters):
+    """few -> many on the matrix cores (ipsr_conv_thin_f2m_mfma) against the vector-ALU kernel and MIOpen under autocast."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(9)
+    print("\nfew -> many (batch %d)                              | MFMA thin ms | vector-ALU thin ms | MIOpen autocast ms" % B)
+    cases = [("VGG conv1_1   conv  3 -> 64  k3 s1 @256 +bias,ReLU", ops.CONV_FWD, 3, 64, 256, 3, 1, torch.float32, True),
+             ("netG first    conv  6 -> 64  k3 s1 @256", ops.CONV_FWD, 6, 64, 256, 3, 1, torch.float32, False),
+             ("netD / netP   conv  3 -> 64  k4 s2 @256", ops.CONV_FWD, 3, 64, 256, 4, 2, torch.float32, False),
+             ("netG last     convT 128 -> 3 k3 s1 @256 input gradient", ops.CONVT_BWD_DATA, 128, 3, 256, 3, 1, torch.bfloat16, False)]
+    for name, op, Cin, Cout, S, k, st, idt, fused in cases:
+        tr = op == ops.CONVT_BWD_DATA
+        w = torch.randn((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device=dev, generator=g) * 0.1
+        bias = torch.randn(Cout, device=dev, generator=g) * 0.1
+        inp = (torch.rand(B, Cout if tr else Cin, S, S, device=dev, generator=g) * 2 - 1).to(idt)
+        xb = (torch.rand(B, Cin, S, S, device=dev, generator=g)).to(torch.bfloat16) if tr else None
+        wb = w.to(torch.bfloat16)
+
+        def mfma():
+            return ops.conv_thin_f2m_mfma(op, inp, w, (B, Cin, S, S), Cout, k, st, bias=bias if fused else None, relu=fused)
+
+        def valu():
+            return ops.conv3x3_thin(op, inp, w, (B, Cin, S, S), Cout, bias=bias if fused else None, relu=fused, out_dtype=torch.bfloat16)
+
+        def miopen():
+            if tr:
+                return torch.ops.aten.convolution_backward(inp, xb, wb, None, [st, st], [1, 1], [1, 1], True, [0, 0], 1, [True, False, False])[0]
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = F.conv2d(inp, w, None, st, 1)
+            return ops.bias_act_(y, bias, "relu") if fused else y
+        t_m = timeit(mfma, iters)
+        t_v = timeit(valu, iters) if k == 3 else None
+        t_mi = timeit(miopen, iters)
+        print("%-60s | %12.4f | %18s | %18.4f" % (name, t_m, "%.4f" % t_v if t_v else "-", t_mi), flush=True)
+
+
 if __name__ == "__main__":
     main()
     wrw_table(16, 30)
+    f2m_table(16, 30)
