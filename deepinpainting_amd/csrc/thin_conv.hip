@@ -257,8 +257,11 @@ typedef __bf16 thin_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float thin_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned thin_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MT, int RT, typename TS>
-__global__ void __launch_bounds__(256) thin_wrw_mfma_kernel(const bf16_t* __restrict__ big, const TS* __restrict__ small, float* __restrict__ slabs,
+// TB = float: the same reduction in the reference's own arithmetic on v_mfma_f32_32x32x2_f32 (fp32 operands, eight matrix instructions per
+// 16 pixels: lane half h holds pixels 8h .. 8h+7 of the step, instruction i multiplies pixels i and 8 + i) — the fp32 training step's thin
+// weight gradients (MIOpen: 0.14-0.23 ms each at batch 8).
+template <int MT, int RT, typename TB, typename TS>
+__global__ void __launch_bounds__(256) thin_wrw_mfma_kernel(const TB* __restrict__ big, const TS* __restrict__ small, float* __restrict__ slabs,
                                                             int B, int Kb, int Cs, int Hb, int Wb, int Hs, int Ws, int k, int st, int pad, int rows_per_wg)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -291,14 +294,18 @@ __global__ void __launch_bounds__(256) thin_wrw_mfma_kernel(const bf16_t* __rest
     int nrows = 0;
     for (int y = y_lo + wave; y < y_lo + rows_per_wg && y < Hb; y += 4) ++nrows;
     const int nsteps = nrows * xsteps;
-    thin_u32x4 la[2][MT];
+    constexpr bool F32 = !thin_is_bf16<TB>::value;
+    constexpr int NA = F32 ? 2 : 1;                            // 16-byte vectors of `big` per lane and step: 8 pixels
+    thin_u32x4 la[2][MT][NA];
     float lg[2][RT][8];
     auto issue = [&](int i, int buf) {
         const int y = y_lo + wave + 4 * (i / xsteps), x0 = (i % xsteps) << 4;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int kb = min(k0 + 32 * mt + n, Kb - 1);                  // rows beyond Kb are masked when consumed
-            la[buf][mt] = *reinterpret_cast<const thin_u32x4*>(big + ((size_t)b * Kb + kb) * plane_b + (size_t)y * Wb + x0 + 8 * h);
+            const thin_u32x4* src = reinterpret_cast<const thin_u32x4*>(big + ((size_t)b * Kb + kb) * plane_b + (size_t)y * Wb + x0 + 8 * h);
+#pragma unroll
+            for (int v = 0; v < NA; ++v) la[buf][mt][v] = src[v];
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -315,29 +322,44 @@ __global__ void __launch_bounds__(256) thin_wrw_mfma_kernel(const bf16_t* __rest
     };
     auto consume = [&](int i, int buf) {
         const int y = y_lo + wave + 4 * (i / xsteps), x0 = (i % xsteps) << 4;
-        thin_bf16x8 fa[MT], fb[RT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const thin_u32x4 z = {0u, 0u, 0u, 0u};
-            fa[mt] = __builtin_bit_cast(thin_bf16x8, (k0 + 32 * mt + n < Kb) ? la[buf][mt] : z);
-        }
+        float q[RT][8];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int sy = y * st + c_rr[rt] - pad;
             const bool rowok = c_cs[rt] >= 0 && (unsigned)sy < (unsigned)Hs;
-            float q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int sx = (x0 + 8 * h + j) * st + c_ss[rt] - pad;
-                q[j] = (rowok && (unsigned)sx < (unsigned)Ws) ? lg[buf][rt][j] : 0.0f;
+                q[rt][j] = (rowok && (unsigned)sx < (unsigned)Ws) ? lg[buf][rt][j] : 0.0f;
             }
-            const thin_u32x4 pk = {f2bf2(q[0], q[1]), f2bf2(q[2], q[3]), f2bf2(q[4], q[5]), f2bf2(q[6], q[7])};      // (exact for a bf16 narrow tensor)
-            fb[rt] = __builtin_bit_cast(thin_bf16x8, pk);
         }
+        const thin_u32x4 z = {0u, 0u, 0u, 0u};
+        if constexpr (F32) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool live = k0 + 32 * mt + n < Kb;
+                const thin_u32x4 v0 = live ? la[buf][mt][0] : z, v1 = live ? la[buf][mt][NA - 1] : z;
+                const float a8[8] = {__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z), __uint_as_float(v0.w),
+                                     __uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z), __uint_as_float(v1.w)};
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[rt], acc[mt][rt], 0, 0, 0);
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[mt][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a8[i], q[rt][i], acc[mt][rt], 0, 0, 0);
+            }
+        } else {
+            thin_bf16x8 fa[MT], fb[RT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[mt] = __builtin_bit_cast(thin_bf16x8, (k0 + 32 * mt + n < Kb) ? la[buf][mt][0] : z);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const thin_u32x4 pk = {f2bf2(q[rt][0], q[rt][1]), f2bf2(q[rt][2], q[rt][3]), f2bf2(q[rt][4], q[rt][5]), f2bf2(q[rt][6], q[rt][7])};      // (exact for a bf16 narrow tensor)
+                fb[rt] = __builtin_bit_cast(thin_bf16x8, pk);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[rt], acc[mt][rt], 0, 0, 0);
+        }
     };
     if (nsteps > 0) issue(0, 0);
     for (int i = 0; i < nsteps; i += 2) {                      // two steps per trip: the buffer index is a compile-time constant
@@ -862,11 +884,15 @@ size_t ipsr_conv_thin_wrw_mfma_workspace_bytes(int B, int Kb, int Cs, int Hb, in
     return align_up((size_t)ktiles * B * gx * (32 * MT) * (32 * RT) * sizeof(float), 256) + 256;
 }
 
-// big [B,Kb,Hb,Wb] bf16; small [B,Cs,Hs,Ws] fp32 (small_bf16 = 0) or bf16, Hs = Hb (k3 s1 p1) or 2 Hb (k4 s2 p1); g [Kb][Cs][k][k] fp32.
-int ipsr_conv_thin_wrw_mfma(const void* big, const void* small, float* g, int B, int Kb, int Cs, int Hb, int Wb, int k, int stride, int small_bf16,
+// big [B,Kb,Hb,Wb], small [B,Cs,Hs,Ws], Hs = Hb (k3 s1 p1) or 2 Hb (k4 s2 p1); g [Kb][Cs][k][k] fp32.  io: bit 0 = `big` is bf16, bit 1 =
+// `small` is bf16.  A bf16 `big` multiplies on the bf16 matrix cores (an fp32 `small` is rounded to bf16); an fp32 `big` (with an fp32
+// `small`) multiplies in fp32 on v_mfma_f32_32x32x2_f32 — the reference's arithmetic.
+int ipsr_conv_thin_wrw_mfma(const void* big, const void* small, float* g, int B, int Kb, int Cs, int Hb, int Wb, int k, int stride, int io,
                             void* ws, size_t ws_bytes, void* stream)
 {
-    if (!big || !small || !g || !ws) return fail(IPSR_ERR_INVALID, "ipsr_conv_thin_wrw_mfma: null pointer");
+    if (!big || !small || !g || !ws || (io & ~3)) return fail(IPSR_ERR_INVALID, "ipsr_conv_thin_wrw_mfma: null pointer / bad io code");
+    if (io == 2) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_thin_wrw_mfma: an fp32 wide tensor needs an fp32 narrow one");
+    const int small_bf16 = (io >> 1) & 1, big_bf16 = io & 1;
     int MT, RT, rows, gx;
     const int ktiles = thin_wrw_mfma_plan(B, Kb, Cs, Hb, Wb, k, stride, &MT, &RT, &rows, &gx);
     if (!ktiles) return fail(IPSR_ERR_UNSUPPORTED, "ipsr_conv_thin_wrw_mfma: Kb=%d Cs=%d %dx%d k%d s%d is not implemented", Kb, Cs, Hb, Wb, k, stride);
@@ -878,9 +904,10 @@ int ipsr_conv_thin_wrw_mfma(const void* big, const void* small, float* g, int B,
     float* slabs = static_cast<float*>(ws);
     const int Hs = Hb * stride, Ws = Wb * stride, pad = 1;
     const dim3 grid(gx, B, ktiles);
-#define THIN_WM(MTT, RTT, TSM) thin_wrw_mfma_kernel<MTT, RTT, TSM><<<grid, 256, 0, st>>>(static_cast<const bf16_t*>(big), static_cast<const TSM*>(small), slabs, \
-                                                                                  B, Kb, Cs, Hb, Wb, Hs, Ws, k, stride, pad, rows)
-#define THIN_WM_TS(MTT, RTT) do { if (small_bf16) THIN_WM(MTT, RTT, bf16_t); else THIN_WM(MTT, RTT, float); } while (0)
+#define THIN_WM(MTT, RTT, TBG, TSM) thin_wrw_mfma_kernel<MTT, RTT, TBG, TSM><<<grid, 256, 0, st>>>(static_cast<const TBG*>(big), static_cast<const TSM*>(small), slabs, \
+                                                                                            B, Kb, Cs, Hb, Wb, Hs, Ws, k, stride, pad, rows)
+#define THIN_WM_TS(MTT, RTT) do { if (!big_bf16) THIN_WM(MTT, RTT, float, float); else if (small_bf16) THIN_WM(MTT, RTT, bf16_t, bf16_t); \
+                                  else THIN_WM(MTT, RTT, bf16_t, float); } while (0)
     if (MT == 4 && RT == 1) THIN_WM_TS(4, 1);
     else if (MT == 4 && RT == 2) THIN_WM_TS(4, 2);
     else if (RT == 1) THIN_WM_TS(2, 1);

@@ -305,12 +305,14 @@ def select_wrw(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16=False):
 
 def _select_wrw_any(transposed, B, Cin, H, W, Cout, k, stride, pad, dil, bf16):
     eng = _select_wrw(_mode(), _env("IPSR_NO_SMALLMAP", "0"), transposed, B, Cin, H, W, Cout, k, stride, pad, dil)
+    thin = _mode() == "auto" and _env("IPSR_NO_THIN", "0") != "1" and pad == 1 and dil == 1 and (k, stride) in ((3, 1), (4, 2)) and H * W >= 4096 \
+        and ops.thin_wrw_mfma_supported(transposed, B, Cin, H, W, Cout, k, stride)
     if not bf16:
-        return eng
+        # fp32 activations: the same pixel reduction on v_mfma_f32_32x32x2_f32 (profiles/r04_thin_fp32.txt, batch 8)
+        return "thin_mfma" if thin and eng == "miopen" else eng
     if _bf16_wins(eng, Cin, H, W, Cout, True) or eng in _CAST_ENGINES:
         return eng
-    if _mode() == "auto" and _env("IPSR_NO_THIN", "0") != "1" and pad == 1 and dil == 1 and (k, stride) in ((3, 1), (4, 2)) and H * W >= 4096 \
-            and ops.thin_wrw_mfma_supported(transposed, B, Cin, H, W, Cout, k, stride):
+    if thin:
         # 3 / 6 channels on the narrow side: the pixel reduction on the bf16 matrix cores straight from NCHW (profiles/r04_thin_bf16.txt, batch 16:
         # 3 -> 64 k4 s2 0.033 vs MIOpen's 0.057 ms, ConvT 128 -> 3 k3 0.152 vs 0.202, k4 s2 0.052 vs 0.063, 6 -> 64 0.118 vs 0.125 — and 2
         # launches instead of MIOpen's 5-6)
@@ -457,7 +459,8 @@ class _HipConv(torch.autograd.Function):
         if weng == "winograd":
             dw = ops.conv3x3_winograd_wrw(transposed, xw, dy, Cout, out=sink, math=math)
         elif weng == "thin_mfma":
-            dw = ops.conv_thin_wrw_mfma(transposed, (x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)) if transposed else x, dy, k, stride, out=sink)
+            xa = x.to(torch.bfloat16) if (bf16 and transposed and x.dtype != torch.bfloat16) else x       # the WIDE tensor decides the arithmetic
+            dw = ops.conv_thin_wrw_mfma(transposed, xa, dy, k, stride, out=sink)
         elif weng == "bf16d" and k == 3:
             dw = ops.conv3x3_bf16_wrw(transposed, xw, dy, Cout, out=sink)
         elif weng == "bf16d":

@@ -921,13 +921,13 @@ def thin_wrw_mfma_supported(transposed, B, Cin, H, W, Cout, k, stride):
 
 
 def conv_thin_wrw_mfma(transposed, x, dy, k, stride, out=None):
-    """-> dW (fp32, the module's layout) of a thin Conv2d / ConvTranspose2d under bf16 activations (ipsr_conv_thin_wrw_mfma).  The wide
-    tensor of (x, dy) must be bf16; the narrow one may be fp32 (it is rounded to bf16 inside, as autocast's cast would)."""
+    """-> dW (fp32, the module's layout) of a thin Conv2d / ConvTranspose2d on the matrix cores (ipsr_conv_thin_wrw_mfma).  A bf16 wide
+    tensor multiplies in bf16 (the narrow one may be fp32: it is rounded inside, as autocast's cast would); fp32 tensors multiply in fp32."""
     x, _ = _act(x, "x")
     dy, _ = _act(dy, "dy")
     big, small = (x, dy) if transposed else (dy, x)
-    if big.dtype != torch.bfloat16:
-        raise TypeError("conv_thin_wrw_mfma reads the wide tensor as bf16, got %s" % big.dtype)
+    if big.dtype == torch.float32 and small.dtype != torch.float32:
+        raise TypeError("conv_thin_wrw_mfma: an fp32 wide tensor needs an fp32 narrow one")
     B, Kb, Hb, Wb = big.shape
     Cs = small.shape[1]
     if tuple(small.shape) != (B, Cs, Hb * stride, Wb * stride):
@@ -940,7 +940,7 @@ def conv_thin_wrw_mfma(transposed, x, dy, k, stride, out=None):
     if tuple(g.shape) != (Kb, Cs, k, k) or g.dtype != torch.float32 or not g.is_contiguous():
         raise RuntimeError("conv_thin_wrw_mfma: `out` must be a contiguous fp32 %s tensor" % ((Kb, Cs, k, k),))
     ws = _workspace(nbytes, x.device)
-    _lib.check(L.ipsr_conv_thin_wrw_mfma(big.data_ptr(), small.data_ptr(), g.data_ptr(), B, Kb, Cs, Hb, Wb, k, stride, int(small.dtype == torch.bfloat16),
+    _lib.check(L.ipsr_conv_thin_wrw_mfma(big.data_ptr(), small.data_ptr(), g.data_ptr(), B, Kb, Cs, Hb, Wb, k, stride, int(big.dtype == torch.bfloat16) | (2 if small.dtype == torch.bfloat16 else 0),
                                          ws.data_ptr(), ws.numel(), _stream()), "ipsr_conv_thin_wrw_mfma")
     return g
 

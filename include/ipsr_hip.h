@@ -345,14 +345,16 @@ int ipsr_conv3x3_thin_wrw_io(const void* big, const void* small, float* g, int B
 int ipsr_conv_thin_f2m_mfma_supported(int B, int Cs, int O, int Ho, int Wo, int k, int stride);
 int ipsr_conv_thin_f2m_mfma(const void* in, const float* w, const float* bias, int relu, void* out, int B, int Cs, int O, int Ho, int Wo, int k, int stride,
                             long so, long si, int flip, int io, void* stream);
-/* Weight gradient of the thin layers on the bf16 matrix cores (BASELINE config 5):
+/* Weight gradient of the thin layers on the matrix cores:
  *   g[kb][cs][r][s] = sum_{b,y,x} big[b][kb][y][x] * small[b][cs][y*stride + r - 1][x*stride + s - 1]
- * big [B,Kb,Hb,Wb] bf16 = the wide tensor of the pair (x, dy) — dy of a Conv2d, x of a ConvTranspose2d — small [B,Cs,Hb*stride,Wb*stride]
- * fp32 or bf16 (`small_bf16`; rounded to bf16 inside either way), Cs in {3, 6}; (k, stride) = (3, 1) or (4, 2), padding 1; Wb % 16 == 0.
- * g fp32 in the module's own weight layout: Conv2d [Cout=Kb][Cin=Cs][k][k] (models/networks.py:300-312,404-410,470-476),
- * ConvTranspose2d [Cin=Kb][Cout=Cs][k][k] (:255-259,424-432).  Fixed summation order.  0 workspace bytes = not implemented. */
+ * big [B,Kb,Hb,Wb] = the wide tensor of the pair (x, dy) — dy of a Conv2d, x of a ConvTranspose2d — small [B,Cs,Hb*stride,Wb*stride],
+ * Cs in {3, 6}; (k, stride) = (3, 1) or (4, 2), padding 1; Wb % 16 == 0.  `io`: bit 0 = big is bf16, bit 1 = small is bf16.  bf16 big:
+ * v_mfma_f32_32x32x16_bf16, an fp32 small is rounded to bf16 (BASELINE config 5); fp32 big + fp32 small: v_mfma_f32_32x32x2_f32, the
+ * reference's arithmetic (config 2).  g fp32 in the module's own weight layout: Conv2d [Cout=Kb][Cin=Cs][k][k]
+ * (models/networks.py:300-312,404-410,470-476), ConvTranspose2d [Cin=Kb][Cout=Cs][k][k] (:255-259,424-432).  Fixed summation order.
+ * 0 workspace bytes = not implemented. */
 size_t ipsr_conv_thin_wrw_mfma_workspace_bytes(int B, int Kb, int Cs, int Hb, int Wb, int k, int stride);
-int ipsr_conv_thin_wrw_mfma(const void* big, const void* small, float* g, int B, int Kb, int Cs, int Hb, int Wb, int k, int stride, int small_bf16,
+int ipsr_conv_thin_wrw_mfma(const void* big, const void* small, float* g, int B, int Kb, int Cs, int Hb, int Wb, int k, int stride, int io,
                             void* ws, size_t ws_bytes, void* stream);
 /* ipsr_conv_to_one: nn.Conv2d(C, 1, K, stride 1, padding pad) — netD's last layer (models/networks.py:489-495, 512 -> 1, k4 p1 on
  * 31x31) — as one pass over the input (252 MFLOP against 31.5 MB: a stream).  x [B,C,H,W] fp32, K in {3, 4}.

@@ -123,7 +123,8 @@ def test_conv_dispatcher_rules_on_the_host():
     assert sel(ops.CONV_FWD, 16, 3, 256, 256, 64, 4, 2, 1, 1, True) == "thin_f2m"          # the first Conv2d of netP / netD
     assert sel(ops.CONV_FWD, 16, 64, 256, 256, 64, 4, 2, 3, 2, True) == "miopen"           # the dilated family on large maps
     assert wrw(False, 16, 3, 256, 256, 64, 4, 2, 1, 1, True) == "thin_mfma" and wrw(True, 16, 128, 256, 256, 3, 3, 1, 1, 1, True) == "thin_mfma"   # thin weight gradients
-    assert wrw(False, 16, 6, 256, 256, 64, 3, 1, 1, 1, True) == "thin_mfma" and wrw(False, 16, 3, 256, 256, 64, 4, 2, 1, 1) == "miopen"            # (bf16 only)
+    assert wrw(False, 16, 6, 256, 256, 64, 3, 1, 1, 1, True) == "thin_mfma" and wrw(False, 8, 3, 256, 256, 64, 4, 2, 1, 1) == "thin_mfma"           # fp32 too (fp32 MFMA)
+    assert wrw(True, 8, 128, 256, 256, 3, 3, 1, 1, 1) == "thin_mfma" and wrw(False, 8, 3, 32, 32, 64, 4, 2, 1, 1) == "miopen"                       # (small maps: MIOpen)
     assert ops.conv3x3_bf16_supported(ops.CONV_FWD, 2, 32, 16, 16, 48)                     # <= 64 produced channels on a map too small for 512-pixel tiles
     # the selection is memoised per shape and per forced mode; the A/B switches are read from the environment once (reload_env re-reads)
     was = hipconv._FORCE

@@ -338,25 +338,28 @@ def test_thin_3x3_layers_on_bf16_tensors(kind, Ci, Co, H, W, B, in_bf16, out_bf1
 @pytest.mark.parametrize("kind,Ci,Co,H,W,B,k,st", [("conv", 6, 64, 20, 48, 3, 3, 1), ("conv", 3, 64, 32, 64, 2, 4, 2), ("convT", 128, 3, 24, 32, 2, 3, 1),
                                                    ("convT", 128, 3, 16, 32, 2, 4, 2), ("conv", 3, 16, 8, 16, 1, 3, 1), ("convT", 72, 6, 12, 16, 2, 4, 2),
                                                    ("conv", 3, 64, 256, 256, 2, 4, 2)])
-@pytest.mark.parametrize("small_bf16", [False, True])
+@pytest.mark.parametrize("small_bf16", [False, True, None])
 def test_thin_weight_gradient_on_the_matrix_cores(kind, Ci, Co, H, W, B, k, st, small_bf16):
     """ipsr_conv_thin_wrw_mfma: dW of the k3 s1 p1 / k4 s2 p1 layers with 3 or 6 channels on the narrow side, reduction over pixels on
-    v_mfma_f32_32x32x16_bf16 — against the fp64 autograd gradient of the module on the SAME bf16-rounded operands: within 2e-5 of the
+    v_mfma_f32_32x32x16_bf16 (bf16 wide tensor) or v_mfma_f32_32x32x2_f32 (fp32 tensors) — against the fp64 autograd gradient of the module on
+    the SAME operands (bf16-rounded in the bf16 cases): within 2e-5 of the
     gradient's scale (fp32 accumulation of up to 131072 products per entry), and the same bits on a second call (fixed summation order)."""
     from deepinpainting_amd import ops
     g = torch.Generator().manual_seed(Ci * 7 + H + k)
     tr = kind == "convT"
     bf = torch.bfloat16
+    fp32 = small_bf16 is None                     # third case: both tensors fp32, multiplied in fp32 (v_mfma_f32_32x32x2_f32, BASELINE config 2)
+    rnd = (lambda t: t) if fp32 else (lambda t: t.to(bf))
     x = torch.randn(B, Ci, H, W, generator=g).cuda()
     w = (torch.randn((Ci, Co, k, k) if tr else (Co, Ci, k, k), generator=g) * 0.1).cuda()
-    xd, wd = x.to(bf).double().cpu(), w.double().cpu().requires_grad_(True)
+    xd, wd = rnd(x).double().cpu(), w.double().cpu().requires_grad_(True)
     y64 = F.conv_transpose2d(xd, wd, None, st, 1) if tr else F.conv2d(xd, wd, None, st, 1)
     dy = torch.randn(y64.shape, generator=g).cuda()
-    (dw64,) = torch.autograd.grad(y64, (wd,), dy.to(bf).double().cpu())
+    (dw64,) = torch.autograd.grad(y64, (wd,), rnd(dy).double().cpu())
     assert ops.thin_wrw_mfma_supported(tr, B, Ci, H, W, Co, k, st)
-    # the wide tensor is bf16; the narrow one bf16 or fp32 (rounded inside)
-    xin = x.to(bf) if (tr or small_bf16) else x
-    dyin = dy.to(bf) if (not tr or small_bf16) else dy
+    # bf16 cases: the wide tensor is bf16; the narrow one bf16 or fp32 (rounded inside)
+    xin = x if fp32 else (x.to(bf) if (tr or small_bf16) else x)
+    dyin = dy if fp32 else (dy.to(bf) if (not tr or small_bf16) else dy)
     dw = ops.conv_thin_wrw_mfma(tr, xin, dyin, k, st)
     assert dw.dtype == torch.float32 and tuple(dw.shape) == tuple(w.shape)
     assert _rel(dw, dw64) <= 2e-5
