@@ -462,8 +462,8 @@ def main():
     ap.add_argument("--ddp-bucket-mb", type=int, default=64, help="gradient bucket size of the all-reduce (dist.GradBucketReducer)")
     ap.add_argument("--graph", choices=("on", "off"), default="off",
                     help="on: replay the training step from one HIP graph (deepinpainting_amd/stepgraph.py, one GPU only) instead of queueing its "
-                         "~1100-1400 kernels from Python every step.  Off by default: measured at --dtype bf16 --batch 16 the replay takes 22.5 ms "
-                         "against 21.7 ms for the eager step (hipGraphLaunch orders its ~1400 nodes one by one), although it frees the host "
+                         "~1100-1400 kernels from Python every step.  Off by default: measured at --dtype bf16 --batch 16 the replay takes 22.0 ms "
+                         "against 21.2 ms for the eager step (hipGraphLaunch orders its ~1400 nodes one by one), although it frees the host "
                          "(0.4 ms instead of 21.9 ms of queueing per step)")
     args = ap.parse_args()
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
