@@ -71,6 +71,7 @@ struct CbGeom {
     int ktiles, ptiles, nstage; // ceil(K / 128), B * Hl / R, (C / 16) * nsub
     int a_bytes, t_bytes, raw_bytes, raw1;      // LDS plan: stage sizes, one raw buffer instead of two
     int kt, ptile;              // produced channels per workgroup tile: 128, or 64 when K <= 64; pixels per tile: 256, or 512 (64-row kernel)
+    int nsplit, sps;            // reduction split (small maps: too few tiles to fill the chip): runs of `sps` stages, fp32 partials added by a second launch
 };
 
 // packed weights: Wp[kt][phase][cb][sub][t][cg][k & 127][c & 7] bf16 (zero for k >= K); source element (k, c, tap) at w[c * sc + k * sk + srctap]
@@ -123,9 +124,12 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
 
     // tile: all (k tile, row phase) workgroups of one pixel tile are neighbours (they share the activation tile in L2)
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_pt = g.ktiles * g.nphase;
-    const int pt = L / per_pt, kp = L - pt * per_pt;
+    const int per_pt = g.ktiles * g.nphase * g.nsplit;
+    const int pt = L / per_pt, kps = L - pt * per_pt;
+    const int split = kps % g.nsplit, kp = kps / g.nsplit;
     const int kt = kp % g.ktiles, phase = kp / g.ktiles;
+    const int s_lo = split * g.sps, s_hi = min(g.nstage, s_lo + g.sps);        // this workgroup's run of stages (the whole reduction unless split)
+    out += (size_t)split * g.B * g.K * g.Hout * g.Wout;                         // split runs write their own fp32 partial
     const int tiles_per_img = g.Hl / g.R;
     const int b = pt / tiles_per_img, y0 = (pt - b * tiles_per_img) * g.R;
 
@@ -225,23 +229,23 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
     for (int i = tid; i < 2 * (g.t_bytes / 16); i += CB_THREADS)
         *reinterpret_cast<uint4*>(lds + t_base + i * 16) = make_uint4(0u, 0u, 0u, 0u);
     // prologue: A[0], raw[0] <- stage 0; raw[1] <- stage 1 (two raw buffers)
-    dma_a(0, 0);
-    dma_x(0, 0);
-    if (!g.raw1 && g.nstage > 1) dma_x(1, 1);
+    dma_a(0, s_lo);
+    dma_x(0, s_lo);
+    if (!g.raw1 && s_lo + 1 < s_hi) dma_x(1, s_lo + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     transpose(0, 0);
     __syncthreads();
 
-    for (int s = 0; s < g.nstage; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
+    for (int s = s_lo; s < s_hi; ++s) {
+        const int cur = (s - s_lo) & 1, nxt = cur ^ 1;
         // The transposition goes first: hipcc drains every LDS-DMA in flight (s_waitcnt vmcnt(0)) before a ds_read_b64_tr_b16, so a
         // DMA issued ahead of it would be waited for here instead of behind the multiplications.
-        if (!g.raw1 && s + 1 < g.nstage) transpose(nxt, nxt);  // raw[nxt] (stage s+1) landed before the barrier that ended stage s-1
-        if (s + 1 < g.nstage) dma_a(nxt, s + 1);               // A[nxt] was last read in stage s-1
+        if (!g.raw1 && s + 1 < s_hi) transpose(nxt, nxt);      // raw[nxt] (stage s+1) landed before the barrier that ended stage s-1
+        if (s + 1 < s_hi) dma_a(nxt, s + 1);                   // A[nxt] was last read in stage s-1
         if (!g.raw1) {
-            if (s + 2 < g.nstage) dma_x(cur, s + 2);           // raw[cur] was transposed in stage s-1
-        } else if (s + 1 < g.nstage) {
+            if (s + 2 < s_hi) dma_x(cur, s + 2);               // raw[cur] was transposed in stage s-1
+        } else if (s + 1 < s_hi) {
             dma_x(0, s + 1);                                   // the one raw buffer was transposed at the end of stage s-1
         }
         const unsigned char* A = lds + cur * g.a_bytes + a_off;
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(CB_THREADS, 1) conv_bf16_kernel(const unsigned
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this stage's DMAs are the next stage's operands
         __syncthreads();
-        if (g.raw1 && s + 1 < g.nstage) {                      // one raw buffer: the next stage's tile crosses LDS now, behind the multiplications
+        if (g.raw1 && s + 1 < s_hi) {                          // one raw buffer: the next stage's tile crosses LDS now, behind the multiplications
             transpose(0, nxt);
             __syncthreads();
         }
@@ -364,6 +368,16 @@ static int cb_finish(CbGeom* g, const char* who)
     g->ktiles = (g->K + g->kt - 1) / g->kt;
     g->ptiles = g->B * (g->Hl / g->R);
     g->nstage = (g->C / CB_C) * g->nsub;
+    // Small maps leave the chip idle (a 16x16 map is ONE pixel tile per image: 64 workgroups at 512 produced channels and batch 16): the
+    // reduction is cut into up to four runs of whole channel blocks, each run a workgroup of its own writing an fp32 partial.
+    {
+        const int wgs = g->ktiles * g->nphase * g->ptiles, nblocks = g->C / CB_C;
+        int ns = 1;
+        if (wgs < 128 && nblocks >= 8) ns = min(min(4, nblocks / 4), (256 + wgs - 1) / wgs);
+        const int bps = (nblocks + ns - 1) / max(ns, 1);      // channel blocks per run
+        g->nsplit = (nblocks + bps - 1) / bps;
+        g->sps = bps * g->nsub;
+    }
     const int planes = g->nsub;                               // F2C keeps the two column phases
     g->a_bytes = g->ntap * 2 * g->kt * 16;
     g->t_bytes = (int)align_up((size_t)planes * 2 * g->NPOS * 16, 256);
@@ -438,18 +452,35 @@ static int cb_geometry_s2_p(int form, int B, int C, int K, int nh, int nw, int p
     return cb_finish(g, "bf16 direct 4x4 stride-2 conv");
 }
 
+// fp32 partials of a split reduction, behind the packed weights
+static size_t cb_partial_bytes(const CbGeom& g) { return g.nsplit > 1 ? align_up((size_t)g.nsplit * g.B * g.K * g.Hout * g.Wout * sizeof(float), 256) : 0; }
+
+// out[i] = sum over the runs' partials, ascending
+template <typename TOUT>
+__global__ void __launch_bounds__(256) cb_split_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n4, TOUT* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    for (int sI = 1; sI < nsplit; ++sI) {
+        const float4 v = reinterpret_cast<const float4*>(part)[(size_t)sI * n4 + i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    st4(out, i, a);
+}
+
 size_t conv_bf16_ws_bytes(int B, int C, int K, int H, int W)
 {
     CbGeom g;
     if (cb_geometry(B, C, K, H, W, &g) != IPSR_OK) return 0;
-    return 256 + (size_t)g.ktiles * g.nstage * 9 * 2 * g.kt * 16;
+    return 256 + (size_t)g.ktiles * g.nstage * 9 * 2 * g.kt * 16 + cb_partial_bytes(g);
 }
 
 size_t conv_bf16_s2_ws_bytes(int form, int B, int C, int K, int nh, int nw)
 {
     CbGeom g;
     if (cb_geometry_s2(form, B, C, K, nh, nw, &g) != IPSR_OK) return 0;
-    return 256 + (size_t)g.ktiles * g.nphase * g.nstage * 8 * 2 * g.kt * 16;
+    return 256 + (size_t)g.ktiles * g.nphase * g.nstage * 8 * 2 * g.kt * 16 + cb_partial_bytes(g);
 }
 
 template <int MODE, int KT, int P, typename TOUT>
@@ -471,8 +502,15 @@ static int cb_launch(const CbGeom& g, CbPack pk, const void* in, const float* w,
         cb_pack_weights_kernel<<<dim3(cdiv(g.ktiles * g.kt, 256), g.C / 8, pk.ntap * pk.nsub * pk.nphase), 256, 0, st>>>(w, g.C, g.K, sc, sk, pk, Wp, zero_page);
         if (int rc = check_launch("cb_pack_weights_kernel")) return rc;
     }
-    const unsigned grid = (unsigned)(g.ktiles * g.nphase * g.ptiles);
+    const unsigned grid = (unsigned)(g.ktiles * g.nphase * g.ptiles * g.nsplit);
     const size_t smem = 2 * (size_t)(g.a_bytes + g.t_bytes) + (size_t)(g.raw1 ? 1 : 2) * g.raw_bytes;
+    void* final_out = out;
+    const int final_bf16 = out_bf16;
+    if (g.nsplit > 1) {                                       // the runs write fp32 partials behind the packed weights
+        const size_t pack_bytes = (size_t)g.ktiles * g.nphase * g.nstage * pk.ntap * 2 * g.kt * 16;
+        out = reinterpret_cast<unsigned char*>(Wp) + align_up(pack_bytes, 256);
+        out_bf16 = 0;
+    }
     profile_mark_start(st, 4);
     if (g.kt == 64 && g.ptile == 2 * CB_P) {
         if (out_bf16) cb_launch_kernel<MODE, 64, 2 * CB_P, bf16_t>(g, in, Wp, zero_page, out, grid, smem, st);
@@ -485,8 +523,14 @@ static int cb_launch(const CbGeom& g, CbPack pk, const void* in, const float* w,
         else cb_launch_kernel<MODE, 128, CB_P, float>(g, in, Wp, zero_page, out, grid, smem, st);
     }
     const double outs = (double)g.B * g.Hout * g.Wout;
+    if (g.nsplit > 1) {
+        if (int rc = check_launch("conv_bf16_kernel")) return rc;
+        const size_t n = (size_t)g.B * g.K * g.Hout * g.Wout;          // a multiple of 4: Wout is
+        if (final_bf16) cb_split_reduce_kernel<bf16_t><<<(unsigned)cdiv(n / 4, 256), 256, 0, st>>>(static_cast<const float*>(out), g.nsplit, n / 4, static_cast<bf16_t*>(final_out));
+        else cb_split_reduce_kernel<float><<<(unsigned)cdiv(n / 4, 256), 256, 0, st>>>(static_cast<const float*>(out), g.nsplit, n / 4, static_cast<float*>(final_out));
+    }
     profile_mark_stop(st, 4, 2.0 * taps_per_out * g.C * (double)(g.ktiles * g.kt) * outs, 2.0 * taps_per_out * g.C * (double)g.K * outs);
-    return check_launch("conv_bf16_kernel");
+    return check_launch(g.nsplit > 1 ? "cb_split_reduce_kernel" : "conv_bf16_kernel");
 }
 
 // in [B,C,H,W] bf16, weight fp32 with element (c, k, tap) at w[c*sc + k*sk + tap] (taps flipped when `flip`), out [B,K,H,W] bf16 / fp32

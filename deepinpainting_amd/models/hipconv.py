@@ -132,8 +132,8 @@ def _bf16_direct(force, mode, op, B, Cin, H, W, Cout, k, stride, pad, dil):
     every map from 32x32 up; on 16x16 maps MIOpen ties (and the Winograd engines win from 512 channels)."""
     if force == "none" or mode in ("miopen", "winograd", "direct"):
         return "miopen"
-    if k == 3 and stride == 1 and pad == 1 and dil == 1 and H * W >= 1024 and ops.conv3x3_bf16_supported(op, B, Cin, H, W, Cout):
-        return "bf16d"
+    if k == 3 and stride == 1 and pad == 1 and dil == 1 and H * W >= 256 and ops.conv3x3_bf16_supported(op, B, Cin, H, W, Cout):
+        return "bf16d"           # 16x16 maps too since the reduction is cut over workgroups there (0.041-0.063 vs 0.056-0.081 split-Winograd, 0.070-0.122 MIOpen)
     # (measured and not kept: the small-map engine on fp32 copies for the innermost levels beyond 32 positions per batch — 708 images/s at
     # 32, 706 at 64, 696 at 256, 658 at 1024: MIOpen's tiny bf16 convolutions cost 45-60 us per CALL but far less device time)
     g = _s2_geometry(op in (ops.CONVT_FWD, ops.CONVT_BWD_DATA), B, Cin, H, W, Cout, k, stride, pad, dil)
@@ -142,8 +142,10 @@ def _bf16_direct(force, mode, op, B, Cin, H, W, Cout, k, stride, pad, dil):
         # a 16x16 coarse grid gives one pixel tile per image (64 workgroups at 512 channels) and MIOpen ties or wins
         Kc, Cf, nh, nw = g
         if _s2_mode(op) == ops.S2_FINE_TO_COARSE:
+            if nw == 16:                 # one pixel tile per image: the split reduction fills the chip up to 512 produced channels (0.048-0.078 vs MIOpen's
+                return "bf16d" if Kc <= 512 else "miopen"      # 0.083-0.106); 1024 produced channels leave no room to split: 0.098 vs 0.087
             return "bf16d" if nw >= 32 and ((Kc + 127) // 128) * B * nh * nw // 256 >= 128 else "miopen"
-        return "bf16d" if not (nw == 16 and Kc >= 1024) else "miopen"
+        return "bf16d"
     return "miopen"
 
 
@@ -161,9 +163,10 @@ def _bf16_wins(eng, Cin, H, W, Cout, wrw=False):
     if force == "all":
         return True
     if eng == "winograd":
-        # round 4: against the DIRECT bf16 kernel (csrc/conv_bf16.hip, profiles/r04_conv_bf16_layers.txt) the split engines keep the 16x16
-        # maps (0.056-0.080 vs 0.079-0.146 ms); at 32x32 the direct weight gradient ties or wins since its runs were halved (0.068-0.131 vs 0.084-0.126)
-        return H * W <= 256 and max(Cin, Cout) >= 512
+        # round 4: against the DIRECT bf16 kernel (csrc/conv_bf16.hip, profiles/r04_conv_bf16_layers.txt) the split engines keep the WEIGHT
+        # GRADIENTS of the 16x16 maps (0.060-0.084 vs 0.076-0.159 ms); forward / input gradient went to the direct kernel when its reduction
+        # was cut over workgroups; at 32x32 the direct weight gradient ties or wins since its runs were halved (0.068-0.131 vs 0.084-0.126)
+        return wrw and H * W <= 256 and max(Cin, Cout) >= 512
     if eng == "wino_dil":
         return H * W <= 4096 and min(Cin, Cout) >= 256
     return False

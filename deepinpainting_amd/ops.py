@@ -5,6 +5,7 @@ libipsr_hip.so.  All functions require CUDA(HIP) tensors and raise otherwise —
 """
 import contextlib
 import threading
+import weakref
 from collections import namedtuple
 
 import torch
@@ -557,7 +558,19 @@ def conv3x3_bf16_supported(op, B, Cin, H, W, Cout):
     return _lib.lib().ipsr_conv3x3_bf16_workspace_bytes(op, B, Cin, H, W, Cout) > 0
 
 
-_BF16_PACKS = {}          # frozen weights: (data_ptr, op, device) -> (version, shape, buffer holding the re-packed bf16 weights)
+# frozen weights: weight tensor (weakly held) -> {op: (version, shape, buffer holding the re-packed bf16 weights)}.  Keyed by the tensor OBJECT:
+# a storage pointer comes back to life with another tensor's data once the first is freed (two test cases with equal shapes met that way).
+# (id-keyed with a weak reference for liveness: tensors compare elementwise, which rules out a WeakKeyDictionary)
+_BF16_PACKS = {}
+
+
+def _packs_of(weight):
+    ent = _BF16_PACKS.get(id(weight))
+    if ent is None or ent[0]() is not weight:
+        key = id(weight)
+        ent = (weakref.ref(weight, lambda _r, key=key: _BF16_PACKS.pop(key, None)), {})
+        _BF16_PACKS[key] = ent
+    return ent[1]
 
 
 def conv3x3_bf16(op, inp, weight, in_shape, Cout, out_dtype=torch.bfloat16, keep_packed=False):
@@ -584,13 +597,14 @@ def conv3x3_bf16(op, inp, weight, in_shape, Cout, out_dtype=torch.bfloat16, keep
     out = torch.empty((B, Cout if fwd else Cin, H, W), dtype=out_dtype, device=inp.device)
     valid = 0
     if keep_packed:
-        key = (weight.data_ptr(), op, inp.device)
-        ent = _BF16_PACKS.get(key)
-        if ent is not None and ent[0] == weight._version and ent[1] == tuple(weight.shape) and ent[2].numel() >= nbytes:
+        packs = _packs_of(weight)
+        ent = packs.get(op)
+        if ent is not None and ent[0] == (weight._version, weight.data_ptr()) and ent[1] == tuple(weight.shape) and ent[2].numel() >= nbytes \
+                and ent[2].device == inp.device:
             ws, valid = ent[2], 1
         else:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=inp.device)
-            _BF16_PACKS[key] = (weight._version, tuple(weight.shape), ws)
+            packs[op] = ((weight._version, weight.data_ptr()), tuple(weight.shape), ws)
     else:
         ws = _workspace(nbytes, inp.device)
     _lib.check(L.ipsr_conv3x3_bf16_packed(op, inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout, int(out_dtype == torch.bfloat16),

@@ -114,7 +114,9 @@ def test_conv_dispatcher_rules_on_the_host():
     # channels, the 3-channel ends on the stream kernels, MIOpen for what nothing here expresses
     assert sel(ops.CONV_FWD, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d" and wrw(False, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d"
     assert sel(ops.CONV_FWD, 16, 64, 256, 256, 64, 3, 1, 1, 1, True) == "bf16d"           # VGG conv1_2: the 64-row kernel, 512-pixel tile
-    assert sel(ops.CONV_FWD, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"
+    assert sel(ops.CONV_FWD, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "bf16d" and wrw(False, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"   # 16x16: split reduction
+    assert sel(ops.CONV_FWD, 16, 256, 32, 32, 512, 4, 2, 1, 1, True) == "bf16d" and sel(ops.CONVT_FWD, 16, 1024, 16, 16, 256, 4, 2, 1, 1, True) == "bf16d"
+    assert sel(ops.CONVT_BWD_DATA, 16, 1024, 16, 16, 256, 4, 2, 1, 1, True) == "miopen"                                                                    # 1024 produced: no room
     assert sel(ops.CONVT_FWD, 16, 512, 32, 32, 128, 4, 2, 1, 1, True) == "bf16d" and wrw(True, 16, 512, 32, 32, 128, 4, 2, 1, 1, True) == "bf16d"
     assert sel(ops.CONV_FWD, 16, 3, 256, 256, 64, 3, 1, 1, 1, True) == "thin"              # VGG conv1_1
     assert sel(ops.CONVT_BWD_DATA, 16, 128, 256, 256, 3, 3, 1, 1, 1, True) == "thin"       # the last ConvTranspose2d's input gradient (3 -> 128)

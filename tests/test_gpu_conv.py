@@ -687,7 +687,8 @@ def test_every_engine_call_of_a_training_step_checked_in_situ(tmp_path):
 
 
 @pytest.mark.parametrize("tr,Cin,H,W,Cout,B", [(False, 32, 16, 16, 48, 2), (False, 128, 32, 32, 160, 3), (True, 64, 32, 64, 48, 2), (False, 16, 128, 128, 16, 1),
-                                               (True, 256, 8, 32, 304, 2), (False, 64, 64, 64, 64, 2), (True, 144, 64, 16, 208, 1), (False, 512, 32, 32, 512, 16), (False, 64, 256, 256, 64, 1), (True, 32, 4, 256, 16, 2)])
+                                               (True, 256, 8, 32, 304, 2), (False, 64, 64, 64, 64, 2), (True, 144, 64, 16, 208, 1), (False, 512, 32, 32, 512, 16), (False, 64, 256, 256, 64, 1), (True, 32, 4, 256, 16, 2),
+                                               (False, 256, 16, 16, 256, 2), (True, 512, 16, 16, 272, 3)])          # (the last two: reduction cut into four runs)
 def test_direct_bf16_conv_all_passes(tr, Cin, H, W, Cout, B):
     """csrc/conv_bf16.hip (BASELINE config 5): the k3 s1 p1 layers as direct implicit GEMMs on v_mfma_f32_32x32x16_bf16 — forward, input
     gradient (bf16 and fp32 outputs) and weight gradient — against fp64 of the SAME bf16-rounded operands: what is left is the fp32
@@ -729,7 +730,8 @@ def test_direct_bf16_conv_all_passes(tr, Cin, H, W, Cout, B):
         ops.conv3x3_bf16(fop, torch.zeros(1, 16, 12, 24, device="cuda", dtype=torch.bfloat16), torch.zeros((16, 16, 3, 3), device="cuda"), (1, 16, 12, 24), 16)
 
 
-@pytest.mark.parametrize("Kc,Cf,nh,nw,B", [(128, 64, 64, 64, 2), (48, 32, 16, 16, 3), (256, 128, 16, 32, 2), (200, 16, 32, 32, 1), (64, 64, 4, 64, 2), (512, 128, 32, 32, 16)])
+@pytest.mark.parametrize("Kc,Cf,nh,nw,B", [(128, 64, 64, 64, 2), (48, 32, 16, 16, 3), (256, 128, 16, 32, 2), (200, 16, 32, 32, 1), (64, 64, 4, 64, 2), (512, 128, 32, 32, 16),
+                                           (256, 256, 16, 16, 2), (272, 512, 16, 16, 3)])                                # (the last two: split reductions)
 def test_direct_bf16_stride2_family(Kc, Cf, nh, nw, B):
     """The k4 s2 p1 layers on the direct bf16 kernels: fine -> coarse (Conv2d forward / ConvTranspose2d input gradient: the input row
     parity is a sub-stage, the column parities two planes of the LDS image) and coarse -> fine (ConvTranspose2d forward / Conv2d input
@@ -787,7 +789,7 @@ def test_direct_bf16_conv_through_the_modules_under_autocast():
     finally:
         hipconv._check_hook = None
     assert seen.count(("forward", "bf16d")) == 4 and seen.count(("input_grad", "bf16d")) == 4 and seen.count(("weight_grad", "bf16d")) == 4, seen
-    assert hipconv.select(ops.CONV_FWD, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"          # where split-bf16 Winograd still wins
+    assert hipconv.select(ops.CONV_FWD, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "bf16d"             # 16x16: the direct kernel with its reduction cut over workgroups
     assert hipconv.select(ops.CONV_FWD, 16, 512, 32, 32, 512, 3, 1, 1, 1, True) == "bf16d" and hipconv.select_wrw(False, 16, 512, 16, 16, 512, 3, 1, 1, 1, True) == "winograd"
     assert hipconv.select(ops.CONV_FWD, 16, 128, 128, 128, 128, 3, 1, 1, 1, True) == "bf16d"
     assert hipconv.select_wrw(False, 16, 64, 128, 128, 128, 3, 1, 1, 1, True) == "bf16d" and hipconv.select_wrw(False, 16, 64, 256, 256, 64, 3, 1, 1, 1, True) == "miopen"
